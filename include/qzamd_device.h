@@ -1,0 +1,75 @@
+/*
+ * qzamd_device.h — device-resident C ABI of the MI355X backend (libqatzip_amd.so).
+ *
+ * This is the layer that takes the place of the QAT driver calls on the
+ * reference's hot path: where src/qatzip.c:1542 submits one hw_buff_sz chunk with
+ * cpaDcCompressData2() and src/qatzip.c:1633 polls it back, the MI355X backend
+ * submits ALL chunks of a call as one batch of workgroups.  Pointers prefixed d_
+ * are device (HBM) pointers, h_ are host pointers; sizes are plain integers; no
+ * torch / C++ types cross this boundary.  The qatzip.h API (include/qatzip.h) is
+ * implemented on top of it in qatzip_amd/csrc/qz_api.cpp; bench.py and the GPU
+ * parity tests also call it directly with buffers already resident in HBM.
+ *
+ * All functions return 0 on success or a negative QZD_* code.  They are
+ * synchronous with respect to the host (they return after the work finished)
+ * unless stated otherwise.
+ */
+#ifndef QZAMD_DEVICE_H
+#define QZAMD_DEVICE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QZD_OK 0
+#define QZD_ERR_PARAM (-1)
+#define QZD_ERR_HIP (-2)
+#define QZD_ERR_DSTCAP (-3)      /* destination too small (maps to QZ_BUF_ERROR / QZ_FAIL) */
+#define QZD_ERR_DATA (-4)        /* corrupt compressed input (maps to QZ_DATA_ERROR) */
+#define QZD_ERR_UNSUPPORTED (-5)
+
+typedef struct qzd_ctx qzd_ctx;
+
+/* one context per (host thread, GPU); owns streams + scratch HBM */
+int qzd_create(int device, qzd_ctx **ctx);
+void qzd_destroy(qzd_ctx *ctx);
+const char *qzd_last_error(qzd_ctx *ctx);
+int qzd_device_count(void);
+
+/* plain HBM / pinned-host memory helpers (replace qaeMemAllocNUMA, src/qatzip_mem.c:169-224) */
+void *qzd_dev_alloc(qzd_ctx *ctx, size_t n);
+void qzd_dev_free(qzd_ctx *ctx, void *d_p);
+int qzd_h2d(qzd_ctx *ctx, void *d_dst, const void *h_src, size_t n);
+int qzd_d2h(qzd_ctx *ctx, void *h_dst, const void *d_src, size_t n);
+void *qzd_host_alloc_pinned(size_t n);
+void qzd_host_free_pinned(void *p);
+
+/*
+ * Raw-deflate `n` bytes at d_src exactly as the reference's software path does
+ * for one qzCompress() call (src/qatzip_sw.c:178-231): independent chunks of
+ * chunk_sz bytes, zlib level `level` (1 only in round 1), every chunk closed by
+ * the Z_FULL_FLUSH marker except — when last != 0 — the final one, which
+ * carries BFINAL.  n == 0 emits the single empty final block (last) or the
+ * bare marker.  The stream is written contiguously to d_dst.
+ *   h_out_len    <- stream length
+ *   h_chunk_crc  <- (optional) CRC-32 of every input chunk, nchunks entries
+ * d_src must be readable for n bytes; d_dst needs dst_cap bytes.
+ */
+int qzd_deflate_raw(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
+                    uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_chunk_crc);
+
+/* asynchronous flavour used by bench.py: enqueue only; qzd_sync() + qzd_result() finish it */
+int qzd_deflate_raw_async(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
+                          uint8_t *d_dst, uint64_t dst_cap);
+int qzd_sync(qzd_ctx *ctx);
+int qzd_result(qzd_ctx *ctx, uint64_t *h_out_len, uint32_t *h_chunk_crc, uint32_t nchunks);
+
+/* elapsed GPU time (ms) of the kernels of the last *_async call, per kernel family, measured
+ * with hipEvents on the stream the kernels ran on: [0]=lz77 [1]=huffman [2]=scan+gather [3]=total */
+int qzd_last_timing(qzd_ctx *ctx, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

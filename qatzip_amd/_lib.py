@@ -1,0 +1,141 @@
+"""ctypes view of libqatzip_amd.so's device-resident C ABI (include/qzamd_device.h).
+
+There is deliberately no fallback: if the HIP library is missing or no GPU is present
+the constructors raise.  (The CPU oracle lives under oracle/ and is test-only.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+
+class QzdError(RuntimeError):
+    pass
+
+
+def load(build_if_missing=True):
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = _build.SO
+    if not os.path.exists(so):
+        if not build_if_missing:
+            raise QzdError("libqatzip_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        _build.build()
+    L = C.CDLL(so)
+    vp, u8p = C.c_void_p, C.c_void_p
+    L.qzd_device_count.restype = C.c_int
+    L.qzd_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.qzd_destroy.argtypes = [vp]
+    L.qzd_last_error.argtypes = [vp]; L.qzd_last_error.restype = C.c_char_p
+    L.qzd_dev_alloc.argtypes = [vp, C.c_size_t]; L.qzd_dev_alloc.restype = vp
+    L.qzd_dev_free.argtypes = [vp, vp]
+    L.qzd_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.qzd_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.qzd_deflate_raw.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, u8p, C.c_uint64,
+                                  C.POINTER(C.c_uint64), vp]
+    L.qzd_deflate_raw_async.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, u8p, C.c_uint64]
+    L.qzd_sync.argtypes = [vp]
+    L.qzd_result.argtypes = [vp, C.POINTER(C.c_uint64), vp, C.c_uint32]
+    L.qzd_last_timing.argtypes = [vp, C.POINTER(C.c_float * 4)]
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names include/*.h declares that must be exported by the library (checked on CPU too)."""
+    return ["qzd_create", "qzd_destroy", "qzd_last_error", "qzd_device_count", "qzd_dev_alloc", "qzd_dev_free",
+            "qzd_h2d", "qzd_d2h", "qzd_host_alloc_pinned", "qzd_host_free_pinned", "qzd_deflate_raw",
+            "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing"]
+
+
+class DevBuf:
+    """A plain HBM allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        self.ptr = ctx.L.qzd_dev_alloc(ctx.h, self.nbytes + 512)   # slack: kernels may look a few bytes ahead
+        if not self.ptr:
+            raise QzdError("hipMalloc failed for %d bytes" % nbytes)
+
+    def upload(self, data, offset=0):
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1)
+        assert offset + a.size <= self.nbytes
+        if a.size:
+            a = np.ascontiguousarray(a)
+            self.ctx._chk(self.ctx.L.qzd_h2d(self.ctx.h, self.ptr + offset, a.ctypes.data, a.size))
+
+    def download(self, n=None, offset=0):
+        n = self.nbytes - offset if n is None else int(n)
+        out = np.empty(n, np.uint8)
+        if n:
+            self.ctx._chk(self.ctx.L.qzd_d2h(self.ctx.h, out.ctypes.data, self.ptr + offset, n))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.qzd_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """qzd_ctx wrapper: one per (process, GPU)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        if self.L.qzd_device_count() <= 0:
+            raise QzdError("no HIP device visible: the MI355X backend has no CPU fallback")
+        h = C.c_void_p()
+        rc = self.L.qzd_create(device, C.byref(h))
+        if rc != 0:
+            raise QzdError("qzd_create failed rc=%d" % rc)
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise QzdError("rc=%d: %s" % (rc, self.L.qzd_last_error(self.h).decode()))
+
+    def alloc(self, n):
+        return DevBuf(self, n)
+
+    def close(self):
+        if self.h:
+            self.L.qzd_destroy(self.h)
+            self.h = None
+
+    # -- deflate
+    def deflate_raw(self, d_src, n, chunk_sz=65536, level=1, last=1, d_dst=None, want_crc=True):
+        """-> (out_len, crc array or None)"""
+        nchunks = max(1, (n + chunk_sz - 1) // chunk_sz)
+        out_len = C.c_uint64(0)
+        crcs = np.zeros(nchunks, np.uint32) if want_crc else None
+        self._chk(self.L.qzd_deflate_raw(self.h, d_src.ptr, n, chunk_sz, level, last, d_dst.ptr, d_dst.nbytes,
+                                         C.byref(out_len), crcs.ctypes.data if want_crc else None))
+        return out_len.value, crcs
+
+    def deflate_raw_async(self, d_src, n, chunk_sz, level, last, d_dst):
+        self._chk(self.L.qzd_deflate_raw_async(self.h, d_src.ptr, n, chunk_sz, level, last, d_dst.ptr, d_dst.nbytes))
+
+    def sync(self):
+        self._chk(self.L.qzd_sync(self.h))
+
+    def result(self):
+        out_len = C.c_uint64(0)
+        self._chk(self.L.qzd_result(self.h, C.byref(out_len), None, 0))
+        return out_len.value
+
+    def timing(self):
+        ms = (C.c_float * 4)()
+        self.L.qzd_last_timing(self.h, C.byref(ms))
+        return list(ms)
+
+
+def max_deflate_len(n, chunk_sz=65536):
+    """worst-case raw stream size for n bytes (stored blocks + markers)"""
+    nchunks = max(1, (n + chunk_sz - 1) // chunk_sz)
+    return n + nchunks * (5 * (chunk_sz // 32767 + 2) + 16) + 64

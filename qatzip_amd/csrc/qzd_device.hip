@@ -1,0 +1,296 @@
+/*
+ * qzd_device.hip — host side of the device-resident C ABI (include/qzamd_device.h)
+ * and the small utility kernels (size scan, slot gather).  gfx950 only.
+ *
+ * A call is cut into batches of QZD_BATCH chunks.  Per batch, on one stream:
+ *   K1 qzk_lz77_kernel  (1 wave / chunk, 132 KiB LDS => one workgroup per CU)
+ *   K2 qzk_huff_kernel  (256 threads / chunk) -> per-chunk slot + length + crc32
+ *   scan of the lengths (running total carried in HBM, no host round trip)
+ *   gather of the slots into the contiguous destination
+ * Scratch (symbols, slots) is double-buffered and batches alternate between two
+ * streams, so K1 of batch b+1 (latency-bound, 1 wave per CU) overlaps K2/gather of
+ * batch b (which co-reside on the same CUs: they need < 16 KiB LDS).
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/qzamd_device.h"
+#include "qzk_deflate_lz77.h"
+#include "qzk_deflate_huff.h"
+
+#define QZD_BATCH 2048u
+#define QZD_NBUF 2
+
+/* ------------------------------------------------------------------ utility kernels */
+/* offs[i] = *running + sum(len[0..i)); then *running += sum.  One 1024-thread workgroup. */
+__global__ void qzk_scan_kernel(const uint32_t *len, uint32_t nchunks, uint64_t *offs, uint64_t *running)
+{
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x, per = (nchunks + 1023) / 1024;
+    uint32_t b = t * per, e = b + per;
+    if (b > nchunks) b = nchunks;
+    if (e > nchunks) e = nchunks;
+    uint64_t s = 0;
+    for (uint32_t i = b; i < e; i++) s += len[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t base = *running + part[t] - s;
+    for (uint32_t i = b; i < e; i++) { offs[i] = base; base += len[i]; }
+    __syncthreads();
+    if (t == 1023) *running += part[1023];
+}
+
+/* copy slot i (len[i] bytes) to dst + offs[i]; flag overflow instead of writing past cap */
+__global__ void qzk_gather_kernel(const uint8_t *slots, uint32_t stride, const uint32_t *len, const uint64_t *offs,
+                                  uint32_t nchunks, uint8_t *dst, uint64_t cap, uint32_t *overflow)
+{
+    const uint32_t c = blockIdx.x;
+    if (c >= nchunks) return;
+    const uint8_t *s = slots + (uint64_t)c * stride;
+    const uint32_t n = len[c];
+    const uint64_t o = offs[c];
+    if (o + n > cap) { if (threadIdx.x == 0) atomicOr(overflow, 1u); return; }
+    uint8_t *d = dst + o;
+    const uint32_t nw = n >> 2;
+    for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x)
+        ((qz_u32u *)d)[i].v = ((const uint32_t *)s)[i];
+    for (uint32_t i = (nw << 2) + threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+}
+
+/* ------------------------------------------------------------------ context */
+struct qzd_ctx {
+    int device;
+    hipStream_t st[QZD_NBUF];
+    hipEvent_t done[QZD_NBUF];
+    /* scratch per buffer set */
+    uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];
+    qzk_lzmeta *meta[QZD_NBUF];
+    size_t sym_cap, slot_cap; uint32_t meta_cap;
+    /* per-call arrays */
+    uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;
+    uint64_t *d_running; uint32_t *d_overflow;
+    uint64_t *h_running; uint32_t *h_overflow;      /* pinned */
+    /* timing */
+    hipEvent_t ev[QZD_NBUF][4]; hipEvent_t ev_begin, ev_end;
+    uint32_t nbatches; float ms[4];
+    uint32_t last_nchunks;
+    char err[256];
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+    return QZD_ERR_HIP; } } while (0)
+
+extern "C" int qzd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int qzd_create(int device, qzd_ctx **out)
+{
+    if (!out) return QZD_ERR_PARAM;
+    *out = NULL;
+    if (hipSetDevice(device) != hipSuccess) return QZD_ERR_HIP;
+    qzd_ctx *c = new (std::nothrow) qzd_ctx();
+    if (!c) return QZD_ERR_HIP;
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    for (int i = 0; i < QZD_NBUF; i++) {
+        if (hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking) != hipSuccess) return QZD_ERR_HIP;
+        hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+        for (int k = 0; k < 4; k++) hipEventCreate(&c->ev[i][k]);
+    }
+    hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
+    if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) return QZD_ERR_HIP;
+    hipHostMalloc((void **)&c->h_running, 8, hipHostMallocDefault);
+    hipHostMalloc((void **)&c->h_overflow, 4, hipHostMallocDefault);
+    *out = c;
+    return QZD_OK;
+}
+
+extern "C" void qzd_destroy(qzd_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (int i = 0; i < QZD_NBUF; i++) {
+        hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
+        hipStreamDestroy(c->st[i]); hipEventDestroy(c->done[i]);
+        for (int k = 0; k < 4; k++) hipEventDestroy(c->ev[i][k]);
+    }
+    hipEventDestroy(c->ev_begin); hipEventDestroy(c->ev_end);
+    hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
+    hipHostFree(c->h_running); hipHostFree(c->h_overflow);
+    delete c;
+}
+
+extern "C" const char *qzd_last_error(qzd_ctx *c) { return c ? c->err : "no context"; }
+
+extern "C" void *qzd_dev_alloc(qzd_ctx *c, size_t n)
+{
+    void *p = NULL;
+    if (c) hipSetDevice(c->device);
+    if (hipMalloc(&p, n ? n : 1) != hipSuccess) return NULL;
+    return p;
+}
+extern "C" void qzd_dev_free(qzd_ctx *c, void *p) { if (c) hipSetDevice(c->device); if (p) hipFree(p); }
+extern "C" int qzd_h2d(qzd_ctx *c, void *d, const void *h, size_t n)
+{
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpy(d, h, n, hipMemcpyHostToDevice));
+    return QZD_OK;
+}
+extern "C" int qzd_d2h(qzd_ctx *c, void *h, const void *d, size_t n)
+{
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+    return QZD_OK;
+}
+extern "C" void *qzd_host_alloc_pinned(size_t n)
+{
+    void *p = NULL;
+    if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return NULL;
+    return p;
+}
+extern "C" void qzd_host_free_pinned(void *p) { if (p) hipHostFree(p); }
+
+static uint32_t slot_stride_for(uint32_t chunk_sz) { return (chunk_sz / 8u * 9u + 1024u + 15u) & ~15u; }
+
+static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
+{
+    uint32_t batch = nchunks < QZD_BATCH ? nchunks : QZD_BATCH;
+    size_t sym = (size_t)batch * chunk_sz + 256, slot = (size_t)batch * slot_stride_for(chunk_sz);
+    if (sym > c->sym_cap || slot > c->slot_cap || batch > c->meta_cap) {
+        hipDeviceSynchronize();
+        for (int i = 0; i < QZD_NBUF; i++) {
+            hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
+            c->sym_lc[i] = NULL; c->sym_dist[i] = NULL; c->slots[i] = NULL; c->meta[i] = NULL;
+            HIPCHK(c, hipMalloc(&c->sym_lc[i], sym));
+            HIPCHK(c, hipMalloc(&c->sym_dist[i], sym * 2));
+            HIPCHK(c, hipMalloc(&c->slots[i], slot));
+            HIPCHK(c, hipMalloc(&c->meta[i], (size_t)batch * sizeof(qzk_lzmeta)));
+        }
+        c->sym_cap = sym; c->slot_cap = slot; c->meta_cap = batch;
+    }
+    if (nchunks > c->call_cap) {
+        hipDeviceSynchronize();
+        hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs);
+        c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL;
+        HIPCHK(c, hipMalloc(&c->d_len, (size_t)nchunks * 4));
+        HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nchunks * 4));
+        HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nchunks * 8));
+        c->call_cap = nchunks;
+    }
+    return QZD_OK;
+}
+
+extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
+                                     int last, uint8_t *d_dst, uint64_t dst_cap)
+{
+    if (!c || !d_dst || (n && !d_src)) return QZD_ERR_PARAM;
+    if (chunk_sz < 1024 || chunk_sz > 512 * 1024 || (chunk_sz & (chunk_sz - 1))) return QZD_ERR_PARAM;
+    if (level != 1) { snprintf(c->err, sizeof(c->err), "deflate level %d not implemented on the GPU path (level 1 only)", level); return QZD_ERR_UNSUPPORTED; }
+    if (n > ((uint64_t)1 << 32)) return QZD_ERR_PARAM;
+    hipSetDevice(c->device);
+    const uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
+    int rc = ensure_scratch(c, chunk_sz, nchunks);
+    if (rc) return rc;
+    const uint32_t stride = slot_stride_for(chunk_sz);
+    c->last_nchunks = nchunks;
+    c->nbatches = (nchunks + QZD_BATCH - 1) / QZD_BATCH;
+
+    HIPCHK(c, hipMemsetAsync(c->d_running, 0, 8, c->st[0]));
+    HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, c->st[0]));
+    HIPCHK(c, hipEventRecord(c->ev_begin, c->st[0]));
+    HIPCHK(c, hipEventRecord(c->done[0], c->st[0]));
+    HIPCHK(c, hipStreamWaitEvent(c->st[1], c->done[0], 0));
+
+    for (uint32_t b = 0, k = 0; b < nchunks; b += QZD_BATCH, k++) {
+        const int s = (int)(k % QZD_NBUF), so = (int)((k + 1) % QZD_NBUF);
+        const uint32_t bn = nchunks - b < QZD_BATCH ? nchunks - b : QZD_BATCH;
+        const uint64_t boff = (uint64_t)b * chunk_sz;
+        const uint64_t blen = n - boff;      /* bytes from this batch's first chunk to the end of the call */
+        const uint32_t final_chunk = (last && b + bn == nchunks) ? bn - 1 : ~0u;
+        hipStream_t st = c->st[s];
+        const bool timed = k < QZD_NBUF;     /* events of the first use of each buffer set */
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
+        hipLaunchKernelGGL(qzk_lz77_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn,
+                           c->sym_lc[s], c->sym_dist[s], c->meta[s]);
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
+        hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn,
+                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->slots[s], stride, final_chunk,
+                           c->d_len + b, c->d_crc + b);
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[s][2], st));
+        /* the running total serialises scan/gather of consecutive batches across the two streams */
+        if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->done[so], 0));
+        hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);
+        hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, c->slots[s], stride, c->d_len + b,
+                           c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[s][3], st));
+        HIPCHK(c, hipEventRecord(c->done[s], st));
+    }
+    /* join: stream 0 waits for stream 1, then publishes the totals */
+    HIPCHK(c, hipStreamWaitEvent(c->st[0], c->done[1], 0));
+    HIPCHK(c, hipStreamWaitEvent(c->st[0], c->done[0], 0));
+    HIPCHK(c, hipMemcpyAsync(c->h_running, c->d_running, 8, hipMemcpyDeviceToHost, c->st[0]));
+    HIPCHK(c, hipMemcpyAsync(c->h_overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, c->st[0]));
+    HIPCHK(c, hipEventRecord(c->ev_end, c->st[0]));
+    HIPCHK(c, hipGetLastError());
+    return QZD_OK;
+}
+
+extern "C" int qzd_sync(qzd_ctx *c)
+{
+    if (!c) return QZD_ERR_PARAM;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->st[0]));
+    HIPCHK(c, hipStreamSynchronize(c->st[1]));
+    return QZD_OK;
+}
+
+extern "C" int qzd_result(qzd_ctx *c, uint64_t *h_out_len, uint32_t *h_chunk_crc, uint32_t nchunks)
+{
+    if (!c) return QZD_ERR_PARAM;
+    if (*c->h_overflow) { snprintf(c->err, sizeof(c->err), "destination too small"); return QZD_ERR_DSTCAP; }
+    if (h_out_len) *h_out_len = *c->h_running;
+    if (h_chunk_crc) {
+        if (nchunks > c->last_nchunks) nchunks = c->last_nchunks;
+        HIPCHK(c, hipMemcpy(h_chunk_crc, c->d_crc, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
+    }
+    return QZD_OK;
+}
+
+extern "C" int qzd_deflate_raw(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
+                               uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_chunk_crc)
+{
+    int rc = qzd_deflate_raw_async(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap);
+    if (rc) return rc;
+    rc = qzd_sync(c);
+    if (rc) return rc;
+    return qzd_result(c, h_out_len, h_chunk_crc, c->last_nchunks);
+}
+
+extern "C" int qzd_last_timing(qzd_ctx *c, float ms[4])
+{
+    if (!c || !ms) return QZD_ERR_PARAM;
+    float t = 0;
+    ms[0] = ms[1] = ms[2] = ms[3] = 0;
+    uint32_t nb = c->nbatches < QZD_NBUF ? c->nbatches : QZD_NBUF;
+    for (uint32_t s = 0; s < nb; s++)
+        for (int k = 0; k < 3; k++) {
+            if (hipEventElapsedTime(&t, c->ev[s][k], c->ev[s][k + 1]) == hipSuccess) ms[k] += t;
+        }
+    if (hipEventElapsedTime(&t, c->ev_begin, c->ev_end) == hipSuccess) ms[3] = t;
+    return QZD_OK;
+}

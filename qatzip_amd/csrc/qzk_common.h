@@ -1,0 +1,58 @@
+/*
+ * qzk_common.h — device-side vocabulary shared by the gfx950 kernels.
+ *
+ * The kernels are written for CDNA4 wave64 and only ever built for the GPU by
+ * hipcc --offload-arch=gfx950.  The single `QZ_SIM` switch below exists for the
+ * test suite: tests/sim/ compiles the same kernel bodies with g++ on top of a
+ * fiber-based SIMT emulator (tests/sim/hipsim.h) so that bit-exactness can be
+ * fuzzed in a container without a GPU.  It is not a second backend.
+ */
+#ifndef QZK_COMMON_H
+#define QZK_COMMON_H
+#include <stdint.h>
+
+#ifdef QZ_SIM
+#include "hipsim.h"
+#define QZ_DEV static inline
+#define QZ_KERNEL static void
+#define QZ_LDS static
+#define QZ_CONST static const
+#else
+#include <hip/hip_runtime.h>
+#define QZ_DEV static __device__ __forceinline__
+#define QZ_KERNEL __global__ void
+#define QZ_LDS __shared__
+#define QZ_CONST static __device__ const
+
+QZ_DEV uint64_t qz_ballot(bool p) { return __ballot(p); }
+QZ_DEV uint32_t qz_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+QZ_DEV uint32_t qz_readlane(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+QZ_DEV uint32_t qz_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+/* orders LDS traffic between the lanes of ONE wave (single-wave workgroups) */
+QZ_DEV void qz_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+QZ_DEV void qz_block_sync() { __syncthreads(); }
+QZ_DEV int qz_lane() { return (int)(threadIdx.x & 63); }
+#endif
+
+QZ_DEV int qz_popc64(uint64_t v) { return __builtin_popcountll(v); }
+QZ_DEV int qz_ctz64(uint64_t v) { return __builtin_ctzll(v); }      /* v != 0 */
+QZ_DEV int qz_ctz32(uint32_t v) { return __builtin_ctz(v); }        /* v != 0 */
+QZ_DEV int qz_msb64(uint64_t v) { return 63 - __builtin_clzll(v); } /* v != 0 */
+QZ_DEV uint64_t qz_below(int l) { return l >= 64 ? ~0ull : ((1ull << l) - 1); } /* bits < l */
+
+/* little-endian loads at arbitrary byte alignment (gfx950 global memory takes
+ * unaligned dword accesses; the packed type lets the compiler choose) */
+typedef struct __attribute__((packed, aligned(1))) { uint32_t v; } qz_u32u;
+typedef struct __attribute__((packed, aligned(1))) { uint16_t v; } qz_u16u;
+QZ_DEV uint32_t qz_ld32(const uint8_t *p) { return ((const qz_u32u *)p)->v; }
+QZ_DEV uint32_t qz_ld16(const uint8_t *p) { return ((const qz_u16u *)p)->v; }
+
+/* wave-uniform value forwarded through an SGPR (helps hipcc scalarise loops) */
+QZ_DEV uint32_t qz_uniform(uint32_t v) { return qz_readfirstlane(v); }
+
+#endif

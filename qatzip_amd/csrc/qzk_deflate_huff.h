@@ -1,0 +1,504 @@
+/*
+ * qzk_deflate_huff.h — K2: zlib-exact block coding (trees.c behaviour) of the
+ * symbol stream K1 produced, one chunk per 256-thread workgroup, gfx950; plus
+ * the chunk's CRC32 (K6) since the chunk is being touched anyway.
+ *
+ * Replaces, on the reference's software path, the _tr_flush_block() half of
+ * zlib's deflate() (src/qatzip_sw.c:197) and the running crc32 zlib keeps for
+ * the gzip trailer; CPU restatement: oracle/qzo_deflate.c (flush_block & co).
+ *
+ * Per block (<= 32767 symbols): parallel histogram (LDS atomics) -> lane 0
+ * builds the three Huffman trees with zlib's exact heap order / tie-break /
+ * overflow repair, RLE-codes the code lengths, and picks stored / fixed /
+ * dynamic with zlib's byte-count rule -> all 256 lanes turn symbols into bit
+ * strings, a workgroup prefix-sum gives every symbol its bit offset, and the
+ * bits are OR-ed into an LDS staging tile that is flushed as whole bytes.
+ * The chunk ends with the Z_FULL_FLUSH marker (000 + pad + 00 00 FF FF) or,
+ * for the last chunk of a stream, BFINAL + byte padding.
+ */
+#ifndef QZK_DEFLATE_HUFF_H
+#define QZK_DEFLATE_HUFF_H
+#include "qzk_common.h"
+#include "qzk_deflate_lz77.h"
+
+#define QZK_HT 256                 /* threads per workgroup */
+#define QZK_LCODES 286
+#define QZK_DCODES 30
+#define QZK_BLCODES 19
+#define QZK_HEAP 573
+
+typedef struct {
+    /* frequencies (u32 for LDS atomics) */
+    uint32_t fl[288], fd[32], fbl[20];
+    /* tree-build scratch (lane 0) */
+    uint32_t heap[QZK_HEAP + 3];       /* freq<<15 | depth<<10 | node */
+    uint16_t order[QZK_HEAP + 3];
+    uint16_t dad[QZK_HEAP + 3];
+    uint16_t nfreq[QZK_HEAP + 3];
+    uint8_t len_l[QZK_HEAP + 3], len_d[64], len_bl[40];
+    uint16_t bl_count[16];
+    /* code tables: code | len<<16 */
+    uint32_t code_l[288], code_d[32], code_bl[20];
+    /* dynamic header bits */
+    uint32_t hdr[320]; uint32_t hbits;
+    /* decisions */
+    uint32_t btype, max_l, max_d;
+    /* output staging */
+    uint32_t stage[420];
+    uint32_t scan[8];
+    uint32_t crc_tab[256];
+    uint32_t x2n[32];
+    uint32_t red[8];
+} qzk_huff_lds;
+
+QZ_DEV uint32_t qzk_bitrev(uint32_t code, int len)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < len; i++) { r = (r << 1) | (code & 1); code >>= 1; }
+    return r;
+}
+
+/* ------------------------------------------------------------------ lane-0 tree code */
+#define QZK_SMALLER(a, b) (((a) >> 10) <= ((b) >> 10))
+
+QZ_DEV void qzk_pqdown(uint32_t *heap, int heap_len, int k)
+{
+    uint32_t v = heap[k];
+    int j = k << 1;
+    while (j <= heap_len) {
+        if (j < heap_len && QZK_SMALLER(heap[j + 1], heap[j])) j++;
+        if (QZK_SMALLER(v, heap[j])) break;
+        heap[k] = heap[j]; k = j; j <<= 1;
+    }
+    heap[k] = v;
+}
+
+/* zlib build_tree(): freq[] -> len[] (and codes).  Returns max_code.  Adds to *opt / *stat. */
+QZ_DEV int qzk_build_tree(qzk_huff_lds *S, uint32_t *freq, uint8_t *len, uint32_t *codes, int elems,
+                          int max_length, int stype /*0 l,1 d,2 bl*/, uint32_t *opt, uint32_t *stat)
+{
+    uint32_t *heap = S->heap; uint16_t *order = S->order, *dad = S->dad, *nf = S->nfreq;
+    int heap_len = 0, heap_max = QZK_HEAP, max_code = -1, n, m, node;
+
+    for (n = 0; n < elems; n++) {
+        nf[n] = (uint16_t)freq[n];
+        if (freq[n] != 0) { heap[++heap_len] = (freq[n] << 15) | (uint32_t)n; max_code = n; }
+        else len[n] = 0;
+    }
+    while (heap_len < 2) {
+        node = max_code < 2 ? ++max_code : 0;
+        heap[++heap_len] = (1u << 15) | (uint32_t)node;
+        nf[node] = 1; freq[node] = 1;
+        (*opt)--;
+        if (stype == 0) *stat -= (node < 144 ? 8 : node < 256 ? 9 : node < 280 ? 7 : 8);
+        else if (stype == 1) *stat -= 5;
+    }
+    for (n = heap_len / 2; n >= 1; n--) qzk_pqdown(heap, heap_len, n);
+    node = elems;
+    do {
+        uint32_t a = heap[1], b;
+        heap[1] = heap[heap_len--];
+        qzk_pqdown(heap, heap_len, 1);
+        b = heap[1];
+        n = (int)(a & 1023); m = (int)(b & 1023);
+        order[--heap_max] = (uint16_t)n; order[--heap_max] = (uint16_t)m;
+        {
+            uint32_t f = (a >> 15) + (b >> 15);
+            uint32_t da = (a >> 10) & 31, db = (b >> 10) & 31, d = (da >= db ? da : db) + 1;
+            nf[node] = (uint16_t)f;
+            dad[n] = dad[m] = (uint16_t)node;
+            heap[1] = (f << 15) | (d << 10) | (uint32_t)node;
+        }
+        node++;
+        qzk_pqdown(heap, heap_len, 1);
+    } while (heap_len >= 2);
+    order[--heap_max] = (uint16_t)(heap[1] & 1023);
+
+    /* gen_bitlen */
+    {
+        int h, bits, overflow = 0;
+        uint16_t *blc = S->bl_count;
+        for (bits = 0; bits <= 15; bits++) blc[bits] = 0;
+        len[order[heap_max]] = 0;
+        for (h = heap_max + 1; h < QZK_HEAP; h++) {
+            int xbits = 0;
+            n = order[h];
+            bits = len[dad[n]] + 1;
+            if (bits > max_length) bits = max_length, overflow++;
+            len[n] = (uint8_t)bits;
+            if (n > max_code) continue;
+            blc[bits]++;
+            if (stype == 0) { if (n >= 265 && n < 285) xbits = (n - 261) >> 2; }
+            else if (stype == 1) { if (n >= 4) xbits = (n >> 1) - 1; }
+            else { xbits = n == 16 ? 2 : n == 17 ? 3 : n == 18 ? 7 : 0; }
+            *opt += (uint32_t)nf[n] * (uint32_t)(bits + xbits);
+            if (stype == 0) *stat += (uint32_t)nf[n] * (uint32_t)((n < 144 ? 8 : n < 256 ? 9 : n < 280 ? 7 : 8) + xbits);
+            else if (stype == 1) *stat += (uint32_t)nf[n] * (uint32_t)(5 + xbits);
+        }
+        if (overflow) {
+            do {
+                bits = max_length - 1;
+                while (blc[bits] == 0) bits--;
+                blc[bits]--; blc[bits + 1] += 2; blc[max_length]--;
+                overflow -= 2;
+            } while (overflow > 0);
+            for (bits = max_length; bits != 0; bits--) {
+                n = blc[bits];
+                while (n != 0) {
+                    m = order[--h];
+                    if (m > max_code) continue;
+                    if (len[m] != bits) { *opt += ((uint32_t)bits - len[m]) * nf[m]; len[m] = (uint8_t)bits; }
+                    n--;
+                }
+            }
+        }
+    }
+    /* gen_codes */
+    {
+        uint32_t next_code[16], code = 0;
+        for (int bits = 1; bits <= 15; bits++) { code = (code + S->bl_count[bits - 1]) << 1; next_code[bits] = code; }
+        for (n = 0; n <= max_code; n++) {
+            int l = len[n];
+            codes[n] = l ? (qzk_bitrev(next_code[l]++, l) | ((uint32_t)l << 16)) : 0;
+        }
+    }
+    return max_code;
+}
+
+QZ_DEV void qzk_scan_tree(qzk_huff_lds *S, uint8_t *len, int max_code)
+{
+    int n, prevlen = -1, curlen, nextlen = len[0], count = 0, max_count = 7, min_count = 4;
+    if (nextlen == 0) max_count = 138, min_count = 3;
+    for (n = 0; n <= max_code; n++) {
+        curlen = nextlen; nextlen = n + 1 <= max_code ? len[n + 1] : 0xffff;
+        if (++count < max_count && curlen == nextlen) continue;
+        else if (count < min_count) S->fbl[curlen] += (uint32_t)count;
+        else if (curlen != 0) { if (curlen != prevlen) S->fbl[curlen]++; S->fbl[16]++; }
+        else if (count <= 10) S->fbl[17]++;
+        else S->fbl[18]++;
+        count = 0; prevlen = curlen;
+        if (nextlen == 0) max_count = 138, min_count = 3;
+        else if (curlen == nextlen) max_count = 6, min_count = 3;
+        else max_count = 7, min_count = 4;
+    }
+}
+
+QZ_DEV void qzk_hdr_bits(qzk_huff_lds *S, uint32_t v, int nb)
+{
+    uint32_t pos = S->hbits, w = pos >> 5, s = pos & 31;
+    S->hdr[w] |= v << s;
+    if (s + (uint32_t)nb > 32) S->hdr[w + 1] |= v >> (32 - s);
+    S->hbits = pos + (uint32_t)nb;
+}
+#define QZK_HCODE(S, c) qzk_hdr_bits(S, (S)->code_bl[c] & 0xffff, (int)((S)->code_bl[c] >> 16))
+
+QZ_DEV void qzk_send_tree(qzk_huff_lds *S, uint8_t *len, int max_code)
+{
+    int n, prevlen = -1, curlen, nextlen = len[0], count = 0, max_count = 7, min_count = 4;
+    if (nextlen == 0) max_count = 138, min_count = 3;
+    for (n = 0; n <= max_code; n++) {
+        curlen = nextlen; nextlen = n + 1 <= max_code ? len[n + 1] : 0xffff;
+        if (++count < max_count && curlen == nextlen) continue;
+        else if (count < min_count) { do { QZK_HCODE(S, curlen); } while (--count != 0); }
+        else if (curlen != 0) {
+            if (curlen != prevlen) { QZK_HCODE(S, curlen); count--; }
+            QZK_HCODE(S, 16); qzk_hdr_bits(S, (uint32_t)(count - 3), 2);
+        } else if (count <= 10) { QZK_HCODE(S, 17); qzk_hdr_bits(S, (uint32_t)(count - 3), 3); }
+        else { QZK_HCODE(S, 18); qzk_hdr_bits(S, (uint32_t)(count - 11), 7); }
+        count = 0; prevlen = curlen;
+        if (nextlen == 0) max_count = 138, min_count = 3;
+        else if (curlen == nextlen) max_count = 6, min_count = 3;
+        else max_count = 7, min_count = 4;
+    }
+}
+
+/* lane 0: everything _tr_flush_block decides.  Leaves S->btype (0 stored,1 fixed,2 dynamic),
+ * code tables and (dynamic) header bits, all AFTER the 3-bit block header. */
+QZ_DEV void qzk_plan_block(qzk_huff_lds *S, uint32_t stored_len, bool can_store)
+{
+    static const uint8_t bl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint32_t opt = 0, stat = 0, opt_lenb, static_lenb;
+    int max_l, max_d, max_blindex;
+
+    max_l = qzk_build_tree(S, S->fl, S->len_l, S->code_l, QZK_LCODES, 15, 0, &opt, &stat);
+    max_d = qzk_build_tree(S, S->fd, S->len_d, S->code_d, QZK_DCODES, 15, 1, &opt, &stat);
+    for (int i = 0; i < 19; i++) S->fbl[i] = 0;
+    qzk_scan_tree(S, S->len_l, max_l);
+    qzk_scan_tree(S, S->len_d, max_d);
+    qzk_build_tree(S, S->fbl, S->len_bl, S->code_bl, QZK_BLCODES, 7, 2, &opt, &stat);
+    for (max_blindex = QZK_BLCODES - 1; max_blindex >= 3; max_blindex--)
+        if (S->len_bl[bl_order[max_blindex]] != 0) break;
+    opt += 3 * ((uint32_t)max_blindex + 1) + 5 + 5 + 4;
+    opt_lenb = (opt + 3 + 7) >> 3;
+    static_lenb = (stat + 3 + 7) >> 3;
+    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+
+    if (stored_len + 4 <= opt_lenb && can_store) { S->btype = 0; return; }
+    if (static_lenb == opt_lenb) {
+        S->btype = 1;
+        /* fixed codes: canonical, lengths 8/9/7/8 and 5 */
+        for (int n = 0; n < 288; n++) {
+            int l = n < 144 ? 8 : n < 256 ? 9 : n < 280 ? 7 : 8;
+            uint32_t c = n < 144 ? 0x30 + (uint32_t)n : n < 256 ? 0x190 + (uint32_t)(n - 144)
+                         : n < 280 ? (uint32_t)(n - 256) : 0xC0 + (uint32_t)(n - 280);
+            S->code_l[n] = qzk_bitrev(c, l) | ((uint32_t)l << 16);
+        }
+        for (int n = 0; n < 30; n++) S->code_d[n] = qzk_bitrev((uint32_t)n, 5) | (5u << 16);
+        return;
+    }
+    S->btype = 2;
+    for (int i = 0; i < 320; i++) S->hdr[i] = 0;
+    S->hbits = 0;
+    qzk_hdr_bits(S, (uint32_t)(max_l + 1 - 257), 5);
+    qzk_hdr_bits(S, (uint32_t)(max_d + 1 - 1), 5);
+    qzk_hdr_bits(S, (uint32_t)(max_blindex + 1 - 4), 4);
+    for (int r = 0; r <= max_blindex; r++) qzk_hdr_bits(S, S->len_bl[bl_order[r]], 3);
+    qzk_send_tree(S, S->len_l, max_l);
+    qzk_send_tree(S, S->len_d, max_d);
+}
+
+/* ------------------------------------------------------------------ workgroup helpers */
+QZ_DEV uint32_t qzk_wave_incl_scan(uint32_t v, int lane)
+{
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = qz_shfl(v, lane - d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+/* exclusive prefix sum over the 256 threads; *total = sum */
+QZ_DEV uint32_t qzk_block_excl_scan(qzk_huff_lds *S, uint32_t v, uint32_t *total)
+{
+    const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t inc = qzk_wave_incl_scan(v, lane);
+    if (lane == 63) S->scan[wv] = inc;
+    qz_block_sync();
+    uint32_t off = 0, tot = 0;
+    for (int k = 0; k < QZK_HT / 64; k++) { uint32_t s = S->scan[k]; if (k < wv) off += s; tot += s; }
+    qz_block_sync();
+    *total = tot;
+    return off + inc - v;
+}
+
+/* symbol -> (bits, nbits) with the current code tables */
+QZ_DEV void qzk_sym_bits(const qzk_huff_lds *S, uint32_t lc, uint32_t dist, uint64_t *val, uint32_t *nb)
+{
+    if (dist == 0) {
+        uint32_t c = S->code_l[lc];
+        *val = c & 0xffff; *nb = c >> 16;
+        return;
+    }
+    uint32_t lcode, lext, lval, dcode, dext, dval, D = dist - 1;
+    if (lc < 8) { lcode = lc; lext = 0; lval = 0; }
+    else if (lc == 255) { lcode = 28; lext = 0; lval = 0; }
+    else {
+        uint32_t k = 31 - (uint32_t)__builtin_clz(lc);
+        lcode = 4 * (k - 1) + ((lc >> (k - 2)) & 3); lext = k - 2; lval = lc & ((1u << lext) - 1);
+    }
+    if (D < 4) { dcode = D; dext = 0; dval = 0; }
+    else {
+        uint32_t k = 31 - (uint32_t)__builtin_clz(D);
+        dcode = 2 * k + ((D >> (k - 1)) & 1); dext = k - 1; dval = D & ((1u << dext) - 1);
+    }
+    uint32_t cl = S->code_l[257 + lcode], cd = S->code_d[dcode];
+    uint64_t v = cl & 0xffff; uint32_t n = cl >> 16;
+    v |= (uint64_t)lval << n; n += lext;
+    v |= (uint64_t)(cd & 0xffff) << n; n += cd >> 16;
+    v |= (uint64_t)dval << n; n += dext;
+    *val = v; *nb = n;
+}
+
+typedef struct { uint8_t *out; uint32_t nbytes; uint32_t cbits; uint32_t carry; } qzk_bitout;
+
+/* One workgroup-wide emission step: every thread contributes (val, nb<=48 bits). */
+QZ_DEV void qzk_emit_step(qzk_huff_lds *S, qzk_bitout *bo, uint64_t val, uint32_t nb)
+{
+    const int t = (int)threadIdx.x;
+    uint32_t total;
+    uint32_t off = qzk_block_excl_scan(S, nb, &total);      /* contains two block syncs */
+    if (total == 0) return;
+    for (int i = t; i < 420; i += QZK_HT) S->stage[i] = i == 0 ? bo->carry : 0;
+    qz_block_sync();
+    if (nb) {
+        uint32_t pos = bo->cbits + off, w = pos >> 5, s = pos & 31;
+        uint64_t a = val << s;
+        uint32_t hi = s ? (uint32_t)(val >> (64 - s)) : 0;
+        atomicOr(&S->stage[w], (uint32_t)a);
+        if ((uint32_t)(a >> 32)) atomicOr(&S->stage[w + 1], (uint32_t)(a >> 32));
+        if (hi) atomicOr(&S->stage[w + 2], hi);
+    }
+    qz_block_sync();
+    uint32_t tb = bo->cbits + total, nby = tb >> 3;
+    for (uint32_t i = (uint32_t)t; i < nby; i += QZK_HT)
+        bo->out[bo->nbytes + i] = (uint8_t)(S->stage[i >> 2] >> (8 * (i & 3)));
+    uint32_t nc = tb & 7;
+    uint32_t cw = (S->stage[nby >> 2] >> (8 * (nby & 3))) & ((1u << nc) - 1);
+    qz_block_sync();
+    bo->nbytes += nby; bo->cbits = nc; bo->carry = cw;
+}
+
+/* flush the partial byte (bi_windup) */
+QZ_DEV void qzk_align(qzk_bitout *bo)
+{
+    if (bo->cbits) {
+        if (threadIdx.x == 0) bo->out[bo->nbytes] = (uint8_t)bo->carry;
+        bo->nbytes++; bo->cbits = 0; bo->carry = 0;
+    }
+}
+
+/* ------------------------------------------------------------------ CRC32 (K6) */
+#define QZK_POLY 0xEDB88320u
+QZ_DEV uint32_t qzk_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ QZK_POLY : b >> 1;
+    }
+    return p;
+}
+/* x^(n * 2^k) mod P, using S->x2n[i] = x^(2^i) */
+QZ_DEV uint32_t qzk_x2nmodp(const uint32_t *x2n, uint64_t n, unsigned k)
+{
+    uint32_t p = 1u << 31;
+    while (n) { if (n & 1) p = qzk_multmodp(x2n[k & 31], p); n >>= 1; k++; }
+    return p;
+}
+
+/* crc32 of src[0..n) by the whole workgroup (finalised, zlib convention) */
+QZ_DEV uint32_t qzk_block_crc32(qzk_huff_lds *S, const uint8_t *src, uint32_t n)
+{
+    const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
+    {
+        uint32_t c = (uint32_t)t;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? QZK_POLY ^ (c >> 1) : c >> 1;
+        S->crc_tab[t] = c;
+    }
+    if (t == 0) {
+        uint32_t p = 1u << 30;
+        S->x2n[0] = p;
+        for (int i = 1; i < 32; i++) S->x2n[i] = p = qzk_multmodp(p, p);
+    }
+    qz_block_sync();
+    uint32_t seg = (n + QZK_HT - 1) / QZK_HT;
+    seg = (seg + 3) & ~3u;
+    uint32_t s0 = (uint32_t)t * seg, s1 = s0 + seg;
+    if (s0 > n) s0 = n;
+    if (s1 > n) s1 = n;
+    uint32_t c = 0xffffffffu;
+    for (uint32_t i = s0; i < s1; i++) c = S->crc_tab[(c ^ src[i]) & 0xff] ^ (c >> 8);
+    c = ~c;
+    uint32_t part = 0;
+    if (s1 > s0) part = (s1 == n) ? c : qzk_multmodp(qzk_x2nmodp(S->x2n, n - s1, 3), c);
+    for (int d = 32; d >= 1; d >>= 1) part ^= qz_shfl(part, lane ^ d);
+    if (lane == 0) S->red[wv] = part;
+    qz_block_sync();
+    uint32_t r = 0;
+    for (int k = 0; k < QZK_HT / 64; k++) r ^= S->red[k];
+    qz_block_sync();
+    return r;
+}
+
+/* ------------------------------------------------------------------ the kernel */
+QZ_KERNEL qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
+                          const uint8_t *sym_lc, const uint16_t *sym_dist, const qzk_lzmeta *meta,
+                          uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk /* index or ~0u */,
+                          uint32_t *out_len, uint32_t *out_crc)
+{
+    QZ_LDS qzk_huff_lds S;
+    const int t = (int)threadIdx.x;
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= nchunks) return;
+    const uint64_t coff = (uint64_t)chunk * chunk_sz;
+    const uint8_t *in = src + coff;
+    const uint8_t *lcs = sym_lc + coff;
+    const uint16_t *dists = sym_dist + coff;
+    const qzk_lzmeta *mt = meta + chunk;
+    const uint32_t n = mt->n, nsym = mt->nsym, nfull = mt->nfull, cs = mt->can_store;
+    const bool is_final = chunk == final_chunk;
+    (void)src_len;
+
+    qzk_bitout bo;
+    bo.out = slots + (uint64_t)chunk * slot_stride; bo.nbytes = 0; bo.cbits = 0; bo.carry = 0;
+
+    const uint32_t crc = qzk_block_crc32(&S, in, n);
+
+    /* blocks 0..nfull-1 are full; block nfull is the remainder (possibly empty) */
+    const uint32_t nblocks = nfull + ((is_final || nsym > nfull * QZK_LITBUF) ? 1 : 0);
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint32_t s0 = b * QZK_LITBUF;
+        const uint32_t s1 = b < nfull ? s0 + QZK_LITBUF : nsym;
+        const uint32_t bs = mt->bstart[b < QZK_MAXBLK ? b : QZK_MAXBLK - 1];
+        const uint32_t be = b < nfull ? mt->bstart[b + 1 < QZK_MAXBLK ? b + 1 : QZK_MAXBLK - 1] : n;
+        const uint32_t last = (is_final && b == nblocks - 1) ? 1u : 0u;
+
+        for (int i = t; i < 288; i += QZK_HT) S.fl[i] = 0;
+        if (t < 32) S.fd[t] = 0;
+        qz_block_sync();
+        for (uint32_t i = s0 + (uint32_t)t; i < s1; i += QZK_HT) {
+            uint32_t lc = lcs[i], dist = dists[i];
+            if (dist == 0) atomicAdd(&S.fl[lc], 1u);
+            else {
+                uint32_t lcode, D = dist - 1, dcode;
+                if (lc < 8) lcode = lc; else if (lc == 255) lcode = 28;
+                else { uint32_t k = 31 - (uint32_t)__builtin_clz(lc); lcode = 4 * (k - 1) + ((lc >> (k - 2)) & 3); }
+                if (D < 4) dcode = D; else { uint32_t k = 31 - (uint32_t)__builtin_clz(D); dcode = 2 * k + ((D >> (k - 1)) & 1); }
+                atomicAdd(&S.fl[257 + lcode], 1u);
+                atomicAdd(&S.fd[dcode], 1u);
+            }
+        }
+        qz_block_sync();
+        if (t == 0) {
+            S.fl[256] = 1;
+            qzk_plan_block(&S, be - bs, (cs >> b) & 1);
+        }
+        qz_block_sync();
+        const uint32_t btype = S.btype;
+
+        /* 3-bit block header */
+        qzk_emit_step(&S, &bo, t == 0 ? (uint64_t)((btype << 1) | last) : 0, t == 0 ? 3 : 0);
+
+        if (btype == 0) {
+            const uint32_t slen = be - bs;
+            qzk_align(&bo);
+            if (t < 4) {
+                uint32_t v = t < 2 ? slen : ~slen;
+                bo.out[bo.nbytes + (uint32_t)t] = (uint8_t)(v >> (8 * (t & 1)));
+            }
+            for (uint32_t i = (uint32_t)t; i < slen; i += QZK_HT) bo.out[bo.nbytes + 4 + i] = in[bs + i];
+            bo.nbytes += 4 + slen;
+        } else {
+            if (btype == 2) {
+                const uint32_t hb = S.hbits, hw = (hb + 31) >> 5;
+                for (uint32_t w0 = 0; w0 < hw; w0 += QZK_HT) {
+                    uint32_t w = w0 + (uint32_t)t, nb = 0; uint64_t v = 0;
+                    if (w < hw) { nb = (w + 1) * 32 <= hb ? 32 : hb - w * 32; v = S.hdr[w] & (nb == 32 ? 0xffffffffu : ((1u << nb) - 1)); }
+                    qzk_emit_step(&S, &bo, v, nb);
+                }
+            }
+            for (uint32_t i0 = s0; i0 < s1; i0 += QZK_HT) {
+                uint32_t i = i0 + (uint32_t)t, nb = 0; uint64_t v = 0;
+                if (i < s1) qzk_sym_bits(&S, lcs[i], dists[i], &v, &nb);
+                qzk_emit_step(&S, &bo, v, nb);
+            }
+            {   /* END_BLOCK */
+                uint32_t c = S.code_l[256];
+                qzk_emit_step(&S, &bo, t == 0 ? (uint64_t)(c & 0xffff) : 0, t == 0 ? c >> 16 : 0);
+            }
+        }
+        qz_block_sync();
+    }
+    if (is_final) qzk_align(&bo);
+    else {
+        /* Z_FULL_FLUSH: empty stored block */
+        qzk_emit_step(&S, &bo, 0, t == 0 ? 3 : 0);
+        qzk_align(&bo);
+        if (t < 4) bo.out[bo.nbytes + (uint32_t)t] = t < 2 ? 0x00 : 0xff;
+        bo.nbytes += 4;
+    }
+    if (t == 0) { out_len[chunk] = bo.nbytes; out_crc[chunk] = crc; }
+}
+
+#endif

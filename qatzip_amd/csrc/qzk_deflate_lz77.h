@@ -1,0 +1,341 @@
+/*
+ * qzk_deflate_lz77.h — K1: zlib-exact greedy LZ77 parse ("deflate_fast", level 1)
+ * of one hw_buff_sz chunk per single-wave workgroup, gfx950.
+ *
+ * What it replaces: the deflate() hot loop the reference's software path spends
+ * ~75 % of its time in (src/qatzip_sw.c:197, zlib deflate_fast + longest_match;
+ * restated on the CPU in oracle/qzo_deflate.c).  Output = the exact symbol
+ * stream zlib tallies (lit / (len-3, dist)), plus where each 32767-symbol block
+ * starts, for K2 (qzk_deflate_huff.h) to Huffman-code.
+ *
+ * MI355X design:
+ *   - the greedy parse is serial by definition; one wave walks the chunk in
+ *     WINDOWS of 64 consecutive positions starting at the next parse point.
+ *     All 64 lanes speculate in parallel (hash, 4-deep chain walk, 16-byte
+ *     candidate compares); a short wave-uniform loop then hops from parse point
+ *     to parse point with v_readlane, and only lanes whose hash bucket was also
+ *     touched earlier in the same window take a slower exact path.
+ *   - hash chains live in LDS (128 KiB of the CU's 160 KiB): a 15-bit bucket
+ *     head table (u16) + a prev table of {1 tag bit, 15-bit distance}; the tag is
+ *     the hash bit the bucket drops, so chains are walked exactly like zlib's
+ *     16-bit-hash chains (wrong-tag links are skipped, not counted).
+ *   - the 64 KiB input window is read straight from HBM/L2 (coalesced for the
+ *     lanes' own bytes, gathers for candidates): LDS is spent on the tables.
+ *   - zlib's window slide (strstart >= 65274 => rebase by 32768, NIL==0) is
+ *     reproduced literally, so chunks up to 512 KiB and odd tail sizes match.
+ */
+#ifndef QZK_DEFLATE_LZ77_H
+#define QZK_DEFLATE_LZ77_H
+#include "qzk_common.h"
+
+#define QZK_WSIZE 32768
+#define QZK_MAXDIST 32506          /* w_size - MIN_LOOKAHEAD */
+#define QZK_MINLOOK 262
+#define QZK_LITBUF 32767           /* symbols per block at memLevel 9 */
+#define QZK_MAXBLK 20
+#define QZK_CAP 16                 /* speculative compare depth (>= nice_match) */
+#define QZK_WLIM 61                /* parse points per window: interiors of a len<=4 match stay < 64 */
+#define QZK_NICE 8
+#define QZK_MAXINS 4
+
+typedef struct {
+    uint32_t nsym;                 /* symbols in the chunk */
+    uint32_t nfull;                /* blocks closed by the 32767-symbol rule */
+    uint32_t bstart[QZK_MAXBLK];   /* chunk-relative byte where block k starts (k <= nfull) */
+    uint32_t can_store;            /* bit k: zlib could still emit block k as stored (block_start >= 0) */
+    uint32_t n;                    /* chunk length */
+} qzk_lzmeta;
+
+QZ_DEV uint32_t qzk_ld32g(const uint8_t *src, uint64_t off, uint64_t src_len)
+{
+    if (off + 4 <= src_len) return qz_ld32(src + off);
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) if (off + k < src_len) v |= (uint32_t)src[off + k] << (8 * k);
+    return v;
+}
+
+/* common-prefix length of src[a..] and src[b..], at most maxlen; whole wave cooperates */
+QZ_DEV int qzk_wave_matchlen(const uint8_t *src, uint64_t src_len, uint64_t a, uint64_t b, int maxlen, int lane)
+{
+    for (int off = 0; off < maxlen; off += 256) {
+        int o = off + 4 * lane;
+        bool act = o < maxlen;
+        uint32_t x = 0;
+        if (act) x = qzk_ld32g(src, a + o, src_len) ^ qzk_ld32g(src, b + o, src_len);
+        uint64_t mm = qz_ballot(act && x != 0);
+        if (mm) {
+            int f = qz_ctz64(mm);
+            uint32_t xf = qz_readlane(x, f);
+            int len = off + 4 * f + (qz_ctz32(xf) >> 3);
+            return len < maxlen ? len : maxlen;
+        }
+    }
+    return maxlen;
+}
+
+QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
+                          uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta)
+{
+    QZ_LDS uint16_t head[QZK_WSIZE];       /* 15-bit bucket -> last inserted window position (0 = NIL) */
+    QZ_LDS uint16_t prevt[QZK_WSIZE];      /* [pos & 32767] = tag<<15 | distance to previous bucket mate (0 = none) */
+    QZ_LDS uint32_t slot[1024];            /* per-window "lowest lane using this bucket key" */
+
+    const int lane = qz_lane();
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= nchunks) return;
+    const uint64_t coff = (uint64_t)chunk * chunk_sz;
+    const uint32_t n = (uint32_t)((src_len - coff) < chunk_sz ? (src_len - coff) : chunk_sz);
+    uint8_t *olc = sym_lc + coff;
+    uint16_t *odist = sym_dist + coff;
+    qzk_lzmeta *mt = meta + chunk;
+
+    for (int i = lane; i < QZK_WSIZE / 2; i += 64) ((uint32_t *)head)[i] = 0;
+    qz_wave_sync();
+
+    uint32_t base = 0;                              /* chunk offset of window position 0 */
+    uint32_t fill = n < 65536u ? n : 65536u;        /* chunk offset one past the data zlib has in its window */
+    uint32_t avail_in = n - fill;
+    uint32_t pos = 0;                               /* next parse point (chunk offset) */
+    uint32_t nsym = 0, nfull = 0, cur_bstart = 0, can_store = 0;
+    if (lane == 0) mt->bstart[0] = 0;
+
+    for (;;) {
+        /* ---- zlib loop top: fill_window() when lookahead < MIN_LOOKAHEAD ---- */
+        uint32_t look = fill - pos;
+        if (look < QZK_MINLOOK) {
+            if (pos - base >= (uint32_t)(QZK_WSIZE + QZK_MAXDIST)) {
+                base += QZK_WSIZE;
+                for (int i = lane; i < QZK_WSIZE / 2; i += 64) {
+                    uint32_t v = ((uint32_t *)head)[i], lo = v & 0xffff, hi = v >> 16;
+                    lo = lo >= QZK_WSIZE ? lo - QZK_WSIZE : 0;
+                    hi = hi >= QZK_WSIZE ? hi - QZK_WSIZE : 0;
+                    ((uint32_t *)head)[i] = lo | (hi << 16);
+                }
+                qz_wave_sync();
+            }
+            if (avail_in) {
+                uint32_t more = 65536u - (fill - base);
+                uint32_t rd = avail_in < more ? avail_in : more;
+                fill += rd; avail_in -= rd;
+            }
+            look = fill - pos;
+            if (look == 0) break;
+        }
+
+        /* ---- speculative phase: all 64 lanes ---- */
+        const uint32_t B = pos - base;                  /* window position of lane 0 */
+        const uint32_t p = B + (uint32_t)lane;          /* my window position */
+        const uint32_t pa = pos + (uint32_t)lane;       /* my chunk offset */
+        const int avail = pa < fill ? (int)(fill - pa) : 0;
+        const bool canh = avail >= 3;
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        if (avail > 0) {
+            w0 = qzk_ld32g(src, coff + pa, src_len);
+            w1 = qzk_ld32g(src, coff + pa + 4, src_len);
+            w2 = qzk_ld32g(src, coff + pa + 8, src_len);
+            w3 = qzk_ld32g(src, coff + pa + 12, src_len);
+        }
+        const uint32_t h = (((w0 & 0xf) << 12) ^ (((w0 >> 8) & 0xff) << 6) ^ ((w0 >> 16) & 0xff)) & 0xffff;
+        const uint32_t bucket = h >> 1, tag = h & 1;
+        const uint32_t key = bucket & 1023;
+
+        /* chain walk on the table state as of the window start */
+        int q0 = canh ? (int)head[bucket] : 0;
+        int q = q0, nc = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        const int lo = p > QZK_MAXDIST ? (int)(p - QZK_MAXDIST) : 0;
+        bool go = canh && q != 0 && (int)p - q <= QZK_MAXDIST;
+        while (qz_ballot(go)) {
+            if (go) {
+                uint32_t e = prevt[q & (QZK_WSIZE - 1)];
+                if ((e >> 15) == tag) {
+                    if (nc > 0 && q <= lo) go = false;      /* chained candidates need cur_match > limit */
+                    else {
+                        if (nc == 0) c0 = q; else if (nc == 1) c1 = q; else if (nc == 2) c2 = q; else c3 = q;
+                        if (++nc == 4) go = false;
+                    }
+                }
+                if (go) {
+                    int d = (int)(e & 0x7fff), q2 = q - d;
+                    if (d == 0 || q2 <= 0 || (int)p - q2 > QZK_MAXDIST) go = false;
+                    else q = q2;
+                }
+            }
+        }
+        /* 16-byte compares against up to 4 candidates, zlib's selection rule */
+        const int maxlen = avail < 258 ? avail : 258;
+        const int nice = avail < QZK_NICE ? avail : QZK_NICE;
+        int best_len = 2, best_c = 0;
+        int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+        {
+            bool done = false;
+            for (int k = 0; k < 4; k++) {
+                int ck = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                int len = 0;
+                if (k < nc) {
+                    uint64_t g = coff + base + (uint32_t)ck;
+                    uint32_t x;
+                    len = QZK_CAP;
+                    x = w3 ^ qzk_ld32g(src, g + 12, src_len); if (x) len = 12 + (qz_ctz32(x) >> 3);
+                    x = w2 ^ qzk_ld32g(src, g + 8, src_len);  if (x) len = 8 + (qz_ctz32(x) >> 3);
+                    x = w1 ^ qzk_ld32g(src, g + 4, src_len);  if (x) len = 4 + (qz_ctz32(x) >> 3);
+                    x = w0 ^ qzk_ld32g(src, g, src_len);      if (x) len = (qz_ctz32(x) >> 3);
+                    if (len > maxlen) len = maxlen;
+                    if (!done) {
+                        if (len > best_len) { best_len = len; best_c = ck; }
+                        if (len >= nice) done = true;
+                    }
+                }
+                if (k == 0) l0 = len; else if (k == 1) l1 = len; else if (k == 2) l2 = len; else l3 = len;
+            }
+        }
+        uint32_t mlen = best_len >= 3 ? (uint32_t)best_len : 0;     /* 0 => literal */
+        uint32_t mdist = mlen ? p - (uint32_t)best_c : 0;
+        const bool capped = (best_len == QZK_CAP) && (maxlen > QZK_CAP);
+        const bool exact0 = nc > 0 && (int)p - c0 == QZK_MAXDIST;
+
+        /* lanes whose bucket key was used by an earlier lane of this window need the exact path */
+        if (canh) slot[key] = 64;
+        qz_wave_sync();
+        if (canh) atomicMin(&slot[key], (uint32_t)lane);
+        qz_wave_sync();
+        const bool suspect = canh && slot[key] != (uint32_t)lane;
+
+        const uint64_t CANH = qz_ballot(canh);
+        const uint64_t CX = qz_ballot(suspect || capped);
+
+        /* ---- serial resolution (wave-uniform) ---- */
+        int nvalid = look < 64 ? (int)look : 64;
+        int lim = nvalid < QZK_WLIM ? nvalid : QZK_WLIM;
+        {   /* stop before a parse point where zlib would slide / refill its window */
+            int lstop;
+            int first_short = (int)look - (QZK_MINLOOK - 1);       /* first l with lookahead < 262 */
+            if (first_short < 0) first_short = 0;
+            if (avail_in) lstop = first_short;
+            else {
+                int sl = (int)(QZK_WSIZE + QZK_MAXDIST) - (int)B;
+                lstop = first_short > sl ? first_short : sl;
+            }
+            if (lstop < 1) lstop = 1;
+            if (lim > lstop) lim = lstop;
+        }
+        uint64_t Pm = 0;
+        int l = 0;
+        while (l < lim) {
+            uint64_t cxr = CX >> l;
+            int nextc = cxr ? l + qz_ctz64(cxr) : 64;
+            int stop = nextc < lim ? nextc : lim;
+            while (l < stop) {                      /* hot loop: hop over clean parse points */
+                Pm |= 1ull << l;
+                uint32_t ml = qz_readlane(mlen, l);
+                l += ml ? (int)ml : 1;
+            }
+            if (l >= lim || l != nextc) continue;
+            /* -- exact path for lane l -- */
+            {
+                const uint32_t h_l = qz_readlane(h, l);
+                const int avail_l = (int)look - l;
+                const int maxlen_l = avail_l < 258 ? avail_l : 258;
+                const int nice_l = avail_l < QZK_NICE ? avail_l : QZK_NICE;
+                /* inserted lanes so far: parse points with >=3 bytes ahead + interiors of short matches */
+                const uint64_t SH = qz_ballot(mlen >= 3 && mlen <= QZK_MAXINS && avail - (int)mlen >= 3);
+                const uint64_t S4 = qz_ballot(mlen == 4);
+                const uint64_t ps = Pm & SH;
+                const uint64_t I = (Pm & CANH) | (ps << 1) | (ps << 2) | ((ps & S4) << 3);
+                uint64_t Sh = qz_ballot(canh && h == h_l) & I & qz_below(l);
+                if (B == 0) Sh &= ~1ull;               /* window position 0 is NIL */
+                int cnt = 0, bl = 2; uint32_t bd = 0; bool fin = false;
+                const bool had_intra = Sh != 0;
+                while (Sh && cnt < 4 && !fin) {
+                    int j = qz_msb64(Sh);
+                    Sh &= ~(1ull << j);
+                    int len = qzk_wave_matchlen(src, src_len, coff + pos + (uint32_t)l, coff + pos + (uint32_t)j, maxlen_l, lane);
+                    cnt++;
+                    if (len > bl) { bl = len; bd = (uint32_t)(l - j); }
+                    if (len >= nice_l) fin = true;
+                }
+                const int nc_l = (int)qz_readlane((uint32_t)nc, l);
+                const bool ex_l = qz_readlane((uint32_t)exact0, l) != 0;
+                if (!fin && !(had_intra && ex_l)) {
+                    for (int k = 0; k < nc_l && cnt < 4 && !fin; k++) {
+                        int ck = (int)qz_readlane((uint32_t)(k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3), l);
+                        int len = (int)qz_readlane((uint32_t)(k == 0 ? l0 : k == 1 ? l1 : k == 2 ? l2 : l3), l);
+                        if (len == QZK_CAP && maxlen_l > QZK_CAP)
+                            len = qzk_wave_matchlen(src, src_len, coff + pos + (uint32_t)l, coff + base + (uint32_t)ck, maxlen_l, lane);
+                        cnt++;
+                        if (len > bl) { bl = len; bd = (B + (uint32_t)l) - (uint32_t)ck; }
+                        if (len >= nice_l) fin = true;
+                    }
+                }
+                uint32_t nl = bl >= 3 ? (uint32_t)bl : 0;
+                if (lane == l) { mlen = nl; mdist = nl ? bd : 0; }
+                Pm |= 1ull << l;
+                l += nl ? (int)nl : 1;
+            }
+        }
+
+        /* ---- vector epilogue: symbols, block marks, table commit ---- */
+        const uint64_t SH = qz_ballot(mlen >= 3 && mlen <= QZK_MAXINS && avail - (int)mlen >= 3);
+        const uint64_t S4 = qz_ballot(mlen == 4);
+        const uint64_t ps = Pm & SH;
+        const uint64_t I = (Pm & CANH) | (ps << 1) | (ps << 2) | ((ps & S4) << 3);
+        const bool isP = (Pm >> lane) & 1, isI = (I >> lane) & 1;
+
+        const uint32_t rank = (uint32_t)qz_popc64(Pm & qz_below(lane));
+        const uint32_t idx = nsym + rank;
+        const uint32_t step = mlen ? mlen : 1;
+        if (isP) {
+            olc[idx] = (uint8_t)(mlen ? mlen - 3 : (w0 & 0xff));
+            odist[idx] = (uint16_t)mdist;
+        }
+        {   /* a symbol that completes a 32767-symbol block (at most one per window) */
+            const bool closes = isP && ((idx + 1) % QZK_LITBUF == 0);
+            const uint64_t cm = qz_ballot(closes);
+            if (cm) {
+                int f = qz_ctz64(cm);
+                uint32_t nb = qz_readlane(pa + step, f);
+                if (cur_bstart >= base) can_store |= 1u << nfull;
+                nfull++;
+                cur_bstart = nb;
+                if (lane == 0 && nfull < QZK_MAXBLK) mt->bstart[nfull] = nb;
+            }
+        }
+        nsym += (uint32_t)qz_popc64(Pm);
+
+        /* clean inserted lanes: link to the table head seen at window start */
+        if (isI && !suspect) {
+            uint32_t d = (q0 != 0 && p - (uint32_t)q0 <= 32767u) ? p - (uint32_t)q0 : 0;
+            prevt[p & (QZK_WSIZE - 1)] = (uint16_t)((tag << 15) | d);
+            head[bucket] = (uint16_t)p;
+        }
+        qz_wave_sync();
+        {   /* suspect inserted lanes, in position order */
+            uint64_t todo = I & qz_ballot(suspect);
+            while (todo) {
+                int j = qz_ctz64(todo);
+                todo &= todo - 1;
+                uint32_t b_j = qz_readlane(bucket, j);
+                uint64_t mates = qz_ballot(canh && bucket == b_j) & I & qz_below(j);
+                uint32_t d;
+                if (mates) d = (uint32_t)(j - qz_msb64(mates));
+                else {
+                    uint32_t q0j = qz_readlane((uint32_t)q0, j), pj = B + (uint32_t)j;
+                    d = (q0j != 0 && pj - q0j <= 32767u) ? pj - q0j : 0;
+                }
+                if (lane == j) {
+                    prevt[p & (QZK_WSIZE - 1)] = (uint16_t)((tag << 15) | d);
+                    head[bucket] = (uint16_t)p;
+                }
+            }
+        }
+        qz_wave_sync();
+        pos += (uint32_t)l;
+    }
+
+    /* zlib's final loop top (lookahead == 0) may still slide before the last flush */
+    if (cur_bstart >= base) can_store |= 1u << nfull;
+    if (lane == 0) {
+        mt->nsym = nsym; mt->nfull = nfull; mt->can_store = can_store; mt->n = n;
+    }
+}
+
+#endif

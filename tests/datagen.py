@@ -39,31 +39,48 @@ def _runs(n, g):
     return np.concatenate(out)[:n]
 
 
+_LEX = None
+
+
+def _lexicon():
+    """4000 pseudo-words (2-10 letters, English-like letter frequencies) as a padded matrix."""
+    global _LEX
+    if _LEX is None:
+        lex_g = np.random.Generator(np.random.PCG64(4000))
+        nwords = 4000
+        wl = lex_g.integers(2, 11, nwords)
+        letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", np.uint8)
+        pl = np.arange(1, 27, dtype=np.float64) ** -1.0
+        pl /= pl.sum()
+        mat = letters[lex_g.choice(26, (nwords, 11), p=pl)]
+        pz = np.arange(1, nwords + 1, dtype=np.float64) ** -1.1
+        pz /= pz.sum()
+        _LEX = (mat, wl.astype(np.int64), np.cumsum(pz))
+    return _LEX
+
+
 def _text(n, g):
+    """Zipf-distributed words separated by space/newline/punctuation (vectorised)."""
     if n == 0:
         return np.zeros(0, np.uint8)
-    lex_g = np.random.Generator(np.random.PCG64(4000))
-    nwords = 4000
-    wl = lex_g.integers(2, 11, nwords)
-    letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", np.uint8)
-    pl = np.arange(1, 27, dtype=np.float64) ** -1.0
-    pl /= pl.sum()
-    words = [letters[lex_g.choice(26, int(k), p=pl)] for k in wl]
-    pz = np.arange(1, nwords + 1, dtype=np.float64) ** -1.1
-    pz /= pz.sum()
-    need = n // 5 + 64
+    mat, wl, cdf = _lexicon()
+    seps = np.frombuffer(b"     \n,.", np.uint8)
     out = []
     tot = 0
     while tot < n:
-        idx = g.choice(nwords, need, p=pz)
-        seps = g.choice(np.frombuffer(b"     \n,.", np.uint8), need)
-        parts = []
-        for i, s in zip(idx, seps):
-            parts.append(words[i])
-            parts.append(np.array([s], np.uint8))
-        a = np.concatenate(parts)
+        need = (n - tot) // 5 + 64
+        idx = np.searchsorted(cdf, g.random(need)).clip(0, len(wl) - 1)
+        lens = wl[idx] + 1                                  # word + separator
+        starts = np.cumsum(lens) - lens
+        total = int(lens.sum())
+        owner = np.repeat(np.arange(need), lens)
+        off = np.arange(total) - starts[owner]
+        m = mat.copy()
+        a = m[idx[owner], np.minimum(off, 10)]
+        sep_pos = off == (lens[owner] - 1)
+        a[sep_pos] = seps[g.integers(0, len(seps), int(sep_pos.sum()))]
         out.append(a)
-        tot += a.size
+        tot += total
     return np.concatenate(out)[:n]
 
 

@@ -1,0 +1,50 @@
+/*
+ * sim_driver.cpp — runs the repo's HIP kernel bodies on the CPU SIMT emulator
+ * (hipsim.h) and exposes them to the Python tests through a C ABI.
+ * TEST INFRASTRUCTURE: used by `-m "not gpu"` tests to fuzz kernel logic against
+ * the oracle in a container without a GPU.  Never part of the product path.
+ */
+#define QZ_SIM 1
+#include "hipsim.h"
+#include "../../qatzip_amd/csrc/qzk_deflate_lz77.h"
+#include "../../qatzip_amd/csrc/qzk_deflate_huff.h"
+#include <vector>
+
+extern "C" {
+
+/* K1 only: symbols + meta of every chunk */
+int sim_lz77(const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta)
+{
+    uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
+    sim::launch(nchunks, 64, 0, [&] { qzk_lz77_kernel(src, n, chunk_sz, nchunks, lc, dist, meta); });
+    return (int)nchunks;
+}
+
+/* K1 + K2: raw deflate stream of all chunks (last: final chunk carries BFINAL) */
+int sim_deflate(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len,
+                uint32_t *crcs)
+{
+    uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
+    std::vector<uint8_t> lc(n + 64);
+    std::vector<uint16_t> dist(n + 64);
+    std::vector<qzk_lzmeta> meta(nchunks);
+    uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
+    std::vector<uint8_t> slots((size_t)nchunks * stride);
+    std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
+    sim::launch(nchunks, 64, 0, [&] { qzk_lz77_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data()); });
+    sim::launch(nchunks, QZK_HT, 0, [&] {
+        qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
+                        last ? nchunks - 1 : ~0u, olen.data(), ocrc.data());
+    });
+    uint64_t pos = 0;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);
+        pos += olen[c];
+        if (crcs) crcs[c] = ocrc[c];
+    }
+    *out_len = pos;
+    return (int)nchunks;
+}
+
+unsigned sim_meta_size(void) { return (unsigned)sizeof(qzk_lzmeta); }
+}
