@@ -294,3 +294,13 @@ extern "C" int qzd_last_timing(qzd_ctx *c, float ms[4])
     if (hipEventElapsedTime(&t, c->ev_begin, c->ev_end) == hipSuccess) ms[3] = t;
     return QZD_OK;
 }
+
+#ifdef QZK_PROF
+/* profiling builds only: raw K1 metadata (with per-phase cycle counters) of buffer set `s` */
+extern "C" int qzd_debug_meta(qzd_ctx *c, int s, void *h_out, uint32_t nchunks)
+{
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpy(h_out, c->meta[s], (size_t)nchunks * sizeof(qzk_lzmeta), hipMemcpyDeviceToHost));
+    return (int)sizeof(qzk_lzmeta);
+}
+#endif

@@ -37,6 +37,16 @@
 #define QZK_WLIM 61                /* parse points per window: interiors of a len<=4 match stay < 64 */
 #define QZK_NICE 8
 #define QZK_MAXINS 4
+#define QZK_HMIX 0x9E37u           /* odd => bijective on 16 bits */
+#define QZK_NSLOT 4096
+
+#if defined(QZK_PROF) && !defined(QZ_SIM)
+#define QZK_T(k) do { uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; } while (0)
+#define QZK_C(k, v) do { prof[k] += (uint64_t)(v); } while (0)
+#else
+#define QZK_T(k) do { } while (0)
+#define QZK_C(k, v) do { } while (0)
+#endif
 
 typedef struct {
     uint32_t nsym;                 /* symbols in the chunk */
@@ -44,6 +54,9 @@ typedef struct {
     uint32_t bstart[QZK_MAXBLK];   /* chunk-relative byte where block k starts (k <= nfull) */
     uint32_t can_store;            /* bit k: zlib could still emit block k as stored (block_start >= 0) */
     uint32_t n;                    /* chunk length */
+#ifdef QZK_PROF
+    uint64_t prof[16];             /* per-phase cycles / counters (profiling builds only) */
+#endif
 } qzk_lzmeta;
 
 QZ_DEV uint32_t qzk_ld32g(const uint8_t *src, uint64_t off, uint64_t src_len)
@@ -78,7 +91,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
 {
     QZ_LDS uint16_t head[QZK_WSIZE];       /* 15-bit bucket -> last inserted window position (0 = NIL) */
     QZ_LDS uint16_t prevt[QZK_WSIZE];      /* [pos & 32767] = tag<<15 | distance to previous bucket mate (0 = none) */
-    QZ_LDS uint32_t slot[1024];            /* per-window "lowest lane using this bucket key" */
+    QZ_LDS uint32_t slot[QZK_NSLOT];            /* per-window "lowest lane using this bucket key" */
 
     const int lane = qz_lane();
     const uint32_t chunk = blockIdx.x;
@@ -98,6 +111,9 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
     uint32_t pos = 0;                               /* next parse point (chunk offset) */
     uint32_t nsym = 0, nfull = 0, cur_bstart = 0, can_store = 0;
     if (lane == 0) mt->bstart[0] = 0;
+#if defined(QZK_PROF) && !defined(QZ_SIM)
+    uint64_t prof[16] = {0}; uint64_t tprev = __builtin_readcyclecounter();
+#endif
 
     for (;;) {
         /* ---- zlib loop top: fill_window() when lookahead < MIN_LOOKAHEAD ---- */
@@ -122,23 +138,33 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
             if (look == 0) break;
         }
 
+        QZK_T(0); QZK_C(8, 1);
         /* ---- speculative phase: all 64 lanes ---- */
         const uint32_t B = pos - base;                  /* window position of lane 0 */
         const uint32_t p = B + (uint32_t)lane;          /* my window position */
         const uint32_t pa = pos + (uint32_t)lane;       /* my chunk offset */
         const int avail = pa < fill ? (int)(fill - pa) : 0;
         const bool canh = avail >= 3;
+        /* all of this window's loads stay inside the buffer unless it sits at the very end of it */
+        const bool guard = coff + pos + 64 + 2 * QZK_CAP > src_len;
         uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        if (avail > 0) {
+        if (!guard) {
+            const uint8_t *o = src + coff + pa;
+            w0 = qz_ld32(o); w1 = qz_ld32(o + 4); w2 = qz_ld32(o + 8); w3 = qz_ld32(o + 12);
+        } else if (avail > 0) {
             w0 = qzk_ld32g(src, coff + pa, src_len);
             w1 = qzk_ld32g(src, coff + pa + 4, src_len);
             w2 = qzk_ld32g(src, coff + pa + 8, src_len);
             w3 = qzk_ld32g(src, coff + pa + 12, src_len);
         }
         const uint32_t h = (((w0 & 0xf) << 12) ^ (((w0 >> 8) & 0xff) << 6) ^ ((w0 >> 16) & 0xff)) & 0xffff;
-        const uint32_t bucket = h >> 1, tag = h & 1;
-        const uint32_t key = bucket & 1023;
+        /* bucket = 15 bits of a bijective mix of zlib's hash, tag = the bit it drops: the two hashes that
+         * share a bucket are unrelated trigrams, so wrong-tag links on a chain are rare */
+        const uint32_t hm = (h * QZK_HMIX) & 0xffff;
+        const uint32_t bucket = hm >> 1, tag = hm & 1;
+        const uint32_t key = bucket & (QZK_NSLOT - 1);
 
+        QZK_T(1);
         /* chain walk on the table state as of the window start */
         int q0 = canh ? (int)head[bucket] : 0;
         int q = q0, nc = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -161,24 +187,38 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
                 }
             }
         }
-        /* 16-byte compares against up to 4 candidates, zlib's selection rule */
+        QZK_T(2);
+        /* 16-byte compares against up to 4 candidates (all 16 loads issued before any is used),
+         * then zlib's selection rule */
         const int maxlen = avail < 258 ? avail : 258;
         const int nice = avail < QZK_NICE ? avail : QZK_NICE;
         int best_len = 2, best_c = 0;
         int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
         {
+            uint32_t x[4][4];
+            for (int k = 0; k < 4; k++) {
+                int ck = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                if (k >= nc) ck = (int)p;                   /* harmless address; result ignored */
+                uint64_t g = coff + base + (uint32_t)ck;
+                if (!guard) {
+                    x[k][0] = qz_ld32(src + g); x[k][1] = qz_ld32(src + g + 4);
+                    x[k][2] = qz_ld32(src + g + 8); x[k][3] = qz_ld32(src + g + 12);
+                } else {
+                    x[k][0] = qzk_ld32g(src, g, src_len); x[k][1] = qzk_ld32g(src, g + 4, src_len);
+                    x[k][2] = qzk_ld32g(src, g + 8, src_len); x[k][3] = qzk_ld32g(src, g + 12, src_len);
+                }
+            }
             bool done = false;
             for (int k = 0; k < 4; k++) {
                 int ck = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
                 int len = 0;
                 if (k < nc) {
-                    uint64_t g = coff + base + (uint32_t)ck;
-                    uint32_t x;
+                    uint32_t d;
                     len = QZK_CAP;
-                    x = w3 ^ qzk_ld32g(src, g + 12, src_len); if (x) len = 12 + (qz_ctz32(x) >> 3);
-                    x = w2 ^ qzk_ld32g(src, g + 8, src_len);  if (x) len = 8 + (qz_ctz32(x) >> 3);
-                    x = w1 ^ qzk_ld32g(src, g + 4, src_len);  if (x) len = 4 + (qz_ctz32(x) >> 3);
-                    x = w0 ^ qzk_ld32g(src, g, src_len);      if (x) len = (qz_ctz32(x) >> 3);
+                    d = w3 ^ x[k][3]; if (d) len = 12 + (qz_ctz32(d) >> 3);
+                    d = w2 ^ x[k][2]; if (d) len = 8 + (qz_ctz32(d) >> 3);
+                    d = w1 ^ x[k][1]; if (d) len = 4 + (qz_ctz32(d) >> 3);
+                    d = w0 ^ x[k][0]; if (d) len = (qz_ctz32(d) >> 3);
                     if (len > maxlen) len = maxlen;
                     if (!done) {
                         if (len > best_len) { best_len = len; best_c = ck; }
@@ -193,6 +233,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         const bool capped = (best_len == QZK_CAP) && (maxlen > QZK_CAP);
         const bool exact0 = nc > 0 && (int)p - c0 == QZK_MAXDIST;
 
+        QZK_T(3);
         /* lanes whose bucket key was used by an earlier lane of this window need the exact path */
         if (canh) slot[key] = 64;
         qz_wave_sync();
@@ -203,6 +244,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         const uint64_t CANH = qz_ballot(canh);
         const uint64_t CX = qz_ballot(suspect || capped);
 
+        QZK_T(4);
         /* ---- serial resolution (wave-uniform) ---- */
         int nvalid = look < 64 ? (int)look : 64;
         int lim = nvalid < QZK_WLIM ? nvalid : QZK_WLIM;
@@ -231,6 +273,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
             }
             if (l >= lim || l != nextc) continue;
             /* -- exact path for lane l -- */
+            QZK_T(5); QZK_C(9, 1);
             {
                 const uint32_t h_l = qz_readlane(h, l);
                 const int avail_l = (int)look - l;
@@ -271,8 +314,10 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
                 Pm |= 1ull << l;
                 l += nl ? (int)nl : 1;
             }
+            QZK_T(6);
         }
 
+        QZK_T(5);
         /* ---- vector epilogue: symbols, block marks, table commit ---- */
         const uint64_t SH = qz_ballot(mlen >= 3 && mlen <= QZK_MAXINS && avail - (int)mlen >= 3);
         const uint64_t S4 = qz_ballot(mlen == 4);
@@ -301,6 +346,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         }
         nsym += (uint32_t)qz_popc64(Pm);
 
+        QZK_T(7);
         /* clean inserted lanes: link to the table head seen at window start */
         if (isI && !suspect) {
             uint32_t d = (q0 != 0 && p - (uint32_t)q0 <= 32767u) ? p - (uint32_t)q0 : 0;
@@ -310,6 +356,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         qz_wave_sync();
         {   /* suspect inserted lanes, in position order */
             uint64_t todo = I & qz_ballot(suspect);
+            QZK_C(10, qz_popc64(todo)); QZK_C(11, qz_popc64(Pm));
             while (todo) {
                 int j = qz_ctz64(todo);
                 todo &= todo - 1;
@@ -329,12 +376,16 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         }
         qz_wave_sync();
         pos += (uint32_t)l;
+        QZK_T(12);
     }
 
     /* zlib's final loop top (lookahead == 0) may still slide before the last flush */
     if (cur_bstart >= base) can_store |= 1u << nfull;
     if (lane == 0) {
         mt->nsym = nsym; mt->nfull = nfull; mt->can_store = can_store; mt->n = n;
+#if defined(QZK_PROF) && !defined(QZ_SIM)
+        for (int k = 0; k < 16; k++) mt->prof[k] = prof[k];
+#endif
     }
 }
 
