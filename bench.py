@@ -2,11 +2,13 @@
 """bench.py — the reference's headline workload on MI355X.
 
 Workload (BASELINE.json configs[1]): QZ_DEFLATE_GZIP_EXT, level 1, hw_buff_sz 64 KB, a 4 GB synthetic
-"Silesia-like" buffer per GPU, compressed as 2 calls of 2 GiB (qatzip lengths are 32-bit), inputs already
-resident in HBM when the timed region starts.  One step = one pass of the hot path over that buffer.
-`value` = uncompressed bytes processed by all ranks / max-over-ranks wall time (reference convention:
-test/main.c:2336-2346 counts uncompressed bytes).  Multi-GPU: independent chunks shard across ranks with no
-data-path collective (weak scaling: every rank owns its own 4 GB).
+"Silesia-like" buffer per GPU, handled as 2 calls of 2 GiB (qatzip lengths are 32-bit), inputs already
+resident in HBM when the timed region starts.  One step = one pass of the hot path over that buffer:
+compress every call, then decompress every call (the reference harness' "-D both", test/main.c:2204-2299).
+`value` = uncompressed bytes moved in both directions by all ranks / max-over-ranks wall time (the reference
+counts uncompressed bytes for either direction and doubles them for "both", test/main.c:2336-2346).
+Multi-GPU: independent chunks shard across ranks with no data-path collective (weak scaling: every rank
+owns its own buffer); gloo carries the barrier and the max/sum reductions of the timings.
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,6 +26,7 @@ import numpy as np  # noqa: E402
 
 CHUNK = 65536
 CALL_BYTES = 1 << 31            # one qzCompress-sized call (2 GiB)
+BATCH_CHUNKS = 2048             # chunks per K1 launch (QZD_BATCH in qatzip_amd/csrc/qzd_internal.h)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -34,7 +37,6 @@ def dist_setup():
     pg = None
     if world > 1:
         import torch.distributed as dist
-        # no data-path collective on this path: gloo carries the barrier and the max-over-ranks reduction
         dist.init_process_group("gloo", rank=rank, world_size=world)
         pg = dist
     return rank, world, local, pg
@@ -45,21 +47,12 @@ def barrier(pg):
         pg.barrier()
 
 
-def allreduce_max(pg, v):
+def allreduce(pg, v, op):
     if pg is None:
         return v
     import torch
     t = torch.tensor([v], dtype=torch.float64)
-    pg.all_reduce(t, op=pg.ReduceOp.MAX)
-    return float(t[0])
-
-
-def allreduce_sum(pg, v):
-    if pg is None:
-        return v
-    import torch
-    t = torch.tensor([v], dtype=torch.float64)
-    pg.all_reduce(t, op=pg.ReduceOp.SUM)
+    pg.all_reduce(t, op=getattr(pg.ReduceOp, op))
     return float(t[0])
 
 
@@ -68,21 +61,27 @@ def cpu_baseline(sample: bytes):
     import oracle_lib as O
     t0 = time.perf_counter()
     rc, used, out, _ = O.sw_compress("GZIP_EXT", sample, CHUNK, 1, cap=len(sample) * 9 // 8 + 65536)
-    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
     assert rc == 0 and used == len(sample)
-    return {"value": round(len(sample) / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "%d MiB of the same buffer, GZIP_EXT L1 64 KB chunks, compress only, oracle/libqzoracle.so"
-                      % (len(sample) >> 20),
+    rc, cused, back = O.sw_decompress("GZIP_EXT", out, len(sample) + 64)
+    t2 = time.perf_counter()
+    assert rc == 0 and back == sample
+    both = 2 * len(sample) / (t2 - t0) / 1e9
+    return {"value": round(both, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "compress": round(len(sample) / (t1 - t0) / 1e9, 4), "decompress": round(len(sample) / (t2 - t1) / 1e9, 4),
+            "sample": "%d MiB of the same buffer, GZIP_EXT L1 64 KB chunks, compress + decompress, "
+                      "oracle/libqzoracle.so, 1 thread" % (len(sample) >> 20),
             "ratio": round(len(out) / len(sample), 4)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mb", type=int, default=4096, help="buffer size per GPU in MiB (default: the 4 GB config)")
     ap.add_argument("--base-mb", type=int, default=128, help="distinct synthetic data generated per GPU (tiled)")
+    ap.add_argument("--cpu-mb", type=int, default=8, help="sample size for the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -94,63 +93,85 @@ def main():
     total = args.mb << 20
     base_n = min(args.base_mb << 20, total)
     base = datagen.gen("silesia", base_n, 20250523 + rank)
-    # resident input: tile the base corpus (chunks are independent => no cross-tile redundancy is exploitable)
     d_src = ctx.alloc(total)
-    for off in range(0, total, base_n):
+    for off in range(0, total, base_n):       # tile: chunks are independent, nothing is shared across tiles
         d_src.upload(base[:min(base_n, total - off)], off)
     ncalls = (total + CALL_BYTES - 1) // CALL_BYTES
     call_n = [min(CALL_BYTES, total - i * CALL_BYTES) for i in range(ncalls)]
-    d_dst = [ctx.alloc(qatzip_amd.max_deflate_len(n, CHUNK)) for n in call_n]
+    d_comp = [ctx.alloc(qatzip_amd.max_deflate_len(n, CHUNK)) for n in call_n]
+    d_back = ctx.alloc(max(call_n))
+
+    def view(buf, off, n):
+        v = qatzip_amd.DevBuf.__new__(qatzip_amd.DevBuf)
+        v.ctx, v.nbytes, v.ptr = buf.ctx, n, buf.ptr + off
+        return v
+
+    comp_len = [0] * ncalls
+
+    def compress_all():
+        for i, n in enumerate(call_n):
+            ctx.deflate_raw_async(view(d_src, i * CALL_BYTES, n), n, CHUNK, 1, 1, d_comp[i])
+            ctx.sync()
+            comp_len[i] = ctx.result()
+
+    def decompress_all():
+        for i, n in enumerate(call_n):
+            iu, ol, crc = ctx.inflate_stream(d_comp[i], comp_len[i], d_back, CHUNK, want_crc=True)
+            assert iu == comp_len[i] and ol == n
 
     def step():
-        outs = []
-        for i, n in enumerate(call_n):
-            src_view = qatzip_amd.DevBuf.__new__(qatzip_amd.DevBuf)
-            src_view.ctx, src_view.nbytes, src_view.ptr = ctx, n, d_src.ptr + i * CALL_BYTES
-            ctx.deflate_raw_async(src_view, n, CHUNK, 1, 1, d_dst[i])
-            ctx.sync()
-            outs.append(ctx.result())
-        return outs
+        compress_all()
+        decompress_all()
 
     for _ in range(args.warmup):
-        outs = step()
-    timing = ctx.timing()
+        step()
+    # parity guard outside the timed region: what came back is what went in
+    assert ctx.crc32(d_back, call_n[-1]) == ctx.crc32(view(d_src, (ncalls - 1) * CALL_BYTES, call_n[-1]), call_n[-1])
+
     barrier(pg); ctx.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        outs = step()
+        step()
     ctx.sync(); barrier(pg)
-    dt = time.perf_counter() - t0
-    dt = allreduce_max(pg, dt)
-    timing = ctx.timing()
-    comp_total = allreduce_sum(pg, float(sum(outs)))
+    dt = allreduce(pg, time.perf_counter() - t0, "MAX")
+
+    # per-direction split and the K1 roofline probe (untimed by the contract, reported alongside)
+    ctx.sync(); t1 = time.perf_counter(); compress_all(); ctx.sync(); tc = time.perf_counter() - t1
+    t1 = time.perf_counter(); decompress_all(); ctx.sync(); td = time.perf_counter() - t1
+    inf_ms = ctx.inflate_timing()
+    probe_n = min(BATCH_CHUNKS * CHUNK, call_n[0])
+    ctx.deflate_raw_async(view(d_src, 0, probe_n), probe_n, CHUNK, 1, 1, d_comp[0]); ctx.sync()
+    probe_out = ctx.result()
+    k_ms = ctx.timing()                      # single batch => K1 ran alone on the chip
+    comp_total = allreduce(pg, float(sum(comp_len)), "SUM")
     raw_total = float(total) * world
+    tc = allreduce(pg, tc, "MAX"); td = allreduce(pg, td, "MAX")
 
     if rank == 0:
-        value = raw_total * args.steps / dt / 1e9
+        value = 2.0 * raw_total * args.steps / dt / 1e9
         ratio = comp_total / raw_total
-        # dominant kernel = K1 (LZ77): one launch = one batch of 2048 chunks; algorithmic bytes = U + C of the batch
-        batch_chunks = min(2048, (call_n[-1] + CHUNK - 1) // CHUNK)
-        nb = min(2, (call_n[-1] + CHUNK * 2048 - 1) // (CHUNK * 2048))
-        lz_ms = timing[0] / max(nb, 1)
-        alg_bytes = batch_chunks * CHUNK * (1.0 + ratio)
-        achieved = alg_bytes / (lz_ms * 1e-3) / 1e9 if lz_ms > 0 else 0.0
+        alg_bytes = probe_n + probe_out                       # U + C of one K1 launch
+        achieved = alg_bytes / (k_ms[0] * 1e-3) / 1e9 if k_ms[0] > 0 else 0.0
         res = {
-            "metric": "compress GB/s (input bytes), QZ_DEFLATE_GZIP_EXT L1, 64 KB chunks",
+            "metric": "compress + decompress GB/s (input bytes), QZ_DEFLATE_GZIP_EXT L1, 64 KB chunks",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "QZ_DEFLATE_GZIP_EXT level 1, 64 KB chunks, %d MiB Silesia-like buffer per GPU "
-                                   "(%d MiB distinct, tiled), %d call(s) of <= 2 GiB, compress" %
+                                   "(%d MiB distinct, tiled), %d call(s) of <= 2 GiB, compress then decompress" %
                                    (args.mb, base_n >> 20, ncalls),
-                       "chunk": CHUNK, "ratio": round(ratio, 4), "parallelism": "chunks sharded, %d rank(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "qzk_lz77_kernel", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "launch_ms": round(lz_ms, 3),
-                         "kernel_ms_first_batches": [round(x, 3) for x in timing]},
+                       "chunk": CHUNK, "ratio": round(ratio, 4), "parallelism": "chunks sharded over %d rank(s), "
+                       "no data-path collective" % world,
+                       "compress_GBps": round(raw_total / tc / 1e9, 3), "decompress_GBps": round(raw_total / td / 1e9, 3)},
+            "roofline": {"bound": "hbm", "kernel": "qzk_lz77_kernel", "achieved": round(achieved, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": None, "launch_ms": round(k_ms[0], 3), "launch_chunks": probe_n // CHUNK,
+                         "other_kernels_ms": {"qzk_huff_kernel": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
+                                              "qzk_inflate_kernel(last call)": round(inf_ms[0], 3),
+                                              "qzk_crc_kernel(last call)": round(inf_ms[1], 3)}},
         }
-        if not args.no_cpu and world >= 1:
-            res["cpu_baseline"] = cpu_baseline(base[:16 << 20].tobytes())
+        if not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(base[:args.cpu_mb << 20].tobytes())
         print(json.dumps(res))
     if pg is not None:
         pg.destroy_process_group()

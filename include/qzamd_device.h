@@ -69,6 +69,39 @@ int qzd_result(qzd_ctx *ctx, uint64_t *h_out_len, uint32_t *h_chunk_crc, uint32_
  * with hipEvents on the stream the kernels ran on: [0]=lz77 [1]=huffman [2]=scan+gather [3]=total */
 int qzd_last_timing(qzd_ctx *ctx, float ms[4]);
 
+/* ------------------------------------------------------------------ decompress side
+ *
+ * Segment records shared with the kernels (see qatzip_amd/csrc/qzk_inflate.h):
+ *   qzd_infseg { u64 in_off; u64 out_off; u32 in_len; u32 out_cap; u32 flags; u32 pad; }
+ *   qzd_infres { i32 status; u32 in_used; u32 out_len; u32 nblocks; }
+ * status: 0 = ended with BFINAL, 1 = ended at a flush marker, <0 = error
+ * (-1 data, -2 output capacity, -3 input exhausted, -4 needs earlier history).
+ * flags: 1 = count only (write nothing), 2 = continue through flush markers.
+ */
+typedef struct { uint64_t in_off, out_off; uint32_t in_len, out_cap, flags, pad; } qzd_infseg;
+typedef struct { int32_t status; uint32_t in_used, out_len, nblocks; } qzd_infres;
+typedef struct { uint64_t off; uint32_t len, pad; } qzd_range;
+
+/* raw-inflate nsegs independent segments (one wave each); what qzDecompress does per member when the
+ * member sizes are known from the gzip-ext header (src/qatzip_utils.c:1232-1345) */
+int qzd_inflate_segments(qzd_ctx *ctx, const uint8_t *d_comp, uint8_t *d_out, const void *h_segs,
+                         uint32_t nsegs, void *h_res);
+
+/* raw-inflate ONE deflate stream that starts at d_src and ends with its BFINAL block; the stream is cut
+ * at Z_FULL_FLUSH markers and decoded segment-parallel (seg_hint = expected bytes per segment, normally
+ * the session's hw_buff_sz; 0 = unknown).  Replaces the inflate() loop of src/qatzip_sw.c:339.
+ *   h_in_used <- compressed bytes consumed   h_out_len <- bytes produced
+ *   h_crc     <- (optional) CRC-32 of the output, for the gzip trailer check */
+int qzd_inflate_stream(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                       uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc);
+
+/* CRC-32 (zlib crc32()) of HBM-resident data */
+int qzd_crc32(qzd_ctx *ctx, const uint8_t *d_data, uint64_t n, uint32_t *h_crc);
+int qzd_crc32_ranges(qzd_ctx *ctx, const uint8_t *d_data, const void *h_ranges, uint32_t nranges, uint32_t *h_crc);
+
+/* GPU time (ms) spent in [0] inflate kernels, [1] crc kernels by the last qzd_inflate_stream call */
+int qzd_last_inflate_timing(qzd_ctx *ctx, float ms[2]);
+
 #ifdef __cplusplus
 }
 #endif

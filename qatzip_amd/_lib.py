@@ -42,15 +42,27 @@ def load(build_if_missing=True):
     L.qzd_sync.argtypes = [vp]
     L.qzd_result.argtypes = [vp, C.POINTER(C.c_uint64), vp, C.c_uint32]
     L.qzd_last_timing.argtypes = [vp, C.POINTER(C.c_float * 4)]
+    L.qzd_inflate_segments.argtypes = [vp, u8p, u8p, vp, C.c_uint32, vp]
+    L.qzd_inflate_stream.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.qzd_crc32.argtypes = [vp, u8p, C.c_uint64, C.POINTER(C.c_uint32)]
+    L.qzd_crc32_ranges.argtypes = [vp, u8p, vp, C.c_uint32, vp]
+    L.qzd_last_inflate_timing.argtypes = [vp, C.POINTER(C.c_float * 2)]
     _lib = L
     return L
+
+
+SEG_DT = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"),
+                   ("flags", "<u4"), ("pad", "<u4")])
+RES_DT = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
 
 
 def exported_symbols():
     """Names include/*.h declares that must be exported by the library (checked on CPU too)."""
     return ["qzd_create", "qzd_destroy", "qzd_last_error", "qzd_device_count", "qzd_dev_alloc", "qzd_dev_free",
             "qzd_h2d", "qzd_d2h", "qzd_host_alloc_pinned", "qzd_host_free_pinned", "qzd_deflate_raw",
-            "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing"]
+            "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing", "qzd_inflate_segments",
+            "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing"]
 
 
 class DevBuf:
@@ -132,6 +144,31 @@ class Context:
     def timing(self):
         ms = (C.c_float * 4)()
         self.L.qzd_last_timing(self.h, C.byref(ms))
+        return list(ms)
+
+    # -- inflate
+    def inflate_segments(self, d_comp, d_out, segs):
+        """segs: list of (in_off, out_off, in_len, out_cap, flags) -> structured result array"""
+        sa = np.array([tuple(s) + (0,) for s in segs], dtype=SEG_DT)
+        res = np.zeros(len(segs), RES_DT)
+        self._chk(self.L.qzd_inflate_segments(self.h, d_comp.ptr, d_out.ptr, sa.ctypes.data, len(segs), res.ctypes.data))
+        return res
+
+    def inflate_stream(self, d_src, n, d_dst, seg_hint=65536, want_crc=True, src_off=0):
+        """-> (in_used, out_len, crc or None); raises QzdError on corrupt data / short destination"""
+        iu, ol, crc = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        self._chk(self.L.qzd_inflate_stream(self.h, d_src.ptr + src_off, n, d_dst.ptr, d_dst.nbytes, seg_hint,
+                                            C.byref(iu), C.byref(ol), C.byref(crc) if want_crc else None))
+        return iu.value, ol.value, (crc.value if want_crc else None)
+
+    def crc32(self, d_data, n):
+        crc = C.c_uint32(0)
+        self._chk(self.L.qzd_crc32(self.h, d_data.ptr, n, C.byref(crc)))
+        return crc.value
+
+    def inflate_timing(self):
+        ms = (C.c_float * 2)()
+        self.L.qzd_last_inflate_timing(self.h, C.byref(ms))
         return list(ms)
 
 

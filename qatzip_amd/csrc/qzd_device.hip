@@ -17,12 +17,8 @@
 #include <string.h>
 #include <new>
 
-#include "../../include/qzamd_device.h"
-#include "qzk_deflate_lz77.h"
+#include "qzd_internal.h"
 #include "qzk_deflate_huff.h"
-
-#define QZD_BATCH 2048u
-#define QZD_NBUF 2
 
 /* ------------------------------------------------------------------ utility kernels */
 /* offs[i] = *running + sum(len[0..i)); then *running += sum.  One 1024-thread workgroup. */
@@ -66,29 +62,44 @@ __global__ void qzk_gather_kernel(const uint8_t *slots, uint32_t stride, const u
     for (uint32_t i = (nw << 2) + threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
 }
 
-/* ------------------------------------------------------------------ context */
-struct qzd_ctx {
-    int device;
-    hipStream_t st[QZD_NBUF];
-    hipEvent_t done[QZD_NBUF];
-    /* scratch per buffer set */
-    uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];
-    qzk_lzmeta *meta[QZD_NBUF];
-    size_t sym_cap, slot_cap; uint32_t meta_cap;
-    /* per-call arrays */
-    uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;
-    uint64_t *d_running; uint32_t *d_overflow;
-    uint64_t *h_running; uint32_t *h_overflow;      /* pinned */
-    /* timing */
-    hipEvent_t ev[QZD_NBUF][4]; hipEvent_t ev_begin, ev_end;
-    uint32_t nbatches; float ms[4];
-    uint32_t last_nchunks;
-    char err[256];
-};
+/* ------------------------------------------------------------------ context (qzd_internal.h) */
+int qzd_aux_reserve(qzd_ctx *c, size_t n)
+{
+    if (n <= c->aux_cap) return QZD_OK;
+    hipDeviceSynchronize();
+    if (c->d_aux) hipFree(c->d_aux);
+    if (c->h_aux) hipHostFree(c->h_aux);
+    c->d_aux = NULL; c->h_aux = NULL; c->aux_cap = 0;
+    n = (n + 65535) & ~(size_t)65535;
+    HIPCHK(c, hipMalloc(&c->d_aux, n));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_aux, n, hipHostMallocDefault));
+    c->aux_cap = n;
+    return QZD_OK;
+}
 
-#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-    snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
-    return QZD_ERR_HIP; } } while (0)
+static uint32_t crc_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+
+uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
+{
+    static uint32_t x2n[32];
+    if (!x2n[0]) {
+        uint32_t p = 1u << 30;
+        x2n[0] = p;
+        for (int i = 1; i < 32; i++) x2n[i] = p = crc_multmodp(p, p);
+    }
+    uint32_t p = 1u << 31; unsigned k = 3;
+    for (uint64_t n = len2; n; n >>= 1, k++) if (n & 1) p = crc_multmodp(x2n[k & 31], p);
+    return crc_multmodp(p, crc1) ^ crc2;
+}
 
 extern "C" int qzd_device_count(void)
 {
@@ -132,6 +143,8 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     hipEventDestroy(c->ev_begin); hipEventDestroy(c->ev_end);
     hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
     hipHostFree(c->h_running); hipHostFree(c->h_overflow);
+    if (c->d_aux) hipFree(c->d_aux);
+    if (c->h_aux) hipHostFree(c->h_aux);
     delete c;
 }
 

@@ -1,0 +1,239 @@
+/*
+ * qzd_inflate.hip — host side of the decompress half of the device C ABI.
+ *
+ * The software path's inflate loop (qzSWDecompressMulti / qzDeflateSWDecompress,
+ * src/qatzip_sw.c:258-441,659-695) walks ONE z_stream per member serially.  On the
+ * MI355X the same member is cut into independent segments at the byte-aligned
+ * Z_FULL_FLUSH markers the compress side leaves after every hw_buff_sz chunk
+ * (src/qatzip_sw.c:182-186), every segment is inflated by its own wave (K3), and
+ * the host validates that the segments form one contiguous chain that ends in
+ * BFINAL.  Marker candidates that are not real boundaries (00 00 FF FF can occur
+ * inside compressed data) are discarded by that chain walk.
+ *
+ * Strategy per stream (qzd_inflate_stream):
+ *   1. marker scan (GPU) -> sorted candidate starts
+ *   2. optimistic single pass: candidate k is assumed real and to produce exactly
+ *      seg_hint bytes (the session's hw_buff_sz) at k*seg_hint; validated afterwards
+ *   3. otherwise two passes: count-only decode of all candidates -> chain walk +
+ *      prefix sums on the host -> decode of the true segments at exact offsets
+ *   4. streams whose segments reference earlier history (Z_SYNC_FLUSH producers)
+ *      or have no markers are decoded by one wave straight through.
+ */
+#include <algorithm>
+#include <string.h>
+#include <vector>
+
+#include "qzd_internal.h"
+#include "qzk_inflate.h"
+#include "qzk_checksum.h"
+
+/* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF */
+__global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list, uint32_t cap, uint32_t *count)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 4 <= n; i += stride) {
+        if (qz_ld32(src + i) == 0xFFFF0000u) {
+            uint32_t k = atomicAdd(count, 1u);
+            if (k < cap) list[k] = (uint32_t)(i + 4);
+        }
+    }
+}
+
+extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const void *h_segs,
+                                    uint32_t nsegs, void *h_res)
+{
+    if (!c || !h_segs || !h_res) return QZD_ERR_PARAM;
+    if (nsegs == 0) return QZD_OK;
+    hipSetDevice(c->device);
+    const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
+    int rc = qzd_aux_reserve(c, sb + rb + 64);
+    if (rc) return rc;
+    qzk_infseg *d_segs = (qzk_infseg *)c->d_aux;
+    qzk_infres *d_res = (qzk_infres *)(c->d_aux + ((sb + 15) & ~(size_t)15));
+    hipStream_t st = c->st[0];
+    HIPCHK(c, hipMemcpyAsync(d_segs, h_segs, sb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev[0][0], st));
+    hipLaunchKernelGGL(qzk_inflate_kernel, dim3((nsegs + QZK_INF_WAVES - 1) / QZK_INF_WAVES), dim3(64 * QZK_INF_WAVES),
+                       0, st, d_comp, d_out, d_segs, d_res, nsegs);
+    HIPCHK(c, hipEventRecord(c->ev[0][1], st));
+    HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    float t = 0;
+    if (hipEventElapsedTime(&t, c->ev[0][0], c->ev[0][1]) == hipSuccess) c->inf_ms[0] += t;
+    return QZD_OK;
+}
+
+extern "C" int qzd_crc32_ranges(qzd_ctx *c, const uint8_t *d_data, const void *h_ranges, uint32_t nranges,
+                                uint32_t *h_crc)
+{
+    if (!c || !h_ranges || !h_crc) return QZD_ERR_PARAM;
+    if (nranges == 0) return QZD_OK;
+    hipSetDevice(c->device);
+    const size_t rb = (size_t)nranges * sizeof(qzk_range), cb = (size_t)nranges * 4;
+    int rc = qzd_aux_reserve(c, rb + cb + 64);
+    if (rc) return rc;
+    qzk_range *d_r = (qzk_range *)c->d_aux;
+    uint32_t *d_c = (uint32_t *)(c->d_aux + ((rb + 15) & ~(size_t)15));
+    hipStream_t st = c->st[0];
+    HIPCHK(c, hipMemcpyAsync(d_r, h_ranges, rb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev[0][2], st));
+    hipLaunchKernelGGL(qzk_crc_kernel, dim3(nranges), dim3(QZK_HT), 0, st, d_data, d_r, nranges, d_c);
+    HIPCHK(c, hipEventRecord(c->ev[0][3], st));
+    HIPCHK(c, hipMemcpyAsync(h_crc, d_c, cb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    float t = 0;
+    if (hipEventElapsedTime(&t, c->ev[0][2], c->ev[0][3]) == hipSuccess) c->inf_ms[1] += t;
+    return QZD_OK;
+}
+
+/* CRC-32 of d_data[0..n) folded on the host from 256 KiB ranges */
+extern "C" int qzd_crc32(qzd_ctx *c, const uint8_t *d_data, uint64_t n, uint32_t *h_crc)
+{
+    const uint32_t R = 256 * 1024;
+    uint32_t nr = (uint32_t)((n + R - 1) / R);
+    *h_crc = 0;
+    if (nr == 0) return QZD_OK;
+    std::vector<qzk_range> rg(nr);
+    std::vector<uint32_t> cr(nr);
+    for (uint32_t i = 0; i < nr; i++) { rg[i].off = (uint64_t)i * R; rg[i].len = (uint32_t)std::min<uint64_t>(R, n - rg[i].off); rg[i].pad = 0; }
+    int rc = qzd_crc32_ranges(c, d_data, rg.data(), nr, cr.data());
+    if (rc) return rc;
+    uint32_t crc = cr[0];
+    for (uint32_t i = 1; i < nr; i++) crc = qzd_crc32_combine(crc, cr[i], rg[i].len);
+    *h_crc = crc;
+    return QZD_OK;
+}
+
+static int find_markers(qzd_ctx *c, const uint8_t *d_src, uint64_t n, std::vector<uint32_t> &pos)
+{
+    pos.clear();
+    if (n < 4) return QZD_OK;
+    uint32_t cap = (uint32_t)(n / 256 + 4096);
+    int rc = qzd_aux_reserve(c, (size_t)cap * 4 + 64);
+    if (rc) return rc;
+    uint32_t *d_cnt = (uint32_t *)c->d_aux, *d_list = d_cnt + 4;
+    hipStream_t st = c->st[0];
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, st));
+    hipLaunchKernelGGL(qzk_marker_kernel, dim3(2048), dim3(256), 0, st, d_src, n, d_list, cap - 8, d_cnt);
+    HIPCHK(c, hipMemcpyAsync(c->h_aux, d_cnt, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    uint32_t cnt = *(uint32_t *)c->h_aux;
+    if (cnt > cap - 8) return 1;       /* too many candidates: caller falls back to the serial walk */
+    if (cnt) {
+        HIPCHK(c, hipMemcpy(c->h_aux, d_list, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        pos.assign((uint32_t *)c->h_aux, (uint32_t *)c->h_aux + cnt);
+        std::sort(pos.begin(), pos.end());
+    }
+    return QZD_OK;
+}
+
+static int map_status(int st)
+{
+    switch (st) {
+    case QZK_INF_EOUT: return QZD_ERR_DSTCAP;
+    default: return QZD_ERR_DATA;
+    }
+}
+
+extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                                  uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc)
+{
+    if (!c || !d_src || !h_in_used || !h_out_len) return QZD_ERR_PARAM;
+    if (n == 0 || n > 0xffffffffull) return QZD_ERR_PARAM;
+    hipSetDevice(c->device);
+    c->inf_ms[0] = c->inf_ms[1] = 0;
+    *h_in_used = 0; *h_out_len = 0;
+    std::vector<uint32_t> mk;
+    int rc = find_markers(c, d_src, n, mk);
+    if (rc < 0) return rc;
+    const bool scan_ok = rc == 0;
+    std::vector<uint32_t> start;            /* candidate segment starts */
+    start.push_back(0);
+    if (scan_ok) for (uint32_t p : mk) if (p < n) start.push_back(p);
+    const uint32_t ns = (uint32_t)start.size();
+    std::vector<qzk_infseg> segs(ns);
+    std::vector<qzk_infres> res(ns);
+    uint64_t total_out = 0, total_in = 0;
+    bool done = false;
+
+    /* --- 2. optimistic single pass --- */
+    if (scan_ok && seg_hint && ns > 1) {
+        for (uint32_t k = 0; k < ns; k++) {
+            uint64_t oo = (uint64_t)k * seg_hint;
+            segs[k].in_off = start[k]; segs[k].in_len = (uint32_t)(n - start[k]);
+            segs[k].out_off = oo < dst_cap ? oo : dst_cap;
+            segs[k].out_cap = (uint32_t)std::min<uint64_t>(seg_hint, dst_cap - segs[k].out_off);
+            segs[k].flags = 0; segs[k].pad = 0;
+        }
+        rc = qzd_inflate_segments(c, d_src, d_dst, segs.data(), ns, res.data());
+        if (rc) return rc;
+        bool ok = true; uint32_t k = 0;
+        for (;; k++) {
+            if (k >= ns) { ok = false; break; }
+            const qzk_infres &r = res[k];
+            if (r.status == QZK_INF_FINAL) { total_out = (uint64_t)k * seg_hint + r.out_len; total_in = (uint64_t)start[k] + r.in_used; break; }
+            if (r.status != QZK_INF_FLUSH || r.out_len != seg_hint) { ok = false; break; }
+            if (k + 1 >= ns || start[k + 1] != start[k] + r.in_used) { ok = false; break; }
+        }
+        done = ok;
+    }
+
+    /* --- 3. two passes over the candidates --- */
+    if (!done && scan_ok && ns > 1) {
+        for (uint32_t k = 0; k < ns; k++) {
+            segs[k].in_off = start[k]; segs[k].in_len = (uint32_t)(n - start[k]);
+            segs[k].out_off = 0; segs[k].out_cap = 0xffffffffu; segs[k].flags = QZK_INF_COUNT_ONLY; segs[k].pad = 0;
+        }
+        rc = qzd_inflate_segments(c, d_src, d_dst, segs.data(), ns, res.data());
+        if (rc) return rc;
+        std::vector<qzk_infseg> chain;
+        uint64_t oo = 0; uint32_t k = 0; bool ok = true;
+        for (;;) {
+            const qzk_infres &r = res[k];
+            if (r.status != QZK_INF_FINAL && r.status != QZK_INF_FLUSH) { ok = false; break; }
+            qzk_infseg s = segs[k];
+            s.flags = 0; s.out_off = oo; s.out_cap = r.out_len; s.in_len = r.in_used;
+            if (oo + r.out_len > dst_cap) return QZD_ERR_DSTCAP;
+            chain.push_back(s);
+            oo += r.out_len;
+            if (r.status == QZK_INF_FINAL) { total_in = (uint64_t)start[k] + r.in_used; break; }
+            uint32_t nxt = start[k] + r.in_used;
+            auto it = std::lower_bound(start.begin() + k + 1, start.end(), nxt);
+            if (it == start.end() || *it != nxt) { ok = false; break; }
+            k = (uint32_t)(it - start.begin());
+        }
+        if (ok) {
+            std::vector<qzk_infres> r2(chain.size());
+            rc = qzd_inflate_segments(c, d_src, d_dst, chain.data(), (uint32_t)chain.size(), r2.data());
+            if (rc) return rc;
+            for (size_t i = 0; i < chain.size(); i++)
+                if (r2[i].status < 0 || r2[i].out_len != chain[i].out_cap) { ok = false; break; }
+            if (ok) { total_out = oo; done = true; }
+        }
+    }
+
+    /* --- 4. one wave, straight through --- */
+    if (!done) {
+        qzk_infseg s; qzk_infres r;
+        s.in_off = 0; s.in_len = (uint32_t)n; s.out_off = 0;
+        s.out_cap = (uint32_t)std::min<uint64_t>(dst_cap, 0xffffffffu); s.flags = QZK_INF_THROUGH_FLUSH; s.pad = 0;
+        rc = qzd_inflate_segments(c, d_src, d_dst, &s, 1, &r);
+        if (rc) return rc;
+        if (r.status != QZK_INF_FINAL) {
+            snprintf(c->err, sizeof(c->err), "inflate failed: status %d after %u bytes", r.status, r.out_len);
+            return map_status(r.status);
+        }
+        total_out = r.out_len; total_in = r.in_used;
+    }
+    *h_in_used = total_in; *h_out_len = total_out;
+    if (h_crc) return qzd_crc32(c, d_dst, total_out, h_crc);
+    return QZD_OK;
+}
+
+extern "C" int qzd_last_inflate_timing(qzd_ctx *c, float ms[2])
+{
+    if (!c || !ms) return QZD_ERR_PARAM;
+    ms[0] = c->inf_ms[0]; ms[1] = c->inf_ms[1];
+    return QZD_OK;
+}

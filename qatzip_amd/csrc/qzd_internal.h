@@ -1,0 +1,45 @@
+/* qzd_internal.h — context shared by the host-side translation units of libqatzip_amd.so */
+#ifndef QZD_INTERNAL_H
+#define QZD_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/qzamd_device.h"
+#include "qzk_deflate_lz77.h"
+
+#define QZD_BATCH 2048u
+#define QZD_NBUF 2
+
+struct qzd_ctx {
+    int device;
+    hipStream_t st[QZD_NBUF];
+    hipEvent_t done[QZD_NBUF];
+    /* scratch per buffer set */
+    uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];
+    qzk_lzmeta *meta[QZD_NBUF];
+    size_t sym_cap, slot_cap; uint32_t meta_cap;
+    /* per-call arrays */
+    uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;
+    uint64_t *d_running; uint32_t *d_overflow;
+    uint64_t *h_running; uint32_t *h_overflow;      /* pinned */
+    /* timing */
+    hipEvent_t ev[QZD_NBUF][4]; hipEvent_t ev_begin, ev_end;
+    uint32_t nbatches; float ms[4];
+    uint32_t last_nchunks;
+    /* generic small scratch for the decompress side: device + pinned host mirror */
+    uint8_t *d_aux, *h_aux; size_t aux_cap;
+    float inf_ms[4];
+    char err[256];
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+    return QZD_ERR_HIP; } } while (0)
+
+/* grow the aux scratch pair to at least n bytes */
+int qzd_aux_reserve(qzd_ctx *c, size_t n);
+
+/* host-side CRC-32 helpers (zlib crc32_combine semantics) */
+uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+
+#endif

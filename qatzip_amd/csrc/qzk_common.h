@@ -20,7 +20,7 @@
 #else
 #include <hip/hip_runtime.h>
 #define QZ_DEV static __device__ __forceinline__
-#define QZ_KERNEL __global__ void
+#define QZ_KERNEL static __global__ void   /* internal linkage: kernels live in headers shared by several .hip units */
 #define QZ_LDS __shared__
 #define QZ_CONST static __device__ const
 

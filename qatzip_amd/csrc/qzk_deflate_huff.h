@@ -27,6 +27,8 @@
 #define QZK_BLCODES 19
 #define QZK_HEAP 573
 
+typedef struct { uint32_t crc_tab[256]; uint32_t x2n[32]; uint32_t red[16]; } qzk_crc_lds;
+
 typedef struct {
     /* frequencies (u32 for LDS atomics) */
     uint32_t fl[288], fd[32], fbl[20];
@@ -46,9 +48,7 @@ typedef struct {
     /* output staging */
     uint32_t stage[420];
     uint32_t scan[8];
-    uint32_t crc_tab[256];
-    uint32_t x2n[32];
-    uint32_t red[8];
+    qzk_crc_lds crc;
 } qzk_huff_lds;
 
 QZ_DEV uint32_t qzk_bitrev(uint32_t code, int len)
@@ -368,7 +368,7 @@ QZ_DEV uint32_t qzk_x2nmodp(const uint32_t *x2n, uint64_t n, unsigned k)
 }
 
 /* crc32 of src[0..n) by the whole workgroup (finalised, zlib convention) */
-QZ_DEV uint32_t qzk_block_crc32(qzk_huff_lds *S, const uint8_t *src, uint32_t n)
+QZ_DEV uint32_t qzk_block_crc32(qzk_crc_lds *S, const uint8_t *src, uint32_t n)
 {
     const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
     {
@@ -423,7 +423,7 @@ QZ_KERNEL qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
     qzk_bitout bo;
     bo.out = slots + (uint64_t)chunk * slot_stride; bo.nbytes = 0; bo.cbits = 0; bo.carry = 0;
 
-    const uint32_t crc = qzk_block_crc32(&S, in, n);
+    const uint32_t crc = qzk_block_crc32(&S.crc, in, n);
 
     /* blocks 0..nfull-1 are full; block nfull is the remainder (possibly empty) */
     const uint32_t nblocks = nfull + ((is_final || nsym > nfull * QZK_LITBUF) ? 1 : 0);

@@ -8,6 +8,8 @@
 #include "hipsim.h"
 #include "../../qatzip_amd/csrc/qzk_deflate_lz77.h"
 #include "../../qatzip_amd/csrc/qzk_deflate_huff.h"
+#include "../../qatzip_amd/csrc/qzk_inflate.h"
+#include "../../qatzip_amd/csrc/qzk_checksum.h"
 #include <vector>
 
 extern "C" {
@@ -47,4 +49,18 @@ int sim_deflate(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uin
 }
 
 unsigned sim_meta_size(void) { return (unsigned)sizeof(qzk_lzmeta); }
+
+/* K3: inflate nsegs segments described by (in_off, out_off, in_len, out_cap, flags, pad) records */
+int sim_inflate(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
+{
+    uint32_t grid = (nsegs + QZK_INF_WAVES - 1) / QZK_INF_WAVES;
+    sim::launch(grid, 64 * QZK_INF_WAVES, 0, [&] { qzk_inflate_kernel(comp, out, segs, res, nsegs); });
+    return 0;
+}
+
+int sim_crc(const uint8_t *data, const qzk_range *ranges, uint32_t nranges, uint32_t *crc_out)
+{
+    sim::launch(nranges, QZK_HT, 0, [&] { qzk_crc_kernel(data, ranges, nranges, crc_out); });
+    return 0;
+}
 }

@@ -1,0 +1,103 @@
+"""GPU parity for K3 (raw inflate) + K6 (CRC-32): decode streams produced by the oracle / system zlib /
+our own compressor and compare with the known plaintext - bit-exact; plus the segment-chain logic."""
+import zlib
+
+import numpy as np
+import pytest
+
+import datagen
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import qatzip_amd
+    c = qatzip_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _inflate(ctx, comp, cap, hint=65536):
+    d_src = ctx.alloc(len(comp)); d_src.upload(comp)
+    d_dst = ctx.alloc(max(cap, 1))
+    try:
+        iu, ol, crc = ctx.inflate_stream(d_src, len(comp), d_dst, hint)
+        out = d_dst.download(ol).tobytes()
+    finally:
+        d_src.free(); d_dst.free()
+    return iu, out, crc
+
+
+@pytest.mark.parametrize("kind", datagen.KINDS)
+def test_inflate_oracle_streams(ctx, kind):
+    for n, chunk in ((1, 65536), (1000, 65536), (65536, 65536), (200777, 65536), (70000, 16384), (300000, 131072)):
+        if kind == "lzmix" and n > 140000:
+            n = 140000
+        src = datagen.gen_bytes(kind, n, 21)
+        rc, _, comp, _ = O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)
+        assert rc == 0
+        for hint in (chunk, 65536, 0):                   # right hint, wrong hint (two-pass), no hint
+            iu, out, crc = _inflate(ctx, comp, n, hint)
+            assert out == src, (kind, n, chunk, hint)
+            assert iu == len(comp) and crc == (zlib.crc32(src) & 0xffffffff)
+
+
+def test_inflate_foreign_zlib_levels(ctx):
+    # streams from other producers: no flush markers, long codes, stored blocks, sync flushes with history
+    src = datagen.gen_bytes("silesia", 300000, 4)
+    for lvl in (0, 1, 6, 9):
+        co = zlib.compressobj(lvl, zlib.DEFLATED, -15)
+        comp = co.compress(src) + co.flush()
+        iu, out, crc = _inflate(ctx, comp, len(src))
+        assert out == src and iu == len(comp)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = b""
+    for i in range(0, len(src), 50000):
+        comp += co.compress(src[i:i + 50000]) + co.flush(zlib.Z_SYNC_FLUSH)     # history crosses the markers
+    comp += co.flush()
+    iu, out, crc = _inflate(ctx, comp, len(src))
+    assert out == src and iu == len(comp)
+
+
+def test_inflate_marker_pattern_inside_data(ctx):
+    # plaintext full of 00 00 FF FF, stored (incompressible wrapper) so the pattern survives into the stream
+    rnd = datagen.gen("rand", 40000, 3)
+    rnd[1000:1004] = [0, 0, 0xff, 0xff]
+    rnd[20000:20004] = [0, 0, 0xff, 0xff]
+    src = rnd.tobytes() * 3
+    rc, _, comp, _ = O.sw_compress("RAW", src, 65536, 1, cap=len(src) * 2)
+    assert comp.count(b"\x00\x00\xff\xff") > len(src) // 65536
+    iu, out, crc = _inflate(ctx, comp, len(src))
+    assert out == src and iu == len(comp)
+
+
+def test_inflate_errors(ctx):
+    import qatzip_amd
+    src = datagen.gen_bytes("text", 100000, 8)
+    rc, _, comp, _ = O.sw_compress("RAW", src, 65536, 1)
+    bad = bytearray(comp); bad[len(bad) // 3] ^= 0x5a
+    try:
+        iu, out, crc = _inflate(ctx, bytes(bad), len(src))
+        assert out != src or crc != (zlib.crc32(src) & 0xffffffff)      # corruption must not pass silently
+    except qatzip_amd.QzdError:
+        pass
+    with pytest.raises(qatzip_amd.QzdError):
+        _inflate(ctx, comp, 5000)                                       # destination too small
+    with pytest.raises(qatzip_amd.QzdError):
+        _inflate(ctx, comp[:len(comp) // 2], len(src))                  # truncated input
+
+
+def test_roundtrip_own_compressor_large(ctx):
+    import qatzip_amd
+    base = datagen.gen("silesia", 8 << 20, 13)
+    src = np.concatenate([base, base[::-1], base ^ 3]).tobytes()          # 24 MiB, 384 chunks
+    d_src = ctx.alloc(len(src)); d_src.upload(src)
+    d_c = ctx.alloc(qatzip_amd.max_deflate_len(len(src)))
+    n, crcs = ctx.deflate_raw(d_src, len(src), 65536, 1, 1, d_c)
+    d_o = ctx.alloc(len(src))
+    iu, ol, crc = ctx.inflate_stream(d_c, n, d_o, 65536)
+    assert iu == n and ol == len(src) and crc == (zlib.crc32(src) & 0xffffffff)
+    assert d_o.download(ol).tobytes() == src
+    assert ctx.crc32(d_src, len(src)) == (zlib.crc32(src) & 0xffffffff)
