@@ -65,6 +65,9 @@ int qzd_deflate_raw_async(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32
 int qzd_sync(qzd_ctx *ctx);
 int qzd_result(qzd_ctx *ctx, uint64_t *h_out_len, uint32_t *h_chunk_crc, uint32_t nchunks);
 
+/* compressed length of each chunk of the last deflate call (nchunks entries) */
+int qzd_chunk_lens(qzd_ctx *ctx, uint32_t *h_len, uint32_t nchunks);
+
 /* elapsed GPU time (ms) of the kernels of the last *_async call, per kernel family, measured
  * with hipEvents on the stream the kernels ran on: [0]=lz77 [1]=huffman [2]=scan+gather [3]=total */
 int qzd_last_timing(qzd_ctx *ctx, float ms[4]);

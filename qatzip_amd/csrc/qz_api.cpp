@@ -1,0 +1,719 @@
+/*
+ * qz_api.cpp — the qatzip.h application interface (include/qatzip.h) on top of the
+ * device-resident MI355X backend (include/qzamd_device.h).
+ *
+ * Structure of the reference this stands in for (nothing is copied, the flow is
+ * re-thought for a GPU that takes a whole call as one batch):
+ *   request engine   src/qatzip.c:1874-2097 (compress), :2446-2671 (decompress)
+ *   SW chunk loop    src/qatzip_sw.c:77-256 (one stream per call, header/trailer, CRC out-param)
+ *   member loop      src/qatzip_sw.c:394-441 (decompress member after member)
+ *   defaults/params  src/qatzip.c:2780-2928, src/qatzip_utils.c:395-886
+ *   pinned memory    src/qatzip_mem.c:102-241
+ * Where the QAT engine keeps <=32 chunks in flight on one instance (doCompressIn/Out,
+ * src/qatzip.c:1483-1764), a call here is: one H2D copy, one batch of kernels over all
+ * chunks, one D2H copy.  There is NO software fallback: without a GPU qzInit reports
+ * QZ_NOSW_NO_HW and every request fails (the CPU oracle under oracle/ is test-only).
+ *
+ * Wire formats produced are those of the reference's SOFTWARE path:
+ * one gzip / gzip-ext / zlib / 4B member per stream with a Z_FULL_FLUSH marker after
+ * every hw_buff_sz chunk.
+ */
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <set>
+#include <vector>
+
+#include "../../include/qatzip.h"
+#include "../../include/qzamd_device.h"
+
+enum { F_4B = 0, F_GZIP, F_GZIP_EXT, F_RAW, F_LZ4, F_LZ4S, F_ZLIB };   /* DataFormatInternal_T order, src/qatzip_internal.h:238-253 */
+
+struct Params {
+    QzHuffmanHdr_T huffman_hdr; QzDirection_T direction; int fmt; unsigned comp_lvl; unsigned char comp_algorithm;
+    unsigned max_forks; unsigned char sw_backup; unsigned hw_buff_sz, strm_buff_sz, input_sz_thrshold,
+    req_cnt_thrshold, wait_cnt_thrshold; QzPollingMode_T polling_mode; unsigned is_sensitive_mode;
+    unsigned char stop_at_stream_end, zlib_format; qzLZ4SCallbackFn cb; void *cb_ext; unsigned lz4s_mini_match;
+};
+
+struct Sess {
+    Params p;
+    qzd_ctx *ctx;
+    uint8_t *d_in, *d_out; size_t in_cap, out_cap;
+    /* open deflate stream (qzCompress with last == 0 keeps it open, src/qatzip_sw.c:115,233-253) */
+    bool open; uint32_t run_sum; uint64_t st_in, st_out;
+    unsigned char end_of_stream;
+    std::vector<uint32_t> lens, crcs;
+};
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER, g_mem_lock = PTHREAD_MUTEX_INITIALIZER;
+static int g_inited, g_ndev, g_next_dev;
+static QzLogLevel_T g_log = LOG_WARNING;
+static std::set<void *> g_pinned;
+static const Params k_factory = {QZ_HUFF_HDR_DEFAULT, QZ_DIRECTION_DEFAULT, F_GZIP_EXT, QZ_COMP_LEVEL_DEFAULT,
+                                 QZ_COMP_ALGOL_DEFAULT, QZ_MAX_FORK_DEFAULT, QZ_SW_BACKUP_DEFAULT, QZ_HW_BUFF_SZ,
+                                 QZ_STRM_BUFF_SZ_DEFAULT, QZ_COMP_THRESHOLD_DEFAULT, QZ_REQ_THRESHOLD_DEFAULT,
+                                 QZ_WAIT_CNT_THRESHOLD_DEFAULT, QZ_PERIODICAL_POLLING, 0, 0, 0, NULL, NULL, 3};
+static Params g_def = k_factory;
+
+static void logmsg(QzLogLevel_T lvl, const char *fmt, ...)
+{
+    if (lvl > g_log) return;
+    va_list ap; va_start(ap, fmt);
+    fputs(lvl <= LOG_ERROR ? "[qatzip-amd error] " : "[qatzip-amd] ", stderr);
+    vfprintf(stderr, fmt, ap); va_end(ap);
+}
+
+extern "C" QzLogLevel_T qzSetLogLevel(QzLogLevel_T level)
+{
+    QzLogLevel_T old = g_log;
+    if ((int)level >= LOG_NONE && (int)level <= LOG_DEBUG3) g_log = level;
+    return old;
+}
+
+/* ------------------------------------------------------------------ parameters */
+static int check_common(const Params &p, bool lz4)
+{
+    if (p.direction > QZ_DIR_BOTH || p.sw_backup > 1) return QZ_PARAMS;
+    if (p.hw_buff_sz < QZ_HW_BUFF_MIN_SZ || p.hw_buff_sz > QZ_HW_BUFF_MAX_SZ || (p.hw_buff_sz & (p.hw_buff_sz - 1))) return QZ_PARAMS;
+    if (p.strm_buff_sz < QZ_STRM_BUFF_MIN_SZ || p.strm_buff_sz > QZ_STRM_BUFF_MAX_SZ) return QZ_PARAMS;
+    if (p.input_sz_thrshold < QZ_COMP_THRESHOLD_MINIMUM) return QZ_PARAMS;
+    if (p.req_cnt_thrshold < QZ_REQ_THRESHOLD_MINIMUM || p.req_cnt_thrshold > QZ_REQ_THRESHOLD_MAXIMUM) return QZ_PARAMS;
+    if (p.comp_lvl < 1 || p.comp_lvl > (lz4 ? QZ_LZS_COMP_LVL_MAXIMUM : QZ_DEFLATE_COMP_LVL_MAXIMUM_Gen3)) return QZ_PARAMS;
+    return QZ_OK;
+}
+
+static void from_common(Params &p, const QzSessionParamsCommon_T &c)
+{
+    p.direction = c.direction; p.comp_lvl = c.comp_lvl; p.comp_algorithm = c.comp_algorithm; p.max_forks = c.max_forks;
+    p.sw_backup = c.sw_backup; p.hw_buff_sz = c.hw_buff_sz; p.strm_buff_sz = c.strm_buff_sz;
+    p.input_sz_thrshold = c.input_sz_thrshold; p.req_cnt_thrshold = c.req_cnt_thrshold;
+    p.wait_cnt_thrshold = c.wait_cnt_thrshold; p.polling_mode = c.polling_mode; p.is_sensitive_mode = c.is_sensitive_mode;
+}
+static void to_common(const Params &p, QzSessionParamsCommon_T &c)
+{
+    c.direction = p.direction; c.comp_lvl = p.comp_lvl; c.comp_algorithm = p.comp_algorithm; c.max_forks = p.max_forks;
+    c.sw_backup = p.sw_backup; c.hw_buff_sz = p.hw_buff_sz; c.strm_buff_sz = p.strm_buff_sz;
+    c.input_sz_thrshold = p.input_sz_thrshold; c.req_cnt_thrshold = p.req_cnt_thrshold;
+    c.wait_cnt_thrshold = p.wait_cnt_thrshold; c.polling_mode = p.polling_mode; c.is_sensitive_mode = p.is_sensitive_mode;
+}
+static int pub_fmt(int f) { return f == F_4B ? QZ_DEFLATE_4B : f == F_GZIP ? QZ_DEFLATE_GZIP : f == F_RAW ? QZ_DEFLATE_RAW : QZ_DEFLATE_GZIP_EXT; }
+
+static int legacy_to(Params &p, const QzSessionParams_T *s)
+{
+    if (s->huffman_hdr > QZ_STATIC_HDR || s->direction > QZ_DIR_BOTH || s->comp_algorithm != QZ_DEFLATE) return QZ_PARAMS;
+    if (s->comp_lvl < QZ_DEFLATE_COMP_LVL_MINIMUM || s->comp_lvl > QZ_DEFLATE_COMP_LVL_MAXIMUM) return QZ_PARAMS;
+    if ((unsigned)s->data_fmt >= QZ_FMT_NUM) return QZ_PARAMS;
+    p = g_def;
+    p.huffman_hdr = s->huffman_hdr; p.direction = s->direction; p.fmt = (int)s->data_fmt; p.comp_lvl = s->comp_lvl;
+    p.comp_algorithm = s->comp_algorithm; p.max_forks = s->max_forks; p.sw_backup = s->sw_backup;
+    p.hw_buff_sz = s->hw_buff_sz; p.strm_buff_sz = s->strm_buff_sz; p.input_sz_thrshold = s->input_sz_thrshold;
+    p.req_cnt_thrshold = s->req_cnt_thrshold; p.wait_cnt_thrshold = s->wait_cnt_thrshold;
+    p.zlib_format = 0; p.stop_at_stream_end = 0;
+    return check_common(p, false);
+}
+static int deflate_to(Params &p, const QzSessionParamsDeflate_T *s)
+{
+    if (s->huffman_hdr > QZ_STATIC_HDR || (unsigned)s->data_fmt >= QZ_FMT_NUM || s->common_params.comp_algorithm != QZ_DEFLATE) return QZ_PARAMS;
+    p = g_def;
+    from_common(p, s->common_params);
+    p.huffman_hdr = s->huffman_hdr; p.fmt = (int)s->data_fmt; p.zlib_format = 0; p.stop_at_stream_end = 0;
+    return check_common(p, false);
+}
+static int lz4_to(Params &p, const QzSessionParamsLZ4_T *s)
+{
+    if (s->common_params.comp_algorithm != QZ_LZ4) return QZ_PARAMS;
+    p = g_def;
+    from_common(p, s->common_params);
+    p.fmt = F_LZ4;
+    return check_common(p, true);
+}
+
+extern "C" int qzGetDefaults(QzSessionParams_T *d)
+{
+    if (!d) return QZ_PARAMS;
+    pthread_mutex_lock(&g_lock);
+    Params p = g_def;
+    pthread_mutex_unlock(&g_lock);
+    d->huffman_hdr = p.huffman_hdr; d->direction = p.direction;
+    d->data_fmt = (QzDataFormat_T)pub_fmt(p.fmt); d->comp_lvl = p.comp_lvl; d->comp_algorithm = QZ_DEFLATE;
+    d->max_forks = p.max_forks; d->sw_backup = p.sw_backup; d->hw_buff_sz = p.hw_buff_sz; d->strm_buff_sz = p.strm_buff_sz;
+    d->input_sz_thrshold = p.input_sz_thrshold; d->req_cnt_thrshold = p.req_cnt_thrshold; d->wait_cnt_thrshold = p.wait_cnt_thrshold;
+    return QZ_OK;
+}
+extern "C" int qzGetDefaultsDeflate(QzSessionParamsDeflate_T *d)
+{
+    if (!d) return QZ_PARAMS;
+    pthread_mutex_lock(&g_lock); Params p = g_def; pthread_mutex_unlock(&g_lock);
+    to_common(p, d->common_params); d->common_params.comp_algorithm = QZ_DEFLATE;
+    d->huffman_hdr = p.huffman_hdr; d->data_fmt = (QzDataFormat_T)pub_fmt(p.fmt);
+    return QZ_OK;
+}
+extern "C" int qzGetDefaultsDeflateExt(QzSessionParamsDeflateExt_T *d)
+{
+    if (!d) return QZ_PARAMS;
+    qzGetDefaultsDeflate(&d->deflate_params);
+    pthread_mutex_lock(&g_lock); d->stop_decompression_stream_end = g_def.stop_at_stream_end; d->zlib_format = g_def.zlib_format; pthread_mutex_unlock(&g_lock);
+    return QZ_OK;
+}
+extern "C" int qzGetDefaultsLZ4(QzSessionParamsLZ4_T *d)
+{
+    if (!d) return QZ_PARAMS;
+    pthread_mutex_lock(&g_lock); Params p = g_def; pthread_mutex_unlock(&g_lock);
+    to_common(p, d->common_params); d->common_params.comp_algorithm = QZ_LZ4;
+    return QZ_OK;
+}
+extern "C" int qzGetDefaultsLZ4S(QzSessionParamsLZ4S_T *d)
+{
+    if (!d) return QZ_PARAMS;
+    pthread_mutex_lock(&g_lock); Params p = g_def; pthread_mutex_unlock(&g_lock);
+    to_common(p, d->common_params); d->common_params.comp_algorithm = QZ_LZ4s;
+    d->qzCallback = p.cb; d->qzCallback_external = p.cb_ext; d->lz4s_mini_match = p.lz4s_mini_match;
+    return QZ_OK;
+}
+extern "C" int qzSetDefaults(QzSessionParams_T *d)
+{
+    Params p;
+    if (!d || legacy_to(p, d) != QZ_OK) return QZ_PARAMS;
+    pthread_mutex_lock(&g_lock); g_def = p; pthread_mutex_unlock(&g_lock);
+    return QZ_OK;
+}
+extern "C" int qzSetDefaultsDeflate(QzSessionParamsDeflate_T *d)
+{
+    Params p;
+    if (!d || deflate_to(p, d) != QZ_OK) return QZ_PARAMS;
+    pthread_mutex_lock(&g_lock); g_def = p; pthread_mutex_unlock(&g_lock);
+    return QZ_OK;
+}
+extern "C" int qzSetDefaultsDeflateExt(QzSessionParamsDeflateExt_T *d)
+{
+    Params p;
+    if (!d || deflate_to(p, &d->deflate_params) != QZ_OK) return QZ_PARAMS;
+    p.stop_at_stream_end = d->stop_decompression_stream_end; p.zlib_format = d->zlib_format;
+    if (p.zlib_format) p.fmt = F_ZLIB;
+    pthread_mutex_lock(&g_lock); g_def = p; pthread_mutex_unlock(&g_lock);
+    return QZ_OK;
+}
+extern "C" int qzSetDefaultsLZ4(QzSessionParamsLZ4_T *d)
+{
+    Params p;
+    if (!d || lz4_to(p, d) != QZ_OK) return QZ_PARAMS;
+    pthread_mutex_lock(&g_lock); g_def = p; pthread_mutex_unlock(&g_lock);
+    return QZ_OK;
+}
+extern "C" int qzSetDefaultsLZ4S(QzSessionParamsLZ4S_T *d) { (void)d; return QZ_NOT_SUPPORTED; }
+
+/* ------------------------------------------------------------------ init / sessions */
+extern "C" int qzInit(QzSession_T *sess, unsigned char sw_backup)
+{
+    if (!sess || sw_backup > 1) return QZ_PARAMS;
+    pthread_mutex_lock(&g_lock);
+    if (g_inited) { pthread_mutex_unlock(&g_lock); return QZ_DUPLICATE; }
+    g_ndev = qzd_device_count();
+    if (g_ndev <= 0) {
+        pthread_mutex_unlock(&g_lock);
+        logmsg(LOG_ERROR, "no MI355X visible and this build has no software path\n");
+        sess->hw_session_stat = QZ_NOSW_NO_HW;
+        return QZ_NOSW_NO_HW;
+    }
+    const char *e = getenv("QATZIP_AMD_DEVICE");
+    g_next_dev = e ? atoi(e) % g_ndev : 0;
+    g_inited = 1;
+    pthread_mutex_unlock(&g_lock);
+    return QZ_OK;
+}
+
+static int make_session(QzSession_T *sess, const Params &p)
+{
+    if (sess->internal) return QZ_DUPLICATE;
+    Sess *s = new (std::nothrow) Sess();
+    if (!s) { sess->hw_session_stat = QZ_NOSW_LOW_MEM; return QZ_NOSW_LOW_MEM; }
+    s->p = p; s->ctx = NULL; s->d_in = s->d_out = NULL; s->in_cap = s->out_cap = 0;
+    s->open = false; s->run_sum = 0; s->st_in = s->st_out = 0; s->end_of_stream = 0;
+    sess->internal = s;
+    sess->hw_session_stat = g_inited ? QZ_OK : QZ_NONE;
+    sess->thd_sess_stat = QZ_OK;
+    sess->total_in = sess->total_out = 0;
+    return QZ_OK;
+}
+
+extern "C" int qzSetupSession(QzSession_T *sess, QzSessionParams_T *params)
+{
+    QzSessionParams_T tmp; Params p;
+    if (!sess) return QZ_PARAMS;
+    if (!params) { qzGetDefaults(&tmp); params = &tmp; }
+    if (legacy_to(p, params) != QZ_OK) return QZ_PARAMS;
+    return make_session(sess, p);
+}
+extern "C" int qzSetupSessionDeflate(QzSession_T *sess, QzSessionParamsDeflate_T *params)
+{
+    QzSessionParamsDeflate_T tmp; Params p;
+    if (!sess) return QZ_PARAMS;
+    if (!params) { qzGetDefaultsDeflate(&tmp); params = &tmp; }
+    if (deflate_to(p, params) != QZ_OK) return QZ_PARAMS;
+    return make_session(sess, p);
+}
+extern "C" int qzSetupSessionDeflateExt(QzSession_T *sess, QzSessionParamsDeflateExt_T *params)
+{
+    QzSessionParamsDeflateExt_T tmp; Params p;
+    if (!sess) return QZ_PARAMS;
+    if (!params) { qzGetDefaultsDeflateExt(&tmp); params = &tmp; }
+    if (deflate_to(p, &params->deflate_params) != QZ_OK) return QZ_PARAMS;
+    p.stop_at_stream_end = params->stop_decompression_stream_end; p.zlib_format = params->zlib_format;
+    if (p.zlib_format) p.fmt = F_ZLIB;
+    return make_session(sess, p);
+}
+extern "C" int qzSetupSessionLZ4(QzSession_T *sess, QzSessionParamsLZ4_T *params)
+{
+    QzSessionParamsLZ4_T tmp; Params p;
+    if (!sess) return QZ_PARAMS;
+    if (!params) { qzGetDefaultsLZ4(&tmp); params = &tmp; }
+    if (lz4_to(p, params) != QZ_OK) return QZ_PARAMS;
+    return make_session(sess, p);
+}
+extern "C" int qzSetupSessionLZ4S(QzSession_T *sess, QzSessionParamsLZ4S_T *params)
+{
+    (void)params;
+    if (!sess) return QZ_PARAMS;
+    return QZ_NOT_SUPPORTED;        /* LZ4s is a QAT-2.0 hardware format with no software path in the reference */
+}
+
+extern "C" int qzTeardownSession(QzSession_T *sess)
+{
+    if (!sess) return QZ_PARAMS;
+    Sess *s = (Sess *)sess->internal;
+    if (s) {
+        if (s->ctx) {
+            if (s->d_in) qzd_dev_free(s->ctx, s->d_in);
+            if (s->d_out) qzd_dev_free(s->ctx, s->d_out);
+            qzd_destroy(s->ctx);
+        }
+        delete s;
+        sess->internal = NULL;
+    }
+    return QZ_OK;
+}
+extern "C" int qzClose(QzSession_T *sess) { return sess ? QZ_OK : QZ_PARAMS; }
+
+extern "C" int qzGetStatus(QzSession_T *sess, QzStatus_T *st)
+{
+    if (!sess || !st) return QZ_PARAMS;
+    memset(st, 0, sizeof(*st));
+    int n = qzd_device_count();
+    st->qat_hw_count = (unsigned short)(n > 0 ? n : 0);
+    st->qat_service_init = g_inited ? 1 : 0; st->qat_mem_drvr = 1; st->qat_instance_attach = sess->internal ? 1 : 0;
+    st->hw_session_status = sess->hw_session_stat;
+    st->algo_hw[QZ_DEFLATE] = 1; st->algo_hw[QZ_LZ4] = 1;
+    return QZ_OK;
+}
+extern "C" int qzGetDeflateEndOfStream(QzSession_T *sess, unsigned char *eos)
+{
+    if (!sess || !eos || !sess->internal) return QZ_PARAMS;
+    *eos = ((Sess *)sess->internal)->end_of_stream;
+    return QZ_OK;
+}
+
+/* lazy init + setup, the scenarios of include/qatzip.h:122-148 */
+static int ensure_ready(QzSession_T *sess, Sess **out)
+{
+    int rc = qzInit(sess, 1);
+    if (rc < 0) return rc;
+    if (!sess->internal || sess->hw_session_stat == QZ_NONE) {
+        if (!sess->internal) {
+            pthread_mutex_lock(&g_lock); Params p = g_def; pthread_mutex_unlock(&g_lock);
+            rc = make_session(sess, p);
+            if (rc < 0) return rc;
+        }
+        sess->hw_session_stat = QZ_OK;
+    }
+    Sess *s = (Sess *)sess->internal;
+    if (!s->ctx) {
+        pthread_mutex_lock(&g_lock);
+        int dev = getenv("QATZIP_AMD_DEVICE") ? g_next_dev : (g_next_dev++ % g_ndev);
+        pthread_mutex_unlock(&g_lock);
+        if (qzd_create(dev, &s->ctx) != QZD_OK) { sess->hw_session_stat = QZ_NO_INST_ATTACH; return QZ_NOSW_NO_INST_ATTACH; }
+    }
+    *out = s;
+    return QZ_OK;
+}
+
+static int reserve(Sess *s, size_t in_n, size_t out_n)
+{
+    if (in_n > s->in_cap) {
+        if (s->d_in) qzd_dev_free(s->ctx, s->d_in);
+        s->in_cap = 0;
+        s->d_in = (uint8_t *)qzd_dev_alloc(s->ctx, in_n + 4096);
+        if (!s->d_in) return QZ_NOSW_LOW_MEM;
+        s->in_cap = in_n;
+    }
+    if (out_n > s->out_cap) {
+        if (s->d_out) qzd_dev_free(s->ctx, s->d_out);
+        s->out_cap = 0;
+        s->d_out = (uint8_t *)qzd_dev_alloc(s->ctx, out_n + 4096);
+        if (!s->d_out) return QZ_NOSW_LOW_MEM;
+        s->out_cap = out_n;
+    }
+    return QZ_OK;
+}
+
+static void wr32(unsigned char *p, uint32_t v) { p[0] = (unsigned char)v; p[1] = (unsigned char)(v >> 8); p[2] = (unsigned char)(v >> 16); p[3] = (unsigned char)(v >> 24); }
+static uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+static uint32_t rd16(const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+
+static unsigned hdr_len(int fmt) { return fmt == F_GZIP ? 10 : fmt == F_GZIP_EXT ? 24 : fmt == F_ZLIB ? 2 : fmt == F_4B ? 4 : 0; }
+static unsigned ftr_len(int fmt) { return (fmt == F_GZIP || fmt == F_GZIP_EXT) ? 8 : fmt == F_ZLIB ? 4 : 0; }
+
+extern "C" uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);   /* qzd_device.hip */
+
+/* ------------------------------------------------------------------ compress */
+static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
+                            unsigned char *dest, unsigned int *dest_len, unsigned int last, unsigned long *crc)
+{
+    const int fmt = s->p.fmt;
+    const uint32_t n = *src_len, cap = *dest_len, hw = s->p.hw_buff_sz;
+    if (fmt == F_ZLIB) return QZ_NOT_SUPPORTED;                     /* Adler-32 trailer: not on the GPU path yet */
+    if (s->p.comp_lvl != 1) { logmsg(LOG_ERROR, "comp_lvl %u: only level 1 runs on the GPU path\n", s->p.comp_lvl); return QZ_NOT_SUPPORTED; }
+    const bool opening = !s->open;
+    const unsigned hl = opening ? hdr_len(fmt) : 0;
+    *src_len = 0; *dest_len = 0;
+    if (cap < hl) return QZ_BUF_ERROR;
+    const uint32_t nchunks = n ? (n + hw - 1) / hw : 1;
+    const uint64_t worst = (uint64_t)n + (uint64_t)nchunks * (5ull * (hw / 32767 + 2) + 16) + 64;
+    int rc = reserve(s, n, worst);
+    if (rc) return rc;
+    if (n && qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
+    uint64_t produced = 0;
+    s->crcs.resize(nchunks); s->lens.resize(nchunks);
+    if (qzd_deflate_raw(s->ctx, s->d_in, n, hw, (int)s->p.comp_lvl, (int)last, s->d_out, s->out_cap, &produced, s->crcs.data()) != QZD_OK) {
+        logmsg(LOG_ERROR, "GPU deflate failed: %s\n", qzd_last_error(s->ctx));
+        return QZ_FAIL;
+    }
+    /* how many whole chunks fit into dest (header now, trailer only with the final chunk)? */
+    uint32_t take = nchunks; uint64_t bytes = produced;
+    const unsigned fl = last ? ftr_len(fmt) : 0;
+    if (hl + produced + fl > cap) {
+        if (qzd_chunk_lens(s->ctx, s->lens.data(), nchunks) != QZD_OK) return QZ_FAIL;
+        bytes = 0; take = 0;
+        while (take < nchunks && hl + bytes + s->lens[take] <= cap) bytes += s->lens[take++];
+        if (take == nchunks) take--, bytes -= s->lens[take];      /* the trailer is what does not fit */
+        if (take == 0) return QZ_BUF_ERROR;
+    }
+    const bool complete = take == nchunks;
+    const uint32_t used = complete ? n : take * hw;
+    if (opening) {                                                  /* header, src/qatzip_sw.c:61-75,158-171 and zlib's own gzip header */
+        if (fmt == F_GZIP) { static const unsigned char h[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 3}; memcpy(dest, h, 10); }
+        else if (fmt == F_GZIP_EXT) { static const unsigned char h[24] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0, 'Q', 'Z', 8, 0}; memcpy(dest, h, 24); }
+        else if (fmt == F_4B) wr32(dest, 0);
+        s->open = true; s->run_sum = 0; s->st_in = 0; s->st_out = hl;
+    }
+    if (bytes && qzd_d2h(s->ctx, dest + hl, s->d_out, bytes) != QZD_OK) return QZ_FAIL;
+    /* running CRC-32 of the stream (zlib's strm->adler for gzip) + the crc out-parameter of
+     * src/qatzip_sw.c:217-230, including its cumulative-fold behaviour on multi-chunk calls */
+    uint32_t done_in = 0;
+    for (uint32_t k = 0; k < take; k++) {
+        uint32_t cl = std::min<uint32_t>(hw, n - k * hw);
+        if (fmt == F_GZIP || fmt == F_GZIP_EXT) s->run_sum = qzd_crc32_combine(s->run_sum, s->crcs[k], cl);
+        done_in += cl;
+        if (crc) {
+            if (fmt == F_RAW) *crc = qzd_crc32_combine((uint32_t)*crc, s->crcs[k], cl);
+            else {
+                uint32_t adler = (fmt == F_4B) ? 1u : s->run_sum;
+                if (*crc == 0) *crc = adler; else *crc = qzd_crc32_combine((uint32_t)*crc, adler, done_in);
+            }
+        }
+    }
+    s->st_in += used; s->st_out += bytes;
+    uint32_t out_total = hl + (uint32_t)bytes;
+    if (complete && last) {
+        if (fmt == F_GZIP || fmt == F_GZIP_EXT) { wr32(dest + out_total, s->run_sum); wr32(dest + out_total + 4, (uint32_t)s->st_in); out_total += 8; s->st_out += 8; }
+        if (opening && fmt == F_GZIP_EXT) { wr32(dest + 16, (uint32_t)s->st_in); wr32(dest + 20, (uint32_t)(s->st_out - 24 - 8)); }
+        if (opening && fmt == F_4B) wr32(dest, (uint32_t)(s->st_out - 4));
+        s->open = false;
+    }
+    *src_len = used; *dest_len = out_total;
+    sess->total_in += used; sess->total_out += out_total;
+    return complete ? QZ_OK : QZ_BUF_ERROR;
+}
+
+extern "C" int qzCompressCrcExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                                unsigned int *dest_len, unsigned int last, unsigned long *crc, uint64_t *ext_rc)
+{
+    int rc; Sess *s = NULL;
+    if (!sess || !src || !src_len || !dest || !dest_len || (last != 0 && last != 1)) { rc = QZ_PARAMS; goto fail; }
+    if (ext_rc) *ext_rc = 0;
+    rc = ensure_ready(sess, &s);
+    if (rc < 0) goto fail;
+    if (s->p.fmt == F_LZ4) rc = QZ_NOT_SUPPORTED;                   /* LZ4 kernels: see DESIGN.md (next) */
+    else if (s->p.fmt == F_LZ4S) rc = QZ_UNSUPPORTED_FMT;
+    else rc = compress_deflate(sess, s, src, src_len, dest, dest_len, last, crc);
+    sess->thd_sess_stat = rc;
+    if (rc == QZ_OK || rc == QZ_BUF_ERROR) return rc;
+fail:
+    if (src_len) *src_len = 0;
+    if (dest_len) *dest_len = 0;
+    return rc;
+}
+extern "C" int qzCompressExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                             unsigned int *dest_len, unsigned int last, uint64_t *ext_rc)
+{
+    if (!sess || (last != 0 && last != 1)) { if (src_len) *src_len = 0; if (dest_len) *dest_len = 0; return QZ_PARAMS; }
+    return qzCompressCrcExt(sess, src, src_len, dest, dest_len, last, NULL, ext_rc);
+}
+extern "C" int qzCompress(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                          unsigned int *dest_len, unsigned int last)
+{ return qzCompressExt(sess, src, src_len, dest, dest_len, last, NULL); }
+extern "C" int qzCompressCrc(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                             unsigned int *dest_len, unsigned int last, unsigned long *crc)
+{ return qzCompressCrcExt(sess, src, src_len, dest, dest_len, last, crc, NULL); }
+
+/* ------------------------------------------------------------------ decompress */
+/* parse one member header at p[0..n): returns payload offset or a negative QZ_* code;
+ * for gzip-ext also the sizes its extra field carries (0 when absent) */
+static int parse_header(int fmt, const unsigned char *p, uint32_t n, uint32_t *ext_src, uint32_t *ext_dst)
+{
+    *ext_src = *ext_dst = 0;
+    if (fmt == F_RAW) return 0;
+    if (fmt == F_4B) return n >= 4 ? 4 : QZ_DATA_ERROR;
+    if (fmt == F_ZLIB) {
+        if (n < 2 || (p[0] & 0x0f) != 8 || ((p[0] << 8 | p[1]) % 31) || (p[1] & 0x20)) return QZ_DATA_ERROR;
+        return 2;
+    }
+    if (n < 10 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0)) return QZ_DATA_ERROR;
+    uint32_t pos = 10; unsigned flg = p[3];
+    if (flg & 4) {
+        if (pos + 2 > n) return QZ_DATA_ERROR;
+        uint32_t xl = rd16(p + pos);
+        if (pos + 2 + xl > n) return QZ_DATA_ERROR;
+        if (xl == 12 && p[pos + 2] == 'Q' && p[pos + 3] == 'Z' && rd16(p + pos + 4) == 8) { *ext_src = rd32(p + pos + 6); *ext_dst = rd32(p + pos + 10); }
+        pos += 2 + xl;
+    }
+    if (flg & 8) { while (pos < n && p[pos]) pos++; pos++; }
+    if (flg & 16) { while (pos < n && p[pos]) pos++; pos++; }
+    if (flg & 2) pos += 2;
+    return pos <= n ? (int)pos : QZ_DATA_ERROR;
+}
+
+static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
+                              unsigned char *dest, unsigned int *dest_len, unsigned long *crc)
+{
+    const int fmt = s->p.fmt;
+    const uint32_t n = *src_len, cap = *dest_len;
+    int rc = reserve(s, n, cap);
+    if (rc) return rc;
+    if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
+    uint32_t ti = 0, to = 0; int ret = QZ_OK;
+    s->end_of_stream = 0;
+    while (ti < n && to < cap) {                                    /* member loop, src/qatzip_sw.c:415-435 */
+        uint32_t es, ed;
+        int hl = parse_header(fmt, src + ti, n - ti, &es, &ed);
+        if (hl < 0) { ret = hl; break; }
+        uint64_t iu = 0, ol = 0; uint32_t c32 = 0;
+        int r = qzd_inflate_stream(s->ctx, s->d_in + ti + hl, n - ti - hl, s->d_out + to, cap - to, s->p.hw_buff_sz, &iu, &ol,
+                                   (fmt == F_GZIP || fmt == F_GZIP_EXT || crc) ? &c32 : NULL);
+        if (r == QZD_ERR_DSTCAP) { ret = QZ_BUF_ERROR; break; }
+        if (r != QZD_OK) { ret = QZ_DATA_ERROR; break; }
+        uint32_t pos = ti + (uint32_t)hl + (uint32_t)iu;
+        if (fmt == F_GZIP || fmt == F_GZIP_EXT) {
+            if (pos + 8 > n || rd32(src + pos) != c32 || rd32(src + pos + 4) != (uint32_t)ol) { ret = QZ_DATA_ERROR; break; }
+            pos += 8;
+        } else if (fmt == F_ZLIB) { ret = QZ_NOT_SUPPORTED; break; }
+        if (crc) *crc = (to == 0 && *crc == 0) ? c32 : qzd_crc32_combine((uint32_t)*crc, c32, ol);
+        ti = pos; to += (uint32_t)ol;
+        s->end_of_stream = 1;
+        if (s->p.stop_at_stream_end) break;
+    }
+    if (ret != QZ_OK && !(ret == QZ_BUF_ERROR && to > 0)) { *src_len = 0; *dest_len = 0; return ret; }
+    if (to && qzd_d2h(s->ctx, dest, s->d_out, to) != QZD_OK) return QZ_FAIL;
+    *src_len = ti; *dest_len = to;
+    sess->total_in += ti; sess->total_out += to;
+    return ret;
+}
+
+extern "C" int qzDecompressCrcExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                                  unsigned int *dest_len, unsigned long *crc, uint64_t *ext_rc)
+{
+    int rc; Sess *s = NULL;
+    if (!sess || !src || !src_len || !dest || !dest_len) { rc = QZ_PARAMS; goto fail; }
+    if (ext_rc) *ext_rc = 0;
+    if (*src_len == 0) { *dest_len = 0; return QZ_OK; }
+    rc = ensure_ready(sess, &s);
+    if (rc < 0) goto fail;
+    if (s->p.fmt == F_LZ4) rc = QZ_NOT_SUPPORTED;
+    else if (s->p.fmt == F_LZ4S) rc = QZ_UNSUPPORTED_FMT;
+    else rc = decompress_deflate(sess, s, src, src_len, dest, dest_len, crc);
+    sess->thd_sess_stat = rc;
+    if (rc == QZ_OK || rc == QZ_BUF_ERROR) return rc;
+fail:
+    if (src_len) *src_len = 0;
+    if (dest_len) *dest_len = 0;
+    return rc;
+}
+extern "C" int qzDecompress(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest, unsigned int *dest_len)
+{ return qzDecompressCrcExt(sess, src, src_len, dest, dest_len, NULL, NULL); }
+extern "C" int qzDecompressExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest, unsigned int *dest_len, uint64_t *ext_rc)
+{ return qzDecompressCrcExt(sess, src, src_len, dest, dest_len, NULL, ext_rc); }
+extern "C" int qzDecompressCrc(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest, unsigned int *dest_len, unsigned long *crc)
+{ return qzDecompressCrcExt(sess, src, src_len, dest, dest_len, crc, NULL); }
+
+/* src/qatzip.c:3022-3068: (9n/8 rounded up) + skid pad + one header/footer (the reference's `?:` precedence
+ * makes its chunk count 0 or 1); LZ4: frame bound */
+extern "C" unsigned int qzMaxCompressedLength(unsigned int src_sz, QzSession_T *sess)
+{
+    if (src_sz == 0) return QZ_COMPRESSED_SZ_OF_EMPTY_FILE;
+    uint64_t out = ((uint64_t)9 * src_sz + 7) / 8 + QZ_SKID_PAD_SZ + (24 + 8);
+    if (sess && sess->internal && ((Sess *)sess->internal)->p.fmt == F_LZ4)
+        out = (uint64_t)src_sz + 27 + 4 * ((uint64_t)src_sz / 65536 + 1) + src_sz / 255;
+    return (out >> 32) ? 0 : (unsigned int)out;
+}
+
+/* ------------------------------------------------------------------ pinned memory */
+extern "C" void *qzMalloc(size_t sz, int numa, int force_pinned)
+{
+    (void)numa;
+    void *p = NULL;
+    if (qzd_device_count() > 0) p = qzd_host_alloc_pinned(sz);
+    if (p) { pthread_mutex_lock(&g_mem_lock); g_pinned.insert(p); pthread_mutex_unlock(&g_mem_lock); return p; }
+    return force_pinned == PINNED_MEM ? NULL : malloc(sz);
+}
+extern "C" void qzFree(void *m)
+{
+    if (!m) return;
+    pthread_mutex_lock(&g_mem_lock);
+    bool pinned = g_pinned.erase(m) > 0;
+    pthread_mutex_unlock(&g_mem_lock);
+    if (pinned) qzd_host_free_pinned(m); else free(m);
+}
+extern "C" int qzMemFindAddr(unsigned char *a)
+{
+    pthread_mutex_lock(&g_mem_lock);
+    int r = g_pinned.count((void *)a) ? 1 : 0;
+    pthread_mutex_unlock(&g_mem_lock);
+    return r;
+}
+
+/* ------------------------------------------------------------------ streaming (src/qatzip_stream.c:403-781)
+ * slab accumulate -> qzCompressCrc / qzDecompress on strm_buff_sz slabs -> drain */
+struct StreamBuf { unsigned char *in, *out; unsigned cap, out_cap, out_off, in_off; bool flush_more; };
+
+static int stream_init(Sess *s, QzStream_T *strm, bool comp)
+{
+    StreamBuf *b = (StreamBuf *)calloc(1, sizeof(StreamBuf));
+    if (!b) return QZ_FAIL;
+    b->cap = s->p.strm_buff_sz;
+    b->out_cap = comp ? qzMaxCompressedLength(b->cap, NULL) + 64 : b->cap;
+    b->in = (unsigned char *)qzMalloc(b->cap, 0, COMMON_MEM);
+    b->out = (unsigned char *)qzMalloc(b->out_cap, 0, COMMON_MEM);
+    if (!b->in || !b->out) { qzFree(b->in); qzFree(b->out); free(b); return QZ_FAIL; }
+    strm->opaque = b; strm->pending_in = 0; strm->pending_out = 0; strm->crc_32 = 0;
+    return QZ_OK;
+}
+static unsigned drain(QzStream_T *strm, StreamBuf *b, unsigned char *out, unsigned room)
+{
+    unsigned k = std::min(room, strm->pending_out);
+    memcpy(out, b->out + b->out_off, k);
+    b->out_off += k; strm->pending_out -= k;
+    if (strm->pending_out == 0) b->out_off = 0;
+    return k;
+}
+
+extern "C" int qzCompressStream(QzSession_T *sess, QzStream_T *strm, unsigned int last)
+{
+    if (!sess || !strm || (last != 0 && last != 1) || !strm->out || (!strm->in && strm->in_sz > 0)) {
+        if (strm) { strm->in_sz = 0; strm->out_sz = 0; }
+        return QZ_PARAMS;
+    }
+    Sess *s = NULL;
+    if (ensure_ready(sess, &s) < 0) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
+    if (s->p.fmt != F_RAW && s->p.fmt != F_GZIP_EXT) { strm->in_sz = 0; strm->out_sz = 0; return QZ_PARAMS; }
+    if (!strm->opaque && stream_init(s, strm, true) != QZ_OK) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
+    StreamBuf *b = (StreamBuf *)strm->opaque;
+    unsigned consumed = 0, produced = 0; int rc = QZ_OK;
+    const unsigned in_avail = strm->in_sz, out_room = strm->out_sz;
+    for (;;) {
+        if (strm->pending_out) {
+            produced += drain(strm, b, strm->out + produced, out_room - produced);
+            if (strm->pending_out) break;                           /* caller must bring more room */
+        }
+        unsigned k = std::min(in_avail - consumed, b->cap - strm->pending_in);
+        if (k) { memcpy(b->in + strm->pending_in, strm->in + consumed, k); strm->pending_in += k; consumed += k; }
+        const bool input_done = consumed == in_avail;
+        if (strm->pending_in < b->cap && !(last && input_done)) break;   /* wait for a full slab */
+        unsigned il = strm->pending_in, ol = b->out_cap;
+        unsigned long c = strm->crc_32;
+        const unsigned fin = (last && input_done) ? 1 : 0;
+        rc = qzCompressCrc(sess, b->in, &il, b->out, &ol, fin, &c);
+        if (rc != QZ_OK) { rc = QZ_FAIL; break; }
+        strm->crc_32 = (unsigned int)c;
+        strm->pending_in -= il; strm->pending_out = ol; b->out_off = 0;
+        if (fin) { produced += drain(strm, b, strm->out + produced, out_room - produced); break; }
+    }
+    strm->in_sz = consumed; strm->out_sz = produced;
+    return rc;
+}
+
+extern "C" int qzDecompressStream(QzSession_T *sess, QzStream_T *strm, unsigned int last)
+{
+    if (!sess || !strm || (last != 0 && last != 1) || !strm->out || (!strm->in && strm->in_sz > 0)) {
+        if (strm) { strm->in_sz = 0; strm->out_sz = 0; }
+        return QZ_PARAMS;
+    }
+    Sess *s = NULL;
+    if (ensure_ready(sess, &s) < 0) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
+    if (!strm->opaque && stream_init(s, strm, false) != QZ_OK) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
+    StreamBuf *b = (StreamBuf *)strm->opaque;
+    /* whole members are decoded straight from the caller's buffers: a member never has to fit the slab */
+    unsigned il = strm->in_sz, ol = strm->out_sz;
+    unsigned long c = 0;
+    (void)b;
+    int rc = qzDecompressCrc(sess, strm->in, &il, strm->out, &ol, &c);
+    if (rc == QZ_BUF_ERROR && il > 0) rc = QZ_OK;
+    if (rc != QZ_OK) { strm->in_sz = 0; strm->out_sz = 0; return rc == QZ_DATA_ERROR ? QZ_DATA_ERROR : QZ_FAIL; }
+    strm->crc_32 = (unsigned int)c;
+    strm->in_sz = il; strm->out_sz = ol;
+    return QZ_OK;
+}
+
+extern "C" int qzEndStream(QzSession_T *sess, QzStream_T *strm)
+{
+    if (!sess || !strm) return QZ_PARAMS;
+    StreamBuf *b = (StreamBuf *)strm->opaque;
+    if (b) { qzFree(b->in); qzFree(b->out); free(b); strm->opaque = NULL; }
+    strm->pending_in = 0; strm->pending_out = 0; strm->in_sz = 0; strm->out_sz = 0;
+    return QZ_OK;
+}
+
+/* ------------------------------------------------------------------ declared-only surface */
+#define NS(...) { return QZ_NOT_SUPPORTED; }
+extern "C" int qzCompress2(QzSession_T *, const unsigned char *, unsigned char *, qzAsyncCallbackFn, QzResult_T *) NS()
+extern "C" int qzDecompress2(QzSession_T *, const unsigned char *, unsigned char *, qzAsyncCallbackFn, QzResult_T *) NS()
+extern "C" int qzCompressCrc64(QzSession_T *, const unsigned char *, unsigned int *, unsigned char *, unsigned int *, unsigned int, uint64_t *) NS()
+extern "C" int qzCompressCrc64Ext(QzSession_T *, const unsigned char *, unsigned int *, unsigned char *, unsigned int *, unsigned int, uint64_t *, uint64_t *) NS()
+extern "C" int qzDecompressCrc64(QzSession_T *, const unsigned char *, unsigned int *, unsigned char *, unsigned int *, uint64_t *) NS()
+extern "C" int qzDecompressCrc64Ext(QzSession_T *, const unsigned char *, unsigned int *, unsigned char *, unsigned int *, uint64_t *, uint64_t *) NS()
+extern "C" int qzCompressWithMetadataExt(QzSession_T *, const unsigned char *, unsigned int *, unsigned char *, unsigned int *, unsigned int, uint64_t *, QzMetadataBlob_T, uint32_t, uint32_t) NS()
+extern "C" int qzDecompressWithMetadataExt(QzSession_T *, const unsigned char *, unsigned int *, unsigned char *, unsigned int *, uint64_t *, QzMetadataBlob_T, uint32_t) NS()
+extern "C" int qzAllocateMetadata(QzMetadataBlob_T *, size_t, uint32_t) NS()
+extern "C" int qzFreeMetadata(QzMetadataBlob_T) NS()
+extern "C" int qzMetadataBlockRead(uint32_t, QzMetadataBlob_T, uint32_t *, uint32_t *, uint32_t *, uint32_t *) NS()
+extern "C" int qzMetadataBlockWrite(uint32_t, QzMetadataBlob_T, uint32_t *, uint32_t *, uint32_t *, uint32_t *) NS()
+extern "C" int qzMetadataBlockGetCrc64(uint32_t, QzMetadataBlob_T, uint64_t *, uint64_t *) NS()
+extern "C" int qzMetadataBlockGetCrc32(uint32_t, QzMetadataBlob_T, uint32_t *, uint32_t *) NS()
+extern "C" int qzGetSessionCrc64Config(QzSession_T *, QzCrc64Config_T *) NS()
+extern "C" int qzGetSessionCrc32Config(QzSession_T *, QzCrc32Config_T *) NS()
+extern "C" int qzSetSessionCrc64Config(QzSession_T *, QzCrc64Config_T *) NS()
+extern "C" int qzSetSessionCrc32Config(QzSession_T *, QzCrc32Config_T *) NS()
+extern "C" int qzGetSoftwareComponentCount(unsigned int *n) { if (!n) return QZ_PARAMS; *n = 1; return QZ_OK; }
+extern "C" int qzGetSoftwareComponentVersionList(QzSoftwareVersionInfo_T *info, unsigned int *n)
+{
+    if (!info || !n || *n < 1) return QZ_PARAMS;
+    memset(info, 0, sizeof(*info));
+    info->component_type = QZ_COMPONENT_QATZIP_API;
+    snprintf((char *)info->component_name, QZ_MAX_STRING_LENGTH, "qatzip-amd (MI355X)");
+    info->major_version = QATZIP_API_VERSION_NUM_MAJOR; info->minor_version = QATZIP_API_VERSION_NUM_MINOR;
+    *n = 1;
+    return QZ_OK;
+}

@@ -294,6 +294,16 @@ extern "C" int qzd_deflate_raw(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uin
     return qzd_result(c, h_out_len, h_chunk_crc, c->last_nchunks);
 }
 
+/* compressed size of every chunk of the last deflate call (for partial-progress reporting) */
+extern "C" int qzd_chunk_lens(qzd_ctx *c, uint32_t *h_len, uint32_t nchunks)
+{
+    if (!c || !h_len) return QZD_ERR_PARAM;
+    hipSetDevice(c->device);
+    if (nchunks > c->last_nchunks) nchunks = c->last_nchunks;
+    HIPCHK(c, hipMemcpy(h_len, c->d_len, (size_t)nchunks * 4, hipMemcpyDeviceToHost));
+    return QZD_OK;
+}
+
 extern "C" int qzd_last_timing(qzd_ctx *c, float ms[4])
 {
     if (!c || !ms) return QZD_ERR_PARAM;

@@ -40,6 +40,6 @@ struct qzd_ctx {
 int qzd_aux_reserve(qzd_ctx *c, size_t n);
 
 /* host-side CRC-32 helpers (zlib crc32_combine semantics) */
-uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+extern "C" uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 
 #endif

@@ -1,0 +1,157 @@
+"""GPU parity through the qatzip.h C ABI: every deflate wire format bit-identical to the oracle's
+restatement of the software path, stream continuation (last=0/1), error behaviour, the streaming
+adapter and a plain-C caller (drop-in proof)."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import pytest
+
+import datagen
+import oracle_lib as O
+from qatzip_amd import api as A
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FMT = {"4B": A.QZ_DEFLATE_4B, "GZIP": A.QZ_DEFLATE_GZIP, "GZIP_EXT": A.QZ_DEFLATE_GZIP_EXT, "RAW": A.QZ_DEFLATE_RAW}
+
+
+@pytest.mark.parametrize("fmt", ["GZIP_EXT", "GZIP", "RAW", "4B"])
+def test_compress_matches_sw_path_bit_for_bit(fmt):
+    for hw in (65536, 16384, 131072):
+        s = A.Session(FMT[fmt], hw)
+        assert s.rc_setup == A.QZ_OK
+        for kind, n in (("silesia", 200777), ("text", 65536), ("rand", 70000), ("runs", 1023), ("allA", 5), ("lzmix", 40000), ("text", 0)):
+            src = datagen.gen_bytes(kind, n, 17)
+            rc, used, out, crc = s.compress(src, 1, crc0=0)
+            erc, eused, exp, ecrc = O.sw_compress(fmt, src, hw, 1, cap=n * 9 // 8 + 65536)
+            assert rc == A.QZ_OK and used == n, (fmt, hw, kind, n, rc)
+            assert out == exp, (fmt, hw, kind, n, len(out), len(exp))
+            assert crc == ecrc, (fmt, hw, kind, n)
+            if fmt in ("GZIP", "GZIP_EXT") and n:
+                assert zlib.decompress(out, 31) == src
+            rc, cused, back = s.decompress(out, n + 16)
+            if n:
+                assert rc == A.QZ_OK and back == src and cused == len(out), (fmt, hw, kind, n, rc)
+        s.close()
+
+
+def test_crc_known_answer_like_reference_test():
+    # test/main.c:4283-4337: qzCompressCrc's crc == zlib crc32(src) for 64 KB and 1023 B
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    for n in (65536, 1023):
+        src = datagen.gen_bytes("runs", n, 3)
+        rc, _, _, crc = s.compress(src, 1, crc0=0)
+        assert rc == 0 and crc == (zlib.crc32(src) & 0xffffffff)
+    s.close()
+
+
+def test_stream_continues_across_calls_like_sw_path():
+    # last=0 then last=1: one member, sizes in the gzip-ext header stay 0
+    src = datagen.gen_bytes("text", 150000, 4)
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    rc1, u1, o1, _ = s.compress(src[:100000], 0)
+    rc2, u2, o2, _ = s.compress(src[100000:], 1)
+    assert rc1 == 0 and rc2 == 0 and u1 == 100000 and u2 == 50000
+    out = o1 + o2
+    assert o1[-4:] == b"\x00\x00\xff\xff" and out[16:24] == b"\0" * 8
+    assert zlib.decompress(out, 31) == src
+    # the first call equals the oracle's view of an open-ended stream
+    assert o1 == O.sw_compress("GZIP_EXT", src[:100000], 65536, 1, last=0)[2]
+    s.close()
+
+
+def test_multi_member_decompress_and_buf_error():
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    parts = [datagen.gen_bytes("silesia", n, 30 + i) for i, n in enumerate((65536, 1000, 140000))]
+    comp = b"".join(s.compress(p, 1)[2] for p in parts)
+    rc, used, back = s.decompress(comp, sum(map(len, parts)) + 10)
+    assert rc == A.QZ_OK and used == len(comp) and back == b"".join(parts)
+    # destination that only holds the first member: progress is reported, caller loops (utils/qzip.c:217-227)
+    rc, used, back = s.decompress(comp, 65536 + 500)
+    assert rc in (A.QZ_OK, A.QZ_BUF_ERROR) and back == parts[0] and 0 < used < len(comp)
+    # compress into a tiny destination: QZ_BUF_ERROR, nothing consumed (HW-path contract, test/main.c:4264-4270)
+    rc, used, out, _ = s.compress(parts[2], 1, cap=1024)
+    assert rc == A.QZ_BUF_ERROR and used == 0 and out == b""
+    # partial progress: room for some chunks only
+    s2 = A.Session(A.QZ_DEFLATE_RAW, 65536)
+    rnd = datagen.gen_bytes("rand", 200000, 2)
+    rc, used, out, _ = s2.compress(rnd, 1, cap=140000)
+    assert rc == A.QZ_BUF_ERROR and used == 131072 and zlib.decompressobj(-15).decompress(out) == rnd[:131072]
+    s.close(); s2.close()
+
+
+def test_corrupt_input_is_a_data_error():
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    src = datagen.gen_bytes("text", 90000, 6)
+    comp = s.compress(src, 1)[2]
+    bad = bytearray(comp); bad[0] ^= 0xff
+    rc, used, back = s.decompress(bytes(bad), len(src))
+    assert rc == A.QZ_DATA_ERROR and used == 0 and back == b""
+    bad = bytearray(comp); bad[len(comp) // 2] ^= 0x10
+    rc, used, back = s.decompress(bytes(bad), len(src))
+    assert rc == A.QZ_DATA_ERROR and used == 0 and back == b""
+    s.close()
+
+
+def test_levels_other_than_one_fail_loudly():
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536, comp_lvl=6)
+    rc, used, out, _ = s.compress(b"x" * 1000, 1)
+    assert rc == A.QZ_NOT_SUPPORTED and used == 0 and out == b""
+    s.close()
+
+
+def test_stream_api_one_member_many_slices():
+    # qzCompressStream fed in hw_buff_sz/4 slices (test/main.c:2548): one gzip-ext member, correct trailer
+    L = A.lib()
+    src = datagen.gen_bytes("silesia", 250000, 8)
+    for sb in (65536, 262144):
+        sess = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536, strm_buff_sz=sb)
+        strm = A.QzStream()
+        out = b""
+        obuf = C.create_string_buffer(1 << 20)
+        pos = 0
+        while True:
+            k = min(16384, len(src) - pos)
+            piece = src[pos:pos + k]
+            ibuf = C.create_string_buffer(piece, max(k, 1))
+            strm.in_ = C.cast(ibuf, C.c_void_p); strm.in_sz = k
+            strm.out = C.cast(obuf, C.c_void_p); strm.out_sz = len(obuf)
+            last = 1 if pos + k == len(src) else 0
+            rc = L.qzCompressStream(C.byref(sess.s), C.byref(strm), last)
+            assert rc == A.QZ_OK
+            pos += strm.in_sz
+            out += obuf.raw[:strm.out_sz]
+            if last and strm.in_sz == k and strm.pending_out == 0 and strm.pending_in == 0:
+                break
+        assert zlib.decompress(out, 31) == src
+        assert out[:4] == b"\x1f\x8b\x08\x04"
+        if sb < len(src):       # stream opened by a non-final slab: size fields are never patched (src/qatzip_sw.c:166,238)
+            assert out[16:24] == b"\0" * 8
+        else:                   # the only slab is also the last: same bytes as a single qzCompress(last=1)
+            assert out == O.sw_compress("GZIP_EXT", src, 65536, 1)[2]
+        L.qzEndStream(C.byref(sess.s), C.byref(strm))
+        sess.close()
+
+
+def test_pinned_memory():
+    L = A.lib()
+    for _ in range(100):                                  # test/main.c:2401-2441 allocates/frees in a loop
+        p = L.qzMalloc(100000, -1, A.PINNED_MEM)
+        assert p and L.qzMemFindAddr(p) == 1
+        L.qzFree(p)
+        assert L.qzMemFindAddr(p) == 0
+
+
+def test_plain_c_caller_links_and_round_trips(tmp_path):
+    exe = str(tmp_path / "bt_sweep")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "bt_sweep.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "qatzip_amd"), "-lqatzip_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "qatzip_amd")])
+    r = subprocess.run([exe, "sweep", "1", "200000", "9973"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe, "perf", "64", "65536", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Gbps" in r.stdout, r.stdout + r.stderr
+    print(r.stdout)
