@@ -102,6 +102,22 @@ int qzd_inflate_stream(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint8_t *
 int qzd_crc32(qzd_ctx *ctx, const uint8_t *d_data, uint64_t n, uint32_t *h_crc);
 int qzd_crc32_ranges(qzd_ctx *ctx, const uint8_t *d_data, const void *h_ranges, uint32_t nranges, uint32_t *h_crc);
 
+/* ------------------------------------------------------------------ LZ4 frames
+ * qzd_lz4seg { u64 in_off; u64 out_off; u32 in_len; u32 out_cap; }
+ * qzd_lz4res { i32 status; u32 in_used; u32 out_len; u32 pad; }   status 0 ok, -1 data, -2 capacity, -3 truncated */
+typedef struct { uint64_t in_off, out_off; uint32_t in_len, out_cap; } qzd_lz4seg;
+typedef struct { int32_t status; uint32_t in_used, out_len, pad; } qzd_lz4res;
+
+/* every frame_sz (<= 64 KB) bytes of d_src -> one LZ4 frame exactly as LZ4F_compressFrame emits it for the
+ * preferences of src/qatzip_sw.c:451-456 (content size + content checksum, one independent block, stored
+ * when incompressible); frames are written back to back.  h_frame_len (optional) <- size of every frame. */
+int qzd_lz4_compress_frames(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t frame_sz, uint8_t *d_dst,
+                            uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len);
+/* decode nsegs frames (any block mode, content checksum verified on the GPU); replaces LZ4F_decompress,
+ * src/qatzip_sw.c:496 */
+int qzd_lz4_decompress_frames(qzd_ctx *ctx, const uint8_t *d_comp, uint8_t *d_out, const void *h_segs,
+                              uint32_t nsegs, void *h_res);
+
 /* GPU time (ms) spent in [0] inflate kernels, [1] crc kernels by the last qzd_inflate_stream call */
 int qzd_last_inflate_timing(qzd_ctx *ctx, float ms[2]);
 

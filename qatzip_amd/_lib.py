@@ -48,6 +48,9 @@ def load(build_if_missing=True):
     L.qzd_crc32.argtypes = [vp, u8p, C.c_uint64, C.POINTER(C.c_uint32)]
     L.qzd_crc32_ranges.argtypes = [vp, u8p, vp, C.c_uint32, vp]
     L.qzd_last_inflate_timing.argtypes = [vp, C.POINTER(C.c_float * 2)]
+    L.qzd_lz4_compress_frames.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
+    L.qzd_lz4_decompress_frames.argtypes = [vp, u8p, u8p, vp, C.c_uint32, vp]
+    L.qzd_chunk_lens.argtypes = [vp, vp, C.c_uint32]
     _lib = L
     return L
 
@@ -55,6 +58,8 @@ def load(build_if_missing=True):
 SEG_DT = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"),
                    ("flags", "<u4"), ("pad", "<u4")])
 RES_DT = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
+LZ4SEG_DT = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4")])
+LZ4RES_DT = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("pad", "<u4")])
 
 
 def exported_symbols():
@@ -62,7 +67,8 @@ def exported_symbols():
     return ["qzd_create", "qzd_destroy", "qzd_last_error", "qzd_device_count", "qzd_dev_alloc", "qzd_dev_free",
             "qzd_h2d", "qzd_d2h", "qzd_host_alloc_pinned", "qzd_host_free_pinned", "qzd_deflate_raw",
             "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing", "qzd_inflate_segments",
-            "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing"]
+            "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing",
+            "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens"]
 
 
 class DevBuf:
@@ -165,6 +171,23 @@ class Context:
         crc = C.c_uint32(0)
         self._chk(self.L.qzd_crc32(self.h, d_data.ptr, n, C.byref(crc)))
         return crc.value
+
+    # -- LZ4
+    def lz4_compress_frames(self, d_src, n, d_dst, frame_sz=65536):
+        """-> (out_len, per-frame lengths)"""
+        nfr = max(1, (n + frame_sz - 1) // frame_sz)
+        ol = C.c_uint64(0)
+        lens = np.zeros(nfr, np.uint32)
+        self._chk(self.L.qzd_lz4_compress_frames(self.h, d_src.ptr, n, frame_sz, d_dst.ptr, d_dst.nbytes, C.byref(ol),
+                                                 lens.ctypes.data))
+        return ol.value, lens
+
+    def lz4_decompress_frames(self, d_comp, d_out, segs):
+        """segs: list of (in_off, out_off, in_len, out_cap) -> structured results (status, in_used, out_len)"""
+        sa = np.array([tuple(s) for s in segs], dtype=LZ4SEG_DT)
+        res = np.zeros(len(segs), LZ4RES_DT)
+        self._chk(self.L.qzd_lz4_decompress_frames(self.h, d_comp.ptr, d_out.ptr, sa.ctypes.data, len(segs), res.ctypes.data))
+        return res
 
     def inflate_timing(self):
         ms = (C.c_float * 2)()

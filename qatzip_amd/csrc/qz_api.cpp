@@ -439,6 +439,89 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
     return complete ? QZ_OK : QZ_BUF_ERROR;
 }
 
+/* LZ4 sessions: one frame per call, `last` ignored (src/qatzip_sw.c:443-471) */
+static int compress_lz4(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
+                        unsigned char *dest, unsigned int *dest_len)
+{
+    const uint32_t n = *src_len, cap = *dest_len;
+    *src_len = 0; *dest_len = 0;
+    if (n > 65536) {
+        logmsg(LOG_ERROR, "LZ4 calls above 64 KB need liblz4's linked-block mode, which the GPU path does not produce\n");
+        return QZ_NOT_SUPPORTED;
+    }
+    if (s->p.comp_lvl >= 3) return QZ_NOT_SUPPORTED;               /* level >= 3 is LZ4-HC in liblz4 */
+    const uint64_t bound = 19 + 4 * ((n >> 16) + ((n & 65535) != 0)) + (uint64_t)n + 8;   /* LZ4F_compressFrameBound */
+    if (cap < bound) return QZ_FAIL;                               /* LZ4F_ERROR_dstMaxSize_tooSmall => QZ_FAIL */
+    int rc = reserve(s, n, bound + 64);
+    if (rc) return rc;
+    if (n && qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
+    uint64_t produced = 0;
+    if (qzd_lz4_compress_frames(s->ctx, s->d_in, n, 65536, s->d_out, s->out_cap, &produced, NULL) != QZD_OK) return QZ_FAIL;
+    if (qzd_d2h(s->ctx, dest, s->d_out, produced) != QZD_OK) return QZ_FAIL;
+    *src_len = n; *dest_len = (unsigned int)produced;
+    sess->total_in += n; sess->total_out += produced;
+    return QZ_OK;
+}
+
+/* walk one LZ4 frame on the host: total frame length and (if present) content size; <0 on malformed input */
+static int64_t lz4_frame_extent(const unsigned char *p, uint32_t n, uint64_t *content, bool *has_content)
+{
+    if (n < 7 || rd32(p) != 0x184D2204u) return -1;
+    unsigned flg = p[4];
+    if ((flg >> 6) != 1) return -1;
+    uint32_t pos = 6;
+    *has_content = (flg >> 3) & 1; *content = 0;
+    if (*has_content) { if (n < 14) return -1; *content = (uint64_t)rd32(p + 6) | (uint64_t)rd32(p + 10) << 32; pos += 8; }
+    if (flg & 1) pos += 4;
+    pos += 1;
+    for (;;) {
+        if (pos + 4 > n) return -1;
+        uint32_t bh = rd32(p + pos); pos += 4;
+        if (bh == 0) break;
+        uint32_t bsz = bh & 0x7fffffffu;
+        if (bsz > n - pos) return -1;
+        pos += bsz + ((flg >> 4) & 1 ? 4 : 0);
+    }
+    if ((flg >> 2) & 1) { if (pos + 4 > n) return -1; pos += 4; }
+    return pos;
+}
+
+static int decompress_lz4(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
+                          unsigned char *dest, unsigned int *dest_len)
+{
+    const uint32_t n = *src_len, cap = *dest_len;
+    *src_len = 0; *dest_len = 0;
+    std::vector<qzd_lz4seg> segs;
+    uint32_t ti = 0; uint64_t to = 0;
+    while (ti < n && to < cap) {                                    /* frame loop, src/qatzip_sw.c:555-571 */
+        uint64_t content; bool hc;
+        int64_t ext = lz4_frame_extent(src + ti, n - ti, &content, &hc);
+        if (ext < 0) return QZ_FAIL;                                /* SW path: LZ4F error => QZ_FAIL */
+        if (!hc) content = cap - to;                                /* unknown: give it the rest */
+        if (to + content > cap) { if (segs.empty()) return QZ_BUF_ERROR; break; }
+        qzd_lz4seg g; g.in_off = ti; g.out_off = to; g.in_len = (uint32_t)ext; g.out_cap = (uint32_t)content;
+        segs.push_back(g);
+        ti += (uint32_t)ext; to += content;
+        if (!hc) break;                                             /* sizes unknown beyond this frame: one at a time */
+    }
+    if (segs.empty()) return QZ_OK;
+    int rc = reserve(s, n, cap);
+    if (rc) return rc;
+    if (qzd_h2d(s->ctx, s->d_in, src, ti) != QZD_OK) return QZ_FAIL;
+    std::vector<qzd_lz4res> res(segs.size());
+    if (qzd_lz4_decompress_frames(s->ctx, s->d_in, s->d_out, segs.data(), (uint32_t)segs.size(), res.data()) != QZD_OK) return QZ_FAIL;
+    uint64_t produced = 0;
+    for (size_t i = 0; i < segs.size(); i++) {
+        if (res[i].status != 0 || res[i].in_used != segs[i].in_len) return QZ_FAIL;
+        if (i + 1 < segs.size() && res[i].out_len != segs[i].out_cap) return QZ_FAIL;
+        produced = segs[i].out_off + res[i].out_len;
+    }
+    if (produced && qzd_d2h(s->ctx, dest, s->d_out, produced) != QZD_OK) return QZ_FAIL;
+    *src_len = ti; *dest_len = (unsigned int)produced;
+    sess->total_in += ti; sess->total_out += produced;
+    return (ti < n && to >= cap) ? QZ_OK : QZ_OK;
+}
+
 extern "C" int qzCompressCrcExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
                                 unsigned int *dest_len, unsigned int last, unsigned long *crc, uint64_t *ext_rc)
 {
@@ -447,7 +530,7 @@ extern "C" int qzCompressCrcExt(QzSession_T *sess, const unsigned char *src, uns
     if (ext_rc) *ext_rc = 0;
     rc = ensure_ready(sess, &s);
     if (rc < 0) goto fail;
-    if (s->p.fmt == F_LZ4) rc = QZ_NOT_SUPPORTED;                   /* LZ4 kernels: see DESIGN.md (next) */
+    if (s->p.fmt == F_LZ4) rc = compress_lz4(sess, s, src, src_len, dest, dest_len);
     else if (s->p.fmt == F_LZ4S) rc = QZ_UNSUPPORTED_FMT;
     else rc = compress_deflate(sess, s, src, src_len, dest, dest_len, last, crc);
     sess->thd_sess_stat = rc;
@@ -542,7 +625,7 @@ extern "C" int qzDecompressCrcExt(QzSession_T *sess, const unsigned char *src, u
     if (*src_len == 0) { *dest_len = 0; return QZ_OK; }
     rc = ensure_ready(sess, &s);
     if (rc < 0) goto fail;
-    if (s->p.fmt == F_LZ4) rc = QZ_NOT_SUPPORTED;
+    if (s->p.fmt == F_LZ4) rc = decompress_lz4(sess, s, src, src_len, dest, dest_len);
     else if (s->p.fmt == F_LZ4S) rc = QZ_UNSUPPORTED_FMT;
     else rc = decompress_deflate(sess, s, src, src_len, dest, dest_len, crc);
     sess->thd_sess_stat = rc;

@@ -318,6 +318,87 @@ extern "C" int qzd_last_timing(qzd_ctx *c, float ms[4])
     return QZD_OK;
 }
 
+/* ------------------------------------------------------------------ LZ4 frames (K4 / K5) */
+#include "qzk_lz4.h"
+
+/* every frame_sz bytes of d_src become one LZ4 frame (what one qzCompress call of an LZ4 session emits for
+ * src_len <= 64 KB, src/qatzip_sw.c:443-471); frames are written back to back to d_dst */
+extern "C" int qzd_lz4_compress_frames(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t frame_sz,
+                                       uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len)
+{
+    if (!c || !d_dst || (n && !d_src) || !h_out_len) return QZD_ERR_PARAM;
+    if (frame_sz == 0 || frame_sz > QZK_LZ4_MAXBLK) { snprintf(c->err, sizeof(c->err), "LZ4 frames above 64 KB (linked blocks) are not produced"); return QZD_ERR_UNSUPPORTED; }
+    hipSetDevice(c->device);
+    const uint32_t nfr = n ? (uint32_t)((n + frame_sz - 1) / frame_sz) : 1;
+    const uint32_t stride = (frame_sz + 15 + 4 + 8 + 64 + 15) & ~15u;
+    if (nfr > c->call_cap) {
+        hipDeviceSynchronize();
+        hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs);
+        c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL; c->call_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_len, (size_t)nfr * 4));
+        HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nfr * 4));
+        HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nfr * 8));
+        c->call_cap = nfr;
+    }
+    const uint32_t batch = nfr < 16384u ? nfr : 16384u;
+    if ((size_t)batch * stride > c->slot_cap) {
+        hipDeviceSynchronize();
+        for (int i = 0; i < QZD_NBUF; i++) { hipFree(c->slots[i]); c->slots[i] = NULL; }
+        c->slot_cap = 0;
+        for (int i = 0; i < QZD_NBUF; i++) HIPCHK(c, hipMalloc(&c->slots[i], (size_t)batch * stride));
+        c->slot_cap = (size_t)batch * stride;
+    }
+    hipStream_t st = c->st[0];
+    HIPCHK(c, hipMemsetAsync(c->d_running, 0, 8, st));
+    HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, st));
+    HIPCHK(c, hipEventRecord(c->ev_begin, st));
+    for (uint32_t b = 0; b < nfr; b += batch) {
+        const uint32_t bn = nfr - b < batch ? nfr - b : batch;
+        const uint64_t boff = (uint64_t)b * frame_sz;
+        hipLaunchKernelGGL(qzk_lz4c_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, bn, c->slots[0], stride, c->d_len + b);
+        hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);
+        hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, c->slots[0], stride, c->d_len + b, c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
+    }
+    HIPCHK(c, hipEventRecord(c->ev_end, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_running, c->d_running, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    c->last_nchunks = nfr;
+    if (*c->h_overflow) { snprintf(c->err, sizeof(c->err), "destination too small"); return QZD_ERR_DSTCAP; }
+    *h_out_len = *c->h_running;
+    if (h_frame_len) HIPCHK(c, hipMemcpy(h_frame_len, c->d_len, (size_t)nfr * 4, hipMemcpyDeviceToHost));
+    float t = 0;
+    if (hipEventElapsedTime(&t, c->ev_begin, c->ev_end) == hipSuccess) c->ms[3] = t;
+    return QZD_OK;
+}
+
+/* decode nsegs LZ4 frames {u64 in_off, u64 out_off, u32 in_len, u32 out_cap} -> {i32 status, u32 in_used, u32 out_len, u32 pad};
+ * content checksums are verified on the GPU (XXH32) */
+extern "C" int qzd_lz4_decompress_frames(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const void *h_segs,
+                                         uint32_t nsegs, void *h_res)
+{
+    if (!c || !h_segs || !h_res) return QZD_ERR_PARAM;
+    if (nsegs == 0) return QZD_OK;
+    hipSetDevice(c->device);
+    const size_t sb = (size_t)nsegs * sizeof(qzk_lz4seg), rb = (size_t)nsegs * sizeof(qzk_lz4res);
+    int rc = qzd_aux_reserve(c, sb + rb + 64);
+    if (rc) return rc;
+    qzk_lz4seg *d_segs = (qzk_lz4seg *)c->d_aux;
+    qzk_lz4res *d_res = (qzk_lz4res *)(c->d_aux + ((sb + 15) & ~(size_t)15));
+    hipStream_t st = c->st[0];
+    HIPCHK(c, hipMemcpyAsync(d_segs, h_segs, sb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev_begin, st));
+    hipLaunchKernelGGL(qzk_lz4d_kernel, dim3((nsegs + 3) / 4), dim3(256), 0, st, d_comp, d_out, d_segs, d_res, nsegs);
+    HIPCHK(c, hipEventRecord(c->ev_end, st));
+    HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    float t = 0;
+    if (hipEventElapsedTime(&t, c->ev_begin, c->ev_end) == hipSuccess) c->ms[3] = t;
+    return QZD_OK;
+}
+
 #ifdef QZK_PROF
 /* profiling builds only: raw K1 metadata (with per-phase cycle counters) of buffer set `s` */
 extern "C" int qzd_debug_meta(qzd_ctx *c, int s, void *h_out, uint32_t nchunks)

@@ -1,0 +1,349 @@
+/*
+ * qzk_lz4.h — K4 (LZ4 block compress, lz4 1.9.3 LZ4_compress_fast acceleration 1 semantics),
+ * K5 (LZ4 frame decode) and XXH32 (K6) for gfx950, one frame per wave.
+ *
+ * Replaces LZ4F_compressFrame / LZ4F_decompress on the reference's software path
+ * (src/qatzip_sw.c:443-533) for frames of at most one 64 KB block — the
+ * "64 KB blocks + xxhash32" configuration of BASELINE.json.  Frames whose content
+ * exceeds 64 KB use liblz4's linked-block mode (a dictionary carried across
+ * blocks); that mode is not produced here (decode handles it).
+ * CPU restatement: oracle/qzo_lz4.c.
+ *
+ * Compress: the parse is greedy and serial (every probed position is inserted in
+ * the table; a hit ends the streak), so the wave speculates a WINDOW of the next 64
+ * probe positions at once — hash, table lookup (u32 positions in LDS, inserted with
+ * atomicMax so that order inside the window does not matter), 4-byte compare — and
+ * takes the first hit.  Only lanes whose hash collides with an earlier lane of the
+ * same window need an exact replay, done with readlanes.  Match extension and the
+ * literal copies are wave-parallel.
+ */
+#ifndef QZK_LZ4_H
+#define QZK_LZ4_H
+#include "qzk_common.h"
+
+#define QZK_LZ4_MINMATCH 4
+#define QZK_LZ4_MFLIMIT 12
+#define QZK_LZ4_LASTLIT 5
+#define QZK_LZ4_HASHSZ 8192
+#define QZK_LZ4_MAXBLK 65536
+
+#define QZK_XP1 2654435761u
+#define QZK_XP2 2246822519u
+#define QZK_XP3 3266489917u
+#define QZK_XP4 668265263u
+#define QZK_XP5 374761393u
+QZ_DEV uint32_t qzk_rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+/* XXH32(p[0..n), seed 0) by one wave: lanes 0-3 carry the four stripe accumulators */
+QZ_DEV uint32_t qzk_wave_xxh32(const uint8_t *p, uint32_t n, int lane)
+{
+    uint32_t h, pos = 0;
+    if (n >= 16) {
+        uint32_t v = lane == 0 ? QZK_XP1 + QZK_XP2 : lane == 1 ? QZK_XP2 : lane == 2 ? 0u : 0u - QZK_XP1;
+        const uint32_t stripes = n >> 4;
+        if (lane < 4) for (uint32_t s = 0; s < stripes; s++) v = qzk_rotl(v + qz_ld32(p + 16 * s + 4 * lane) * QZK_XP2, 13) * QZK_XP1;
+        uint32_t v0 = qz_readlane(v, 0), v1 = qz_readlane(v, 1), v2 = qz_readlane(v, 2), v3 = qz_readlane(v, 3);
+        h = qzk_rotl(v0, 1) + qzk_rotl(v1, 7) + qzk_rotl(v2, 12) + qzk_rotl(v3, 18);
+        pos = stripes << 4;
+    } else h = QZK_XP5;
+    h += n;
+    while (pos + 4 <= n) { h = qzk_rotl(h + qz_ld32(p + pos) * QZK_XP3, 17) * QZK_XP4; pos += 4; }
+    while (pos < n) { h = qzk_rotl(h + p[pos] * QZK_XP5, 11) * QZK_XP1; pos++; }
+    h ^= h >> 15; h *= QZK_XP2; h ^= h >> 13; h *= QZK_XP3; h ^= h >> 16;
+    return h;
+}
+
+QZ_DEV void qzk_wave_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int lane)
+{
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64) dst[i] = src[i];
+}
+
+/* common prefix of a[] and b[] (b < a, may overlap), at most maxlen bytes */
+QZ_DEV uint32_t qzk_lz4_count(const uint8_t *a, const uint8_t *b, uint32_t maxlen, int lane)
+{
+    for (uint32_t off = 0; off < maxlen; off += 256) {
+        uint32_t o = off + 4 * (uint32_t)lane, x = 0;
+        bool act = o < maxlen;
+        if (act) {
+            if (o + 4 <= maxlen) x = qz_ld32(a + o) ^ qz_ld32(b + o);
+            else for (uint32_t k = 0; o + k < maxlen; k++) x |= (uint32_t)(a[o + k] ^ b[o + k]) << (8 * k);
+        }
+        uint64_t mm = qz_ballot(act && x != 0);
+        if (mm) {
+            int f = qz_ctz64(mm);
+            uint32_t xf = qz_readlane(x, f);
+            return off + 4 * (uint32_t)f + ((uint32_t)qz_ctz32(xf) >> 3);
+        }
+    }
+    return maxlen;
+}
+
+#define QZK_LZ4HASH(v) (((v) * 2654435761u) >> 19)
+
+/* LZ4 block compress of in[0..n) into out (capacity cap); returns size or 0 when it does not fit.
+ * table: QZK_LZ4_HASHSZ u32 in LDS (zeroed here). */
+QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap, uint32_t *table,
+                              uint32_t *slot, int lane)
+{
+    for (int i = lane; i < QZK_LZ4_HASHSZ; i += 64) table[i] = 0;
+    qz_wave_sync();
+    uint32_t op = 0, anchor = 0, ip;
+    const int32_t mfl1 = (int32_t)n - QZK_LZ4_MFLIMIT + 1;      /* mflimitPlusOne */
+    const uint32_t matchlimit = n - QZK_LZ4_LASTLIT;
+    bool ended = false;
+    if (n >= QZK_LZ4_MFLIMIT + 1) {
+        /* first byte: position 0 goes into the table (it is 0 already), search starts at 1 */
+        ip = 1;
+        for (;;) {
+            /* ---------------- search streak from ip ---------------- */
+            uint32_t j0 = 0, mpos = 0, mcand = 0; bool found = false;
+            for (;;) {
+                /* probe j of a streak sits at ip + S(j): lz4 advances by step = 1 for the first probe and then by
+                 * (searchMatchNb++ >> 6) with searchMatchNb starting at 64, i.e. step_j = (63 + j) >> 6 for j >= 1 */
+                const uint32_t j = j0 + (uint32_t)lane, t = j ? j - 1 : 0, b = t >> 6, r = t & 63;
+                const uint32_t f = ip + (j ? 1 + 32 * b * (b + 1) + (b + 1) * r : 0), step = j ? (63 + j) >> 6 : 1;
+                const bool live = (int32_t)(f + step) <= mfl1;       /* else this probe is the `goto _last_literals` */
+                uint32_t v = 0, h = 0, cand = 0;
+                if (live) { v = qz_ld32(in + f); h = QZK_LZ4HASH(v); cand = table[h]; }
+                const uint32_t key = h & 1023;
+                if (live) slot[key] = 64;
+                qz_wave_sync();
+                if (live) atomicMin(&slot[key], (uint32_t)lane);
+                qz_wave_sync();
+                const bool suspect = live && slot[key] != (uint32_t)lane;
+                bool hit = false;
+                if (live && !suspect) hit = qz_ld32(in + cand) == v;
+                const uint64_t LIVE = qz_ballot(live);
+                uint64_t HIT = qz_ballot(hit);
+                const uint64_t SUS = qz_ballot(suspect);
+                const int first_dead = ~LIVE ? qz_ctz64(~LIVE) : 64;
+                int bound = HIT ? qz_ctz64(HIT) : 64;
+                if (bound > first_dead) bound = first_dead;
+                /* replay colliding lanes that come before the first clean hit */
+                uint64_t todo = SUS & qz_below(bound);
+                int fl = bound; uint32_t fcand = 0;
+                while (todo) {
+                    int s = qz_ctz64(todo);
+                    todo &= todo - 1;
+                    uint32_t hs = qz_readlane(h, s), vs = qz_readlane(v, s);
+                    uint64_t same = qz_ballot(live && h == hs) & qz_below(s);
+                    uint32_t cs, cv;
+                    if (same) { int m = qz_msb64(same); cs = qz_readlane(f, m); cv = qz_readlane(v, m); }
+                    else { cs = qz_readlane(cand, s); cv = qz_ld32(in + cs); }
+                    if (cv == vs) { fl = s; fcand = cs; break; }
+                }
+                if (fl == bound && bound < first_dead && HIT) fcand = qz_readlane(cand, bound);
+                const bool got = fl < first_dead && (fl < bound || (HIT && bound < 64 && fl == bound));
+                /* insert every probed position up to and including the hit (or the whole window) */
+                const int last_ins = got ? fl : (first_dead < 64 ? first_dead - 1 : 63);
+                if (live && lane <= last_ins) atomicMax(&table[h], f);
+                qz_wave_sync();
+                if (got) { found = true; mpos = qz_readlane(f, fl); mcand = fcand; break; }
+                if (first_dead < 64) break;                          /* ran into the end: last literals */
+                j0 += 64;
+            }
+            if (!found) break;
+            /* ---------------- catch up + sequence(s) ---------------- */
+            uint32_t mip = mpos, match = mcand;
+            {   /* backward extension */
+                uint32_t maxb = mip - anchor < match ? mip - anchor : match;
+                uint32_t back = 0;
+                while (back < maxb) {
+                    uint32_t i = back + 1 + (uint32_t)lane;
+                    bool act = i <= maxb;
+                    bool ne = act && in[mip - i] != in[match - i];
+                    uint64_t mm = qz_ballot(ne), am = qz_ballot(act);
+                    if (mm) { back += (uint32_t)qz_ctz64(mm); break; }
+                    back += (uint32_t)qz_popc64(am);
+                }
+                mip -= back; match -= back;
+            }
+            uint32_t lit = mip - anchor, token_at = op++;
+            if (op + lit + (2 + 1 + QZK_LZ4_LASTLIT) + lit / 255 > cap) return 0;
+            uint32_t tok;
+            if (lit >= 15) {
+                uint32_t len = lit - 15; tok = 15u << 4;
+                for (; len >= 255; len -= 255) { if (lane == 0) out[op] = 255; op++; }
+                if (lane == 0) out[op] = (uint8_t)len;
+                op++;
+            } else tok = lit << 4;
+            qzk_wave_copy(out + op, in + anchor, lit, lane); op += lit;
+            for (;;) {          /* _next_match */
+                if (lane == 0) { out[op] = (uint8_t)(mip - match); out[op + 1] = (uint8_t)((mip - match) >> 8); }
+                op += 2;
+                uint32_t mc = qzk_lz4_count(in + mip + 4, in + match + 4, matchlimit - (mip + 4), lane);
+                mip += mc + 4;
+                if (op + (1 + QZK_LZ4_LASTLIT) + (mc + 240) / 255 > cap) return 0;
+                if (mc >= 15) {
+                    tok += 15; mc -= 15;
+                    for (; mc >= 255; mc -= 255) { if (lane == 0) out[op] = 255; op++; }
+                    if (lane == 0) out[op] = (uint8_t)mc;
+                    op++;
+                } else tok += mc;
+                if (lane == 0) out[token_at] = (uint8_t)tok;
+                anchor = mip;
+                if ((int32_t)mip >= mfl1) { ended = true; break; }
+                /* fill table with ip-2, then test the next position right away */
+                uint32_t v2 = qz_ld32(in + mip - 2), v0 = qz_ld32(in + mip);
+                uint32_t h2 = QZK_LZ4HASH(v2), h0 = QZK_LZ4HASH(v0);
+                if (lane == 0) table[h2] = mip - 2;
+                qz_wave_sync();
+                uint32_t mi = table[h0];
+                qz_wave_sync();
+                if (lane == 0) table[h0] = mip;
+                qz_wave_sync();
+                if (qz_ld32(in + mi) == v0) { token_at = op++; tok = 0; match = mi; continue; }
+                break;
+            }
+            if (ended) break;
+            ip = mip + 1;
+        }
+    }
+    /* last literals */
+    {
+        uint32_t lr = n - anchor;
+        if (op + lr + 1 + (lr + 255 - 15) / 255 > cap) return 0;
+        if (lr >= 15) {
+            uint32_t acc = lr - 15;
+            if (lane == 0) out[op] = 15u << 4;
+            op++;
+            for (; acc >= 255; acc -= 255) { if (lane == 0) out[op] = 255; op++; }
+            if (lane == 0) out[op] = (uint8_t)acc;
+            op++;
+        } else { if (lane == 0) out[op] = (uint8_t)(lr << 4); op++; }
+        qzk_wave_copy(out + op, in + anchor, lr, lane); op += lr;
+    }
+    return op;
+}
+
+/* K4: one LZ4 frame (<= 64 KB of content, one independent block) per wave, written to its slot:
+ * LZ4F_compressFrame with {contentChecksum, contentSize, autoFlush, level < 3}. */
+QZ_KERNEL qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
+                          uint8_t *slots, uint32_t stride, uint32_t *out_len)
+{
+    QZ_LDS uint32_t table[QZK_LZ4_HASHSZ];
+    QZ_LDS uint32_t slot[1024];
+    const int lane = qz_lane();
+    const uint32_t fr = blockIdx.x;
+    if (fr >= nframes) return;
+    const uint64_t off = (uint64_t)fr * frame_sz;
+    const uint32_t n = (uint32_t)((src_len - off) < frame_sz ? (src_len - off) : frame_sz);
+    const uint8_t *in = src + off;
+    uint8_t *o = slots + (uint64_t)fr * stride;
+    uint32_t pos = 0;
+    /* frame header: magic, FLG (v1 | independent | [content size] | content checksum), BD 64 KB */
+    if (lane == 0) {
+        o[0] = 0x04; o[1] = 0x22; o[2] = 0x4d; o[3] = 0x18;
+        o[4] = (uint8_t)((1u << 6) | (1u << 5) | (n ? 1u << 3 : 0) | (1u << 2));
+        o[5] = 4u << 4;
+        if (n) { o[6] = (uint8_t)n; o[7] = (uint8_t)(n >> 8); o[8] = (uint8_t)(n >> 16); o[9] = (uint8_t)(n >> 24); o[10] = o[11] = o[12] = o[13] = 0; }
+    }
+    qz_wave_sync();
+    pos = n ? 14 : 6;
+    {
+        uint32_t hc = qzk_wave_xxh32(o + 4, pos - 4, lane);
+        if (lane == 0) o[pos] = (uint8_t)(hc >> 8);
+        pos++;
+    }
+    if (n) {
+        uint32_t c = qzk_lz4_block(in, n, o + pos + 4, n - 1, table, slot, lane);
+        uint32_t bh = c ? c : (n | 0x80000000u);
+        if (c == 0) { qzk_wave_copy(o + pos + 4, in, n, lane); c = n; }
+        if (lane == 0) { o[pos] = (uint8_t)bh; o[pos + 1] = (uint8_t)(bh >> 8); o[pos + 2] = (uint8_t)(bh >> 16); o[pos + 3] = (uint8_t)(bh >> 24); }
+        pos += 4 + c;
+    }
+    uint32_t xx = qzk_wave_xxh32(in, n, lane);
+    if (lane == 0) {
+        o[pos] = o[pos + 1] = o[pos + 2] = o[pos + 3] = 0;
+        o[pos + 4] = (uint8_t)xx; o[pos + 5] = (uint8_t)(xx >> 8); o[pos + 6] = (uint8_t)(xx >> 16); o[pos + 7] = (uint8_t)(xx >> 24);
+        out_len[fr] = pos + 8;
+    }
+}
+
+/* ------------------------------------------------------------------ K5: frame decode */
+typedef struct { uint64_t in_off; uint64_t out_off; uint32_t in_len; uint32_t out_cap; } qzk_lz4seg;
+typedef struct { int32_t status; uint32_t in_used; uint32_t out_len; uint32_t pad; } qzk_lz4res;
+#define QZK_LZ4_OK 0
+#define QZK_LZ4_EDATA (-1)
+#define QZK_LZ4_EOUT (-2)
+#define QZK_LZ4_EIN (-3)
+
+/* decode one block into o[op..); history = o[0..op) (linked frames).  returns new op or ~0u on error */
+QZ_DEV uint32_t qzk_lz4_dblock(const uint8_t *ip, uint32_t n, uint8_t *o, uint32_t op, uint32_t ocap, int lane)
+{
+    uint32_t p = 0;
+    if (n == 0) return ~0u;
+    for (;;) {
+        if (p >= n) return ~0u;
+        uint32_t tok = ip[p++], len = tok >> 4;
+        if (len == 15) { uint32_t b; do { if (p >= n) return ~0u; b = ip[p++]; len += b; } while (b == 255); }
+        if (len > n - p || len > ocap - op) return ~0u;
+        qzk_wave_copy(o + op, ip + p, len, lane); op += len; p += len;
+        if (p == n) break;
+        if (n - p < 2) return ~0u;
+        uint32_t off = ip[p] | (uint32_t)ip[p + 1] << 8; p += 2;
+        if (off == 0 || off > op) return ~0u;
+        len = tok & 15;
+        if (len == 15) { uint32_t b; do { if (p >= n) return ~0u; b = ip[p++]; len += b; } while (b == 255); }
+        len += QZK_LZ4_MINMATCH;
+        if (len > ocap - op) return ~0u;
+        qz_wave_sync();                                     /* this wave's earlier stores -> its loads */
+        for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+            uint32_t si = off >= len ? i : i % off;
+            o[op + i] = o[op - off + si];
+        }
+        op += len;
+    }
+    return op;
+}
+
+QZ_KERNEL qzk_lz4d_kernel(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *segs, qzk_lz4res *res, uint32_t nsegs)
+{
+    const int lane = qz_lane();
+    const uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= nsegs) return;
+    const qzk_lz4seg sg = segs[s];
+    const uint8_t *p = comp + sg.in_off;
+    uint8_t *o = out + sg.out_off;
+    const uint32_t n = sg.in_len;
+    int status = QZK_LZ4_EDATA; uint32_t pos = 0, op = 0;
+    do {
+        if (n < 7) { status = QZK_LZ4_EIN; break; }
+        if (qz_ld32(p) != 0x184D2204u) break;
+        uint32_t flg = p[4];
+        if ((flg >> 6) != 1 || (flg & 2)) break;
+        const bool bcheck = (flg >> 4) & 1, csize = (flg >> 3) & 1, ccheck = (flg >> 2) & 1, dict = flg & 1;
+        pos = 6 + (csize ? 8 : 0) + (dict ? 4 : 0);
+        if (pos + 1 > n) { status = QZK_LZ4_EIN; break; }
+        if (p[pos] != ((qzk_wave_xxh32(p + 4, pos - 4, lane) >> 8) & 0xff)) break;
+        pos++;
+        bool ok = true;
+        for (;;) {
+            if (pos + 4 > n) { status = QZK_LZ4_EIN; ok = false; break; }
+            uint32_t bh = qz_ld32(p + pos); pos += 4;
+            if (bh == 0) break;
+            uint32_t bsz = bh & 0x7fffffffu;
+            if (bsz > n - pos) { status = QZK_LZ4_EIN; ok = false; break; }
+            if (bh & 0x80000000u) {
+                if (bsz > sg.out_cap - op) { status = QZK_LZ4_EOUT; ok = false; break; }
+                qzk_wave_copy(o + op, p + pos, bsz, lane); op += bsz;
+            } else {
+                uint32_t nop = qzk_lz4_dblock(p + pos, bsz, o, op, sg.out_cap, lane);
+                if (nop == ~0u) { ok = false; break; }
+                op = nop;
+            }
+            pos += bsz + (bcheck ? 4 : 0);
+        }
+        if (!ok) break;
+        if (ccheck) {
+            if (pos + 4 > n) { status = QZK_LZ4_EIN; break; }
+            qz_wave_sync();
+            if (qz_ld32(p + pos) != qzk_wave_xxh32(o, op, lane)) break;
+            pos += 4;
+        }
+        status = QZK_LZ4_OK;
+    } while (0);
+    if (lane == 0) { qzk_lz4res r; r.status = status; r.in_used = pos; r.out_len = op; r.pad = 0; res[s] = r; }
+}
+
+#endif

@@ -10,6 +10,7 @@
 #include "../../qatzip_amd/csrc/qzk_deflate_huff.h"
 #include "../../qatzip_amd/csrc/qzk_inflate.h"
 #include "../../qatzip_amd/csrc/qzk_checksum.h"
+#include "../../qatzip_amd/csrc/qzk_lz4.h"
 #include <vector>
 
 extern "C" {
@@ -55,6 +56,21 @@ int sim_inflate(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_i
 {
     uint32_t grid = (nsegs + QZK_INF_WAVES - 1) / QZK_INF_WAVES;
     sim::launch(grid, 64 * QZK_INF_WAVES, 0, [&] { qzk_inflate_kernel(comp, out, segs, res, nsegs); });
+    return 0;
+}
+
+/* K4: nframes LZ4 frames of frame_sz content bytes each -> slots (stride bytes apart) + lengths */
+int sim_lz4c(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, uint32_t stride, uint32_t *out_len)
+{
+    uint32_t nframes = n ? (uint32_t)((n + frame_sz - 1) / frame_sz) : 1;
+    sim::launch(nframes, 64, 0, [&] { qzk_lz4c_kernel(src, n, frame_sz, nframes, slots, stride, out_len); });
+    return (int)nframes;
+}
+
+/* K5: decode nsegs frames */
+int sim_lz4d(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *segs, qzk_lz4res *res, uint32_t nsegs)
+{
+    sim::launch((nsegs + 3) / 4, 256, 0, [&] { qzk_lz4d_kernel(comp, out, segs, res, nsegs); });
     return 0;
 }
 
