@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size-2 gloo group exercising the shard arithmetic, the 16 B/rank record exchange and the
+CRC / offset fold that turn per-rank compressed shards into ONE gzip-ext stream.  The per-rank codec
+here is the oracle (no GPU in this container); on the GPU box the same host logic sits on top of qzd_deflate_raw."""
+import os
+import struct
+import sys
+import zlib
+
+import torch.multiprocessing as mp
+
+import datagen
+import oracle_lib as O
+from qatzip_amd import shard as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_ranges_cover_and_balance():
+    for n in (0, 1, 7, 8, 65, 32768):
+        for w in (1, 2, 3, 8):
+            rs = [S.shard_chunks(n, w, r) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            assert max(e - b for b, e in rs) - min(e - b for b, e in rs) <= 1
+
+
+def test_crc32_combine_matches_zlib():
+    a, b = datagen.gen_bytes("text", 70001, 1), datagen.gen_bytes("rand", 12345, 2)
+    assert S.crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+    assert S.crc32_combine(zlib.crc32(a), zlib.crc32(b""), 0) == zlib.crc32(a)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hw = 16384
+    src = datagen.gen_bytes("silesia", 10 * hw + 777, 5)
+    nchunks = (len(src) + hw - 1) // hw
+    b, e = S.shard_chunks(nchunks, world, rank)
+    mine = src[b * hw:min(e * hw, len(src))]
+    last = 1 if rank == world - 1 else 0
+    rc, used, comp, _ = O.sw_compress("RAW", mine, hw, 1, last=last)      # stand-in for qzd_deflate_raw on this rank's GPU
+    assert rc == 0 and used == len(mine)
+    recs = S.all_gather_records(dist, S.pack_record(len(mine), len(comp), zlib.crc32(mine)), world)
+    offs, raw, total, crc = S.fold_records(recs)
+    t = S.allreduce(dist, float(rank + 1), "MAX")
+    q.put((rank, offs[rank], comp, raw, total, crc, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_build_one_stream():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    src = datagen.gen_bytes("silesia", 10 * 16384 + 777, 5)
+    _, _, _, raw, total, crc, tmax = got[0]
+    stream = bytearray(total)
+    for rank, off, comp, *_ in got:
+        stream[off:off + len(comp)] = comp
+    assert raw == len(src) and tmax == 2.0
+    assert crc == (zlib.crc32(src) & 0xffffffff)
+    # the sharded stream is the single-stream software-path output, byte for byte
+    assert bytes(stream) == O.sw_compress("RAW", src, 16384, 1)[2]
+    gz = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0]) + b"QZ\x08\x00" + struct.pack("<II", raw, total) + \
+        bytes(stream) + struct.pack("<II", crc, raw)
+    assert gz == O.sw_compress("GZIP_EXT", src, 16384, 1)[2]
