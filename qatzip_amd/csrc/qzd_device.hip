@@ -137,6 +137,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     hipDeviceSynchronize();
     for (int i = 0; i < QZD_NBUF; i++) {
         hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
+        if (c->head[i]) hipFree(c->head[i]);
         hipStreamDestroy(c->st[i]); hipEventDestroy(c->done[i]);
         for (int k = 0; k < 4; k++) hipEventDestroy(c->ev[i][k]);
     }
@@ -193,6 +194,9 @@ static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
             HIPCHK(c, hipMalloc(&c->sym_dist[i], sym * 2));
             HIPCHK(c, hipMalloc(&c->slots[i], slot));
             HIPCHK(c, hipMalloc(&c->meta[i], (size_t)batch * sizeof(qzk_lzmeta)));
+            if (c->head[i]) hipFree(c->head[i]);
+            c->head[i] = NULL;
+            HIPCHK(c, hipMalloc(&c->head[i], (size_t)batch * QZK_HSIZE * sizeof(uint16_t)));
         }
         c->sym_cap = sym; c->slot_cap = slot; c->meta_cap = batch;
     }
@@ -239,7 +243,7 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
         const bool timed = k < QZD_NBUF;     /* events of the first use of each buffer set */
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
         hipLaunchKernelGGL(qzk_lz77_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn,
-                           c->sym_lc[s], c->sym_dist[s], c->meta[s]);
+                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->head[s]);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
         hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn,
                            c->sym_lc[s], c->sym_dist[s], c->meta[s], c->slots[s], stride, final_chunk,

@@ -17,6 +17,7 @@ struct qzd_ctx {
     /* scratch per buffer set */
     uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];
     qzk_lzmeta *meta[QZD_NBUF];
+    uint16_t *head[QZD_NBUF];                       /* K1's zlib head[] tables, 128 KiB per chunk of a batch */
     size_t sym_cap, slot_cap; uint32_t meta_cap;
     /* per-call arrays */
     uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;

@@ -35,8 +35,23 @@ QZ_DEV void qz_wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+/* orders only LDS traffic between the lanes of one wave: DS instructions of a wave execute in order, so all
+ * that is needed is to stop the compiler from moving them; outstanding global loads stay in flight */
+QZ_DEV void qz_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 QZ_DEV void qz_block_sync() { __syncthreads(); }
 QZ_DEV int qz_lane() { return (int)(threadIdx.x & 63); }
+/* byte load served by the L2 (sc1, bypasses this CU's vector L1): used to read back bytes this same wave
+ * stored a moment ago.  Vector memory requests of one wave reach the L2 channel of an address in issue order
+ * and the L1 is write-through, so the load observes the earlier store without waiting for its completion. */
+QZ_DEV uint8_t qz_ld8_l2(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+#ifdef QZ_SIM
+static inline void qz_lds_sync() { qz_wave_sync(); }
+static inline uint8_t qz_ld8_l2(const uint8_t *p) { return *p; }
 #endif
 
 QZ_DEV int qz_popc64(uint64_t v) { return __builtin_popcountll(v); }

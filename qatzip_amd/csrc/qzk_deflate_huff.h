@@ -27,7 +27,7 @@
 #define QZK_BLCODES 19
 #define QZK_HEAP 573
 
-typedef struct { uint32_t crc_tab[256]; uint32_t x2n[32]; uint32_t red[16]; } qzk_crc_lds;
+typedef struct { uint32_t tab[4][256]; uint32_t ktab[4][256]; uint32_t x2n[32]; uint32_t red[16]; } qzk_crc_lds;
 
 typedef struct {
     /* frequencies (u32 for LDS atomics) */
@@ -367,14 +367,28 @@ QZ_DEV uint32_t qzk_x2nmodp(const uint32_t *x2n, uint64_t n, unsigned k)
     return p;
 }
 
-/* crc32 of src[0..n) by the whole workgroup (finalised, zlib convention) */
+/* crc32 of src[0..n) by the whole workgroup (finalised, zlib convention).
+ * Layout: the 256 threads sweep the data in rows of 4 KiB, thread t owning the 16 bytes at row*4096 + 16*t, so
+ * every wave load is one coalesced 1 KiB request.  A thread folds its pieces Horner-style:
+ *     acc = acc * x^(8*4096) ^ crc32(piece)          (crc32_combine algebra; the constant multiply is 4 LDS lookups)
+ * then shifts acc by the bytes that follow its last piece, and the partial results are XOR-reduced. */
+QZ_DEV uint32_t qzk_crc16(const qzk_crc_lds *S, uint32_t a, uint32_t b, uint32_t c2, uint32_t d)
+{
+    uint32_t c = 0xffffffffu ^ a;
+    c = S->tab[3][c & 0xff] ^ S->tab[2][(c >> 8) & 0xff] ^ S->tab[1][(c >> 16) & 0xff] ^ S->tab[0][c >> 24]; c ^= b;
+    c = S->tab[3][c & 0xff] ^ S->tab[2][(c >> 8) & 0xff] ^ S->tab[1][(c >> 16) & 0xff] ^ S->tab[0][c >> 24]; c ^= c2;
+    c = S->tab[3][c & 0xff] ^ S->tab[2][(c >> 8) & 0xff] ^ S->tab[1][(c >> 16) & 0xff] ^ S->tab[0][c >> 24]; c ^= d;
+    c = S->tab[3][c & 0xff] ^ S->tab[2][(c >> 8) & 0xff] ^ S->tab[1][(c >> 16) & 0xff] ^ S->tab[0][c >> 24];
+    return ~c;
+}
+
 QZ_DEV uint32_t qzk_block_crc32(qzk_crc_lds *S, const uint8_t *src, uint32_t n)
 {
     const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
     {
         uint32_t c = (uint32_t)t;
         for (int k = 0; k < 8; k++) c = (c & 1) ? QZK_POLY ^ (c >> 1) : c >> 1;
-        S->crc_tab[t] = c;
+        S->tab[0][t] = c;
     }
     if (t == 0) {
         uint32_t p = 1u << 30;
@@ -382,16 +396,41 @@ QZ_DEV uint32_t qzk_block_crc32(qzk_crc_lds *S, const uint8_t *src, uint32_t n)
         for (int i = 1; i < 32; i++) S->x2n[i] = p = qzk_multmodp(p, p);
     }
     qz_block_sync();
-    uint32_t seg = (n + QZK_HT - 1) / QZK_HT;
-    seg = (seg + 3) & ~3u;
-    uint32_t s0 = (uint32_t)t * seg, s1 = s0 + seg;
-    if (s0 > n) s0 = n;
-    if (s1 > n) s1 = n;
-    uint32_t c = 0xffffffffu;
-    for (uint32_t i = s0; i < s1; i++) c = S->crc_tab[(c ^ src[i]) & 0xff] ^ (c >> 8);
-    c = ~c;
+    {
+        uint32_t c0 = S->tab[0][t], c1, c2, c3;
+        c1 = (c0 >> 8) ^ S->tab[0][c0 & 0xff];
+        c2 = (c1 >> 8) ^ S->tab[0][c1 & 0xff];
+        c3 = (c2 >> 8) ^ S->tab[0][c2 & 0xff];
+        S->tab[1][t] = c1; S->tab[2][t] = c2; S->tab[3][t] = c3;
+        /* ktab[k][b] = (b << 8k) * x^(8*4096) mod P : multiply-by-constant as four byte lookups */
+        const uint32_t K = qzk_x2nmodp(S->x2n, 4096, 3);
+        for (int k = 0; k < 4; k++) S->ktab[k][t] = qzk_multmodp(K, (uint32_t)t << (8 * k));
+    }
+    qz_block_sync();
+    const uint32_t rows = n >> 12;
+    uint32_t acc = 0;
+    for (uint32_t r = 0; r < rows; r++) {
+        const uint8_t *q = src + ((uint64_t)r << 12) + 16u * (uint32_t)t;
+        const uint32_t a = qz_ld32(q), b = qz_ld32(q + 4), c = qz_ld32(q + 8), d = qz_ld32(q + 12);
+        acc = S->ktab[0][acc & 0xff] ^ S->ktab[1][(acc >> 8) & 0xff] ^ S->ktab[2][(acc >> 16) & 0xff] ^ S->ktab[3][acc >> 24];
+        acc ^= qzk_crc16(S, a, b, c, d);
+    }
     uint32_t part = 0;
-    if (s1 > s0) part = (s1 == n) ? c : qzk_multmodp(qzk_x2nmodp(S->x2n, n - s1, 3), c);
+    if (rows) {
+        const uint32_t tail = n - ((rows - 1) << 12) - 16u * (uint32_t)t - 16u;   /* bytes after my last full-row piece */
+        part = qzk_multmodp(qzk_x2nmodp(S->x2n, tail, 3), acc);
+    }
+    {   /* the remaining n mod 4096 bytes: one piece of <= 16 bytes per thread */
+        const uint32_t o = (rows << 12) + 16u * (uint32_t)t;
+        if (o < n) {
+            const uint32_t len = n - o < 16 ? n - o : 16;
+            uint32_t c = 0xffffffffu;
+            for (uint32_t i = 0; i < len; i++) c = S->tab[0][(c ^ src[o + i]) & 0xff] ^ (c >> 8);
+            c = ~c;
+            const uint32_t tail = n - o - len;
+            part ^= tail ? qzk_multmodp(qzk_x2nmodp(S->x2n, tail, 3), c) : c;
+        }
+    }
     for (int d = 32; d >= 1; d >>= 1) part ^= qz_shfl(part, lane ^ d);
     if (lane == 0) S->red[wv] = part;
     qz_block_sync();

@@ -15,10 +15,10 @@
  *     candidate compares); a short wave-uniform loop then hops from parse point
  *     to parse point with v_readlane, and only lanes whose hash bucket was also
  *     touched earlier in the same window take a slower exact path.
- *   - hash chains live in LDS (128 KiB of the CU's 160 KiB): a 15-bit bucket
- *     head table (u16) + a prev table of {1 tag bit, 15-bit distance}; the tag is
- *     the hash bit the bucket drops, so chains are walked exactly like zlib's
- *     16-bit-hash chains (wrong-tag links are skipped, not counted).
+ *   - zlib's exact tables: prev[] (32768 x u16 distances) lives in LDS, head[]
+ *     (65536 x u16, indexed by the 16-bit hash) in HBM/L2 - one gather and one
+ *     scatter per window - so a workgroup needs 72 KiB of LDS and two chunks are
+ *     resident per CU; chains are walked exactly like zlib's (<= 4 candidates).
  *   - the 64 KiB input window is read straight from HBM/L2 (coalesced for the
  *     lanes' own bytes, gathers for candidates): LDS is spent on the tables.
  *   - zlib's window slide (strstart >= 65274 => rebase by 32768, NIL==0) is
@@ -37,8 +37,8 @@
 #define QZK_WLIM 61                /* parse points per window: interiors of a len<=4 match stay < 64 */
 #define QZK_NICE 8
 #define QZK_MAXINS 4
-#define QZK_HMIX 0x9E37u           /* odd => bijective on 16 bits */
-#define QZK_NSLOT 4096
+#define QZK_HSIZE 65536            /* zlib hash_bits 16 at memLevel 9 */
+#define QZK_NSLOT 1024
 
 #if defined(QZK_PROF) && !defined(QZ_SIM)
 #define QZK_T(k) do { uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; } while (0)
@@ -87,11 +87,11 @@ QZ_DEV int qzk_wave_matchlen(const uint8_t *src, uint64_t src_len, uint64_t a, u
 }
 
 QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
-                          uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta)
+                          uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint16_t *head_all)
 {
-    QZ_LDS uint16_t head[QZK_WSIZE];       /* 15-bit bucket -> last inserted window position (0 = NIL) */
-    QZ_LDS uint16_t prevt[QZK_WSIZE];      /* [pos & 32767] = tag<<15 | distance to previous bucket mate (0 = none) */
-    QZ_LDS uint32_t slot[QZK_NSLOT];            /* per-window "lowest lane using this bucket key" */
+    QZ_LDS uint16_t prevt[QZK_WSIZE];      /* [pos & 32767] = distance to the previous inserted position with the same hash (0 = none) */
+    QZ_LDS uint32_t slot[QZK_NSLOT];       /* per-window: min(lane<<16 | hash) over the lanes on a hash key */
+    QZ_LDS uint32_t scnt[QZK_NSLOT];       /* per-window: number of lanes on the key */
 
     const int lane = qz_lane();
     const uint32_t chunk = blockIdx.x;
@@ -101,8 +101,11 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
     uint8_t *olc = sym_lc + coff;
     uint16_t *odist = sym_dist + coff;
     qzk_lzmeta *mt = meta + chunk;
+    /* zlib's head[]: 16-bit hash -> last inserted window position (0 = NIL).  It lives in HBM/L2 (128 KiB per
+     * chunk, one gather + one scatter per window); prev[] stays in LDS.  72 KiB of LDS => two chunks per CU. */
+    uint16_t *head = head_all + (uint64_t)chunk * QZK_HSIZE;
 
-    for (int i = lane; i < QZK_WSIZE / 2; i += 64) ((uint32_t *)head)[i] = 0;
+    for (int i = lane; i < QZK_HSIZE / 4; i += 64) ((uint64_t *)head)[i] = 0;
     qz_wave_sync();
 
     uint32_t base = 0;                              /* chunk offset of window position 0 */
@@ -121,7 +124,8 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         if (look < QZK_MINLOOK) {
             if (pos - base >= (uint32_t)(QZK_WSIZE + QZK_MAXDIST)) {
                 base += QZK_WSIZE;
-                for (int i = lane; i < QZK_WSIZE / 2; i += 64) {
+                qz_wave_sync();
+                for (int i = lane; i < QZK_HSIZE / 2; i += 64) {
                     uint32_t v = ((uint32_t *)head)[i], lo = v & 0xffff, hi = v >> 16;
                     lo = lo >= QZK_WSIZE ? lo - QZK_WSIZE : 0;
                     hi = hi >= QZK_WSIZE ? hi - QZK_WSIZE : 0;
@@ -158,55 +162,58 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
             w3 = qzk_ld32g(src, coff + pa + 12, src_len);
         }
         const uint32_t h = (((w0 & 0xf) << 12) ^ (((w0 >> 8) & 0xff) << 6) ^ ((w0 >> 16) & 0xff)) & 0xffff;
-        /* bucket = 15 bits of a bijective mix of zlib's hash, tag = the bit it drops: the two hashes that
-         * share a bucket are unrelated trigrams, so wrong-tag links on a chain are rare */
-        const uint32_t hm = (h * QZK_HMIX) & 0xffff;
-        const uint32_t bucket = hm >> 1, tag = hm & 1;
-        const uint32_t key = bucket & (QZK_NSLOT - 1);
+        const uint32_t bucket = h;
+        const uint32_t key = h & (QZK_NSLOT - 1);
 
         QZK_T(1);
-        /* chain walk on the table state as of the window start */
-        int q0 = canh ? (int)head[bucket] : 0;
-        int q = q0, nc = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        /* chain walk on the table state as of the window start: head (HBM/L2), then <= 3 prev links (LDS);
+         * first candidate needs dist <= MAX_DIST, chained ones cur_match > limit (zlib's asymmetry) */
+        /* the previous window's head[] stores must have landed before this gather (same wave, same CU) */
+        qz_wave_sync();
+        const int q0 = canh ? (int)head[bucket] : 0;
         const int lo = p > QZK_MAXDIST ? (int)(p - QZK_MAXDIST) : 0;
-        bool go = canh && q != 0 && (int)p - q <= QZK_MAXDIST;
-        while (qz_ballot(go)) {
-            if (go) {
-                uint32_t e = prevt[q & (QZK_WSIZE - 1)];
-                if ((e >> 15) == tag) {
-                    if (nc > 0 && q <= lo) go = false;      /* chained candidates need cur_match > limit */
-                    else {
-                        if (nc == 0) c0 = q; else if (nc == 1) c1 = q; else if (nc == 2) c2 = q; else c3 = q;
-                        if (++nc == 4) go = false;
-                    }
-                }
-                if (go) {
-                    int d = (int)(e & 0x7fff), q2 = q - d;
-                    if (d == 0 || q2 <= 0 || (int)p - q2 > QZK_MAXDIST) go = false;
-                    else q = q2;
-                }
-            }
-        }
-        QZK_T(2);
-        /* 16-byte compares against up to 4 candidates (all 16 loads issued before any is used),
-         * then zlib's selection rule */
+        /* straight-line walk (no branches): a dead link parks on the lane's own position, whose loads are
+         * harmless, so the 16-byte candidate loads can be issued as soon as each address is known */
         const int maxlen = avail < 258 ? avail : 258;
         const int nice = avail < QZK_NICE ? avail : QZK_NICE;
         int best_len = 2, best_c = 0;
         int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+        bool suspect;
+        int nc, c0, c1, c2, c3;
         {
             uint32_t x[4][4];
-            for (int k = 0; k < 4; k++) {
-                int ck = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
-                if (k >= nc) ck = (int)p;                   /* harmless address; result ignored */
-                uint64_t g = coff + base + (uint32_t)ck;
-                if (!guard) {
-                    x[k][0] = qz_ld32(src + g); x[k][1] = qz_ld32(src + g + 4);
-                    x[k][2] = qz_ld32(src + g + 8); x[k][3] = qz_ld32(src + g + 12);
-                } else {
-                    x[k][0] = qzk_ld32g(src, g, src_len); x[k][1] = qzk_ld32g(src, g + 4, src_len);
-                    x[k][2] = qzk_ld32g(src, g + 8, src_len); x[k][3] = qzk_ld32g(src, g + 12, src_len);
-                }
+#define QZK_LDC(k, ck) do { uint64_t g_ = coff + base + (uint32_t)(ck); \
+        if (!guard) { x[k][0] = qz_ld32(src + g_); x[k][1] = qz_ld32(src + g_ + 4); x[k][2] = qz_ld32(src + g_ + 8); x[k][3] = qz_ld32(src + g_ + 12); } \
+        else { x[k][0] = qzk_ld32g(src, g_, src_len); x[k][1] = qzk_ld32g(src, g_ + 4, src_len); x[k][2] = qzk_ld32g(src, g_ + 8, src_len); x[k][3] = qzk_ld32g(src, g_ + 12, src_len); } } while (0)
+            const bool ok0 = canh && q0 != 0 && (int)p - q0 <= QZK_MAXDIST;
+            c0 = ok0 ? q0 : (int)p;
+            QZK_LDC(0, c0);
+            int d = prevt[c0 & (QZK_WSIZE - 1)], q = c0 - d;
+            const bool ok1 = ok0 && d != 0 && q > lo;
+            c1 = ok1 ? q : (int)p;
+            QZK_LDC(1, c1);
+            d = prevt[c1 & (QZK_WSIZE - 1)]; q = c1 - d;
+            const bool ok2 = ok1 && d != 0 && q > lo;
+            c2 = ok2 ? q : (int)p;
+            QZK_LDC(2, c2);
+            d = prevt[c2 & (QZK_WSIZE - 1)]; q = c2 - d;
+            const bool ok3 = ok2 && d != 0 && q > lo;
+            c3 = ok3 ? q : (int)p;
+            QZK_LDC(3, c3);
+#undef QZK_LDC
+            nc = (int)ok0 + (int)ok1 + (int)ok2 + (int)ok3;
+            QZK_T(2);
+            /* while those loads are in flight: which lanes share a hash with an EARLIER lane of this window?
+             * slot[key] <- min(lane<<16 | hash), cnt[key] <- number of lanes on the key.  A lane is clean when it is
+             * the lowest lane of its key, or when the key holds exactly two lanes and the other one has a different
+             * hash; everything else takes the exact path. */
+            if (canh) { slot[key] = 0xffffffffu; scnt[key] = 0; }
+            qz_lds_sync();
+            if (canh) { atomicMin(&slot[key], ((uint32_t)lane << 16) | h); atomicAdd(&scnt[key], 1u); }
+            qz_lds_sync();
+            {
+                const uint32_t sv = canh ? slot[key] : 0, sc = canh ? scnt[key] : 0;
+                suspect = canh && (sv >> 16) != (uint32_t)lane && !(sc == 2 && (sv & 0xffff) != h);
             }
             bool done = false;
             for (int k = 0; k < 4; k++) {
@@ -234,15 +241,10 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         const bool exact0 = nc > 0 && (int)p - c0 == QZK_MAXDIST;
 
         QZK_T(3);
-        /* lanes whose bucket key was used by an earlier lane of this window need the exact path */
-        if (canh) slot[key] = 64;
-        qz_wave_sync();
-        if (canh) atomicMin(&slot[key], (uint32_t)lane);
-        qz_wave_sync();
-        const bool suspect = canh && slot[key] != (uint32_t)lane;
-
         const uint64_t CANH = qz_ballot(canh);
-        const uint64_t CX = qz_ballot(suspect || capped);
+        const uint64_t CAPM = qz_ballot(capped);
+        const uint64_t CX = qz_ballot(suspect) | CAPM;
+        const uint64_t NOLIT = qz_ballot(mlen != 0) | CX;     /* lanes the literal-run shortcut must stop at */
 
         QZK_T(4);
         /* ---- serial resolution (wave-uniform) ---- */
@@ -267,15 +269,28 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
             int nextc = cxr ? l + qz_ctz64(cxr) : 64;
             int stop = nextc < lim ? nextc : lim;
             while (l < stop) {                      /* hot loop: hop over clean parse points */
+                /* a run of literal lanes is a run of parse points: take it in one step, no readlane */
+                const uint64_t nl = NOLIT >> l;
+                int t = nl ? qz_ctz64(nl) : 64;
+                if (t > stop - l) t = stop - l;
+                if (t) { Pm |= qz_below(t) << l; l += t; continue; }
                 Pm |= 1ull << l;
-                uint32_t ml = qz_readlane(mlen, l);
-                l += ml ? (int)ml : 1;
+                l += (int)qz_readlane(mlen, l);
             }
             if (l >= lim || l != nextc) continue;
             /* -- exact path for lane l -- */
             QZK_T(5); QZK_C(9, 1);
             {
                 const uint32_t h_l = qz_readlane(h, l);
+                /* early out: no earlier lane of this window carries the hash and nothing needs extending =>
+                 * the speculative answer is already exact */
+                if ((qz_ballot(canh && h == h_l) & qz_below(l)) == 0 && !((CAPM >> l) & 1)) {
+                    Pm |= 1ull << l;
+                    uint32_t ml = qz_readlane(mlen, l);
+                    l += ml ? (int)ml : 1;
+                    QZK_T(6);
+                    continue;
+                }
                 const int avail_l = (int)look - l;
                 const int maxlen_l = avail_l < 258 ? avail_l : 258;
                 const int nice_l = avail_l < QZK_NICE ? avail_l : QZK_NICE;
@@ -288,10 +303,22 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
                 if (B == 0) Sh &= ~1ull;               /* window position 0 is NIL */
                 int cnt = 0, bl = 2; uint32_t bd = 0; bool fin = false;
                 const bool had_intra = Sh != 0;
+                const uint32_t a0 = qz_readlane(w0, l), a1 = qz_readlane(w1, l), a2 = qz_readlane(w2, l), a3 = qz_readlane(w3, l);
                 while (Sh && cnt < 4 && !fin) {
                     int j = qz_msb64(Sh);
                     Sh &= ~(1ull << j);
-                    int len = qzk_wave_matchlen(src, src_len, coff + pos + (uint32_t)l, coff + pos + (uint32_t)j, maxlen_l, lane);
+                    /* both strings start inside this window: their first 16 bytes are already in registers */
+                    int len = QZK_CAP;
+                    {
+                        uint32_t d;
+                        d = a3 ^ qz_readlane(w3, j); if (d) len = 12 + (qz_ctz32(d) >> 3);
+                        d = a2 ^ qz_readlane(w2, j); if (d) len = 8 + (qz_ctz32(d) >> 3);
+                        d = a1 ^ qz_readlane(w1, j); if (d) len = 4 + (qz_ctz32(d) >> 3);
+                        d = a0 ^ qz_readlane(w0, j); if (d) len = (qz_ctz32(d) >> 3);
+                    }
+                    if (len > maxlen_l) len = maxlen_l;
+                    if (len == QZK_CAP && maxlen_l > QZK_CAP)
+                        len = qzk_wave_matchlen(src, src_len, coff + pos + (uint32_t)l, coff + pos + (uint32_t)j, maxlen_l, lane);
                     cnt++;
                     if (len > bl) { bl = len; bd = (uint32_t)(l - j); }
                     if (len >= nice_l) fin = true;
@@ -350,10 +377,10 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         /* clean inserted lanes: link to the table head seen at window start */
         if (isI && !suspect) {
             uint32_t d = (q0 != 0 && p - (uint32_t)q0 <= 32767u) ? p - (uint32_t)q0 : 0;
-            prevt[p & (QZK_WSIZE - 1)] = (uint16_t)((tag << 15) | d);
+            prevt[p & (QZK_WSIZE - 1)] = (uint16_t)d;
             head[bucket] = (uint16_t)p;
         }
-        qz_wave_sync();
+        qz_lds_sync();
         {   /* suspect inserted lanes, in position order */
             uint64_t todo = I & qz_ballot(suspect);
             QZK_C(10, qz_popc64(todo)); QZK_C(11, qz_popc64(Pm));
@@ -369,12 +396,12 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
                     d = (q0j != 0 && pj - q0j <= 32767u) ? pj - q0j : 0;
                 }
                 if (lane == j) {
-                    prevt[p & (QZK_WSIZE - 1)] = (uint16_t)((tag << 15) | d);
+                    prevt[p & (QZK_WSIZE - 1)] = (uint16_t)d;
                     head[bucket] = (uint16_t)p;
                 }
             }
         }
-        qz_wave_sync();
+        qz_lds_sync();
         pos += (uint32_t)l;
         QZK_T(12);
     }

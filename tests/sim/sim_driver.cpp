@@ -19,7 +19,8 @@ extern "C" {
 int sim_lz77(const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta)
 {
     uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
-    sim::launch(nchunks, 64, 0, [&] { qzk_lz77_kernel(src, n, chunk_sz, nchunks, lc, dist, meta); });
+    std::vector<uint16_t> head((size_t)nchunks * QZK_HSIZE, 0xabcd);   /* the kernel clears its own slice */
+    sim::launch(nchunks, 64, 0, [&] { qzk_lz77_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, head.data()); });
     return (int)nchunks;
 }
 
@@ -34,7 +35,8 @@ int sim_deflate(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uin
     uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
     std::vector<uint8_t> slots((size_t)nchunks * stride);
     std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
-    sim::launch(nchunks, 64, 0, [&] { qzk_lz77_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data()); });
+    std::vector<uint16_t> head((size_t)nchunks * QZK_HSIZE, 0xabcd);
+    sim::launch(nchunks, 64, 0, [&] { qzk_lz77_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), head.data()); });
     sim::launch(nchunks, QZK_HT, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
                         last ? nchunks - 1 : ~0u, olen.data(), ocrc.data());
