@@ -146,6 +146,8 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     hipHostFree(c->h_running); hipHostFree(c->h_overflow);
     if (c->d_aux) hipFree(c->d_aux);
     if (c->h_aux) hipHostFree(c->h_aux);
+    if (c->d_big) hipFree(c->d_big);
+    if (c->d_lane) hipFree(c->d_lane);
     delete c;
 }
 
@@ -212,6 +214,68 @@ static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
     return QZD_OK;
 }
 
+#include "qzk_deflate_lz77_lane.h"
+/* measured on MI355X: a lane needs ~290 ms per 64 KB chunk, so 32 768 chunks run at 4.6 GB/s
+ * against 7.9 GB/s for the wave kernel; K1b only pays off beyond ~10^5 chunks in flight => opt-in for now */
+#define QZD_LZ_LANE_MIN_CHUNKS 0xffffffffu
+
+/* one batch = the whole call: K1b over every chunk, then K2, scan, gather */
+static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int last,
+                             uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks)
+{
+    const uint32_t stride = slot_stride_for(chunk_sz);
+    const size_t symb = ((size_t)nchunks * chunk_sz + 511) & ~(size_t)255;
+    const size_t metab = ((size_t)nchunks * sizeof(qzk_lzmeta) + 255) & ~(size_t)255;
+    const size_t slotb = (size_t)nchunks * stride;
+    const size_t headb = (size_t)nchunks * QZK_HSIZE * 2, prevb = (size_t)nchunks * QZK_WSIZE * 2;
+    const size_t need = symb * 3 + metab + slotb + headb + prevb;
+    if (need > c->lane_cap) {
+        hipDeviceSynchronize();
+        if (c->d_lane) hipFree(c->d_lane);
+        c->d_lane = NULL; c->lane_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_lane, need));
+        c->lane_cap = need;
+    }
+    if (nchunks > c->call_cap) {
+        hipDeviceSynchronize();
+        hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs);
+        c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL; c->call_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_len, (size_t)nchunks * 4));
+        HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nchunks * 4));
+        HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nchunks * 8));
+        c->call_cap = nchunks;
+    }
+    uint8_t *pb = c->d_lane;
+    uint8_t *sym_lc = pb; pb += symb;
+    uint16_t *sym_dist = (uint16_t *)pb; pb += 2 * symb;
+    qzk_lzmeta *meta = (qzk_lzmeta *)pb; pb += metab;
+    uint8_t *slots = pb; pb += slotb;
+    uint16_t *head = (uint16_t *)pb; pb += headb;
+    uint16_t *prev = (uint16_t *)pb;
+    hipStream_t st = c->st[0];
+    c->last_nchunks = nchunks; c->nbatches = 1;
+    HIPCHK(c, hipMemsetAsync(c->d_running, 0, 8, st));
+    HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, st));
+    HIPCHK(c, hipEventRecord(c->ev_begin, st));
+    HIPCHK(c, hipMemsetAsync(head, 0, headb, st));
+    HIPCHK(c, hipEventRecord(c->ev[0][0], st));
+    hipLaunchKernelGGL(qzk_lz77_lane_kernel, dim3((nchunks + 63) / 64), dim3(64), 0, st, d_src, n, chunk_sz, nchunks,
+                       sym_lc, sym_dist, meta, head, prev);
+    HIPCHK(c, hipEventRecord(c->ev[0][1], st));
+    hipLaunchKernelGGL(qzk_huff_kernel, dim3(nchunks), dim3(QZK_HT), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist,
+                       meta, slots, stride, last ? nchunks - 1 : ~0u, c->d_len, c->d_crc);
+    HIPCHK(c, hipEventRecord(c->ev[0][2], st));
+    hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len, nchunks, c->d_offs, c->d_running);
+    hipLaunchKernelGGL(qzk_gather_kernel, dim3(nchunks), dim3(256), 0, st, slots, stride, c->d_len, c->d_offs, nchunks,
+                       d_dst, dst_cap, c->d_overflow);
+    HIPCHK(c, hipEventRecord(c->ev[0][3], st));
+    HIPCHK(c, hipMemcpyAsync(c->h_running, c->d_running, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev_end, st));
+    HIPCHK(c, hipGetLastError());
+    return QZD_OK;
+}
+
 extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
                                      int last, uint8_t *d_dst, uint64_t dst_cap)
 {
@@ -221,6 +285,13 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
     if (n > ((uint64_t)1 << 32)) return QZD_ERR_PARAM;
     hipSetDevice(c->device);
     const uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
+    {
+        /* many chunks: one chunk per LANE (K1b, tables in HBM, every chunk of the call in flight at once);
+         * few chunks: one chunk per wave (K1, tables in LDS).  QATZIP_AMD_DEFLATE=lane|wave overrides. */
+        const char *force = getenv("QATZIP_AMD_DEFLATE");
+        const bool lanes = force ? force[0] == 'l' : nchunks >= QZD_LZ_LANE_MIN_CHUNKS;
+        if (lanes) return deflate_lane_path(c, d_src, n, chunk_sz, last, d_dst, dst_cap, nchunks);
+    }
     int rc = ensure_scratch(c, chunk_sz, nchunks);
     if (rc) return rc;
     const uint32_t stride = slot_stride_for(chunk_sz);

@@ -24,8 +24,14 @@
 #include <vector>
 
 #include "qzd_internal.h"
+#include <stdlib.h>
 #include "qzk_inflate.h"
+#include "qzk_inflate_lane.h"
 #include "qzk_checksum.h"
+
+/* a lane needs ~60 ms per 64 KB segment whatever the segment count, the wave kernel does ~300 segments/ms
+ * (bound by the CUs' scalar units): lanes win from ~18 000 segments on (measured) */
+#define QZD_LANE_MIN_SEGS 20000u
 
 /* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF */
 __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list, uint32_t cap, uint32_t *count)
@@ -53,6 +59,22 @@ extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *
     hipStream_t st = c->st[0];
     HIPCHK(c, hipMemcpyAsync(d_segs, h_segs, sb, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
+    /* few segments: one wave each (a segment finishes sooner); thousands: one LANE each (the wave-per-segment
+     * kernel is bound by the CU's scalar unit, K3b spreads the serial work over the vector lanes) */
+    const char *force = getenv("QATZIP_AMD_INFLATE");
+    const bool lanes = force ? force[0] == 'l' : nsegs >= QZD_LANE_MIN_SEGS;
+    if (lanes) {
+        const size_t tb = (size_t)nsegs * sizeof(qzk_inf_tab);
+        if (tb > c->big_cap) {
+            hipDeviceSynchronize();
+            if (c->d_big) hipFree(c->d_big);
+            c->d_big = NULL; c->big_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_big, tb));
+            c->big_cap = tb;
+        }
+        hipLaunchKernelGGL(qzk_inflate_lane_kernel, dim3((nsegs + 63) / 64), dim3(64), 0, st, d_comp, d_out, d_segs, d_res,
+                           nsegs, (qzk_inf_tab *)c->d_big);
+    } else
     hipLaunchKernelGGL(qzk_inflate_kernel, dim3((nsegs + QZK_INF_WAVES - 1) / QZK_INF_WAVES), dim3(64 * QZK_INF_WAVES),
                        0, st, d_comp, d_out, d_segs, d_res, nsegs);
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
@@ -128,6 +150,25 @@ static int find_markers(qzd_ctx *c, const uint8_t *d_src, uint64_t n, std::vecto
     return QZD_OK;
 }
 
+/* Launch all candidate segments, ordered by compressed size: lanes (K3b) or waves of one workgroup then carry
+ * segments of similar work, which bounds the divergence / tail of mixed data.  Results come back in candidate order. */
+static int inflate_grouped(qzd_ctx *c, const uint8_t *d_src, uint8_t *d_dst, std::vector<qzk_infseg> &segs,
+                           std::vector<qzk_infres> &res, const std::vector<uint32_t> &start, uint64_t n)
+{
+    const uint32_t ns = (uint32_t)segs.size();
+    std::vector<uint32_t> order(ns);
+    for (uint32_t i = 0; i < ns; i++) order[i] = i;
+    auto clen = [&](uint32_t k) { return (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k]; };
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { uint32_t la = clen(a), lb = clen(b); return la != lb ? la < lb : a < b; });
+    std::vector<qzk_infseg> ps(ns);
+    std::vector<qzk_infres> pr(ns);
+    for (uint32_t i = 0; i < ns; i++) ps[i] = segs[order[i]];
+    int rc = qzd_inflate_segments(c, d_src, d_dst, ps.data(), ns, pr.data());
+    if (rc) return rc;
+    for (uint32_t i = 0; i < ns; i++) res[order[i]] = pr[i];
+    return QZD_OK;
+}
+
 static int map_status(int st)
 {
     switch (st) {
@@ -166,7 +207,7 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
             segs[k].out_cap = (uint32_t)std::min<uint64_t>(seg_hint, dst_cap - segs[k].out_off);
             segs[k].flags = 0; segs[k].pad = 0;
         }
-        rc = qzd_inflate_segments(c, d_src, d_dst, segs.data(), ns, res.data());
+        rc = inflate_grouped(c, d_src, d_dst, segs, res, start, n);
         if (rc) return rc;
         bool ok = true; uint32_t k = 0;
         for (;; k++) {
@@ -185,7 +226,7 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
             segs[k].in_off = start[k]; segs[k].in_len = (uint32_t)(n - start[k]);
             segs[k].out_off = 0; segs[k].out_cap = 0xffffffffu; segs[k].flags = QZK_INF_COUNT_ONLY; segs[k].pad = 0;
         }
-        rc = qzd_inflate_segments(c, d_src, d_dst, segs.data(), ns, res.data());
+        rc = inflate_grouped(c, d_src, d_dst, segs, res, start, n);
         if (rc) return rc;
         std::vector<qzk_infseg> chain;
         uint64_t oo = 0; uint32_t k = 0; bool ok = true;

@@ -8,7 +8,9 @@
 #include "hipsim.h"
 #include "../../qatzip_amd/csrc/qzk_deflate_lz77.h"
 #include "../../qatzip_amd/csrc/qzk_deflate_huff.h"
+#include "../../qatzip_amd/csrc/qzk_deflate_lz77_lane.h"
 #include "../../qatzip_amd/csrc/qzk_inflate.h"
+#include "../../qatzip_amd/csrc/qzk_inflate_lane.h"
 #include "../../qatzip_amd/csrc/qzk_checksum.h"
 #include "../../qatzip_amd/csrc/qzk_lz4.h"
 #include <vector>
@@ -51,6 +53,35 @@ int sim_deflate(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uin
     return (int)nchunks;
 }
 
+/* K1b (one chunk per lane) + K2 */
+int sim_deflate_lane(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len,
+                     uint32_t *crcs)
+{
+    uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
+    std::vector<uint8_t> lc(n + 64);
+    std::vector<uint16_t> dist(n + 64);
+    std::vector<qzk_lzmeta> meta(nchunks);
+    uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
+    std::vector<uint8_t> slots((size_t)nchunks * stride);
+    std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
+    std::vector<uint16_t> head((size_t)nchunks * QZK_HSIZE, 0), prev((size_t)nchunks * QZK_WSIZE, 0x5a5a);
+    sim::launch((nchunks + 63) / 64, 64, 0, [&] {
+        qzk_lz77_lane_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), head.data(), prev.data());
+    });
+    sim::launch(nchunks, QZK_HT, 0, [&] {
+        qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
+                        last ? nchunks - 1 : ~0u, olen.data(), ocrc.data());
+    });
+    uint64_t pos = 0;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);
+        pos += olen[c];
+        if (crcs) crcs[c] = ocrc[c];
+    }
+    *out_len = pos;
+    return (int)nchunks;
+}
+
 unsigned sim_meta_size(void) { return (unsigned)sizeof(qzk_lzmeta); }
 
 /* K3: inflate nsegs segments described by (in_off, out_off, in_len, out_cap, flags, pad) records */
@@ -73,6 +104,14 @@ int sim_lz4c(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, 
 int sim_lz4d(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *segs, qzk_lz4res *res, uint32_t nsegs)
 {
     sim::launch((nsegs + 3) / 4, 256, 0, [&] { qzk_lz4d_kernel(comp, out, segs, res, nsegs); });
+    return 0;
+}
+
+/* K3b: one segment per lane */
+int sim_inflate_lane(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
+{
+    std::vector<qzk_inf_tab> tabs(nsegs);
+    sim::launch((nsegs + 63) / 64, 64, 0, [&] { qzk_inflate_lane_kernel(comp, out, segs, res, nsegs, tabs.data()); });
     return 0;
 }
 

@@ -70,3 +70,13 @@ def test_dst_too_small_is_reported(ctx):
     d_dst = ctx.alloc(1000)
     with pytest.raises(qatzip_amd.QzdError):
         ctx.deflate_raw(d_src, len(src), 65536, 1, 1, d_dst)
+
+
+def test_lane_per_chunk_kernel_is_bit_exact_too(ctx, monkeypatch):
+    # K1b (one chunk per lane, tables in HBM): opt-in through QATZIP_AMD_DEFLATE=lane, same bytes
+    monkeypatch.setenv("QATZIP_AMD_DEFLATE", "lane")
+    for kind, n, chunk in (("silesia", 3 << 20, 65536), ("lzmix", 140000, 65536), ("text", 300000, 131072),
+                           ("rand", 200000, 16384), ("runs", 65400, 65536)):
+        src = datagen.gen_bytes(kind, n, 123)
+        got, crcs = _gpu_raw(ctx, src, chunk)
+        assert got == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2], (kind, n, chunk)

@@ -101,3 +101,21 @@ def test_roundtrip_own_compressor_large(ctx):
     assert iu == n and ol == len(src) and crc == (zlib.crc32(src) & 0xffffffff)
     assert d_o.download(ol).tobytes() == src
     assert ctx.crc32(d_src, len(src)) == (zlib.crc32(src) & 0xffffffff)
+
+
+@pytest.mark.parametrize("mode", ["lane", "wave"])
+def test_both_inflate_kernels_agree(ctx, monkeypatch, mode):
+    # K3 (segment per wave) and K3b (segment per lane) are selected by segment count; force each one
+    monkeypatch.setenv("QATZIP_AMD_INFLATE", mode)
+    for kind, n, chunk in (("silesia", 3 << 20, 65536), ("lzmix", 140000, 65536), ("rand", 300000, 65536),
+                           ("allA", 1 << 20, 16384)):
+        src = datagen.gen_bytes(kind, n, 33)
+        rc, _, comp, _ = O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)
+        for hint in (chunk, 0):
+            iu, out, crc = _inflate(ctx, comp, n, hint)
+            assert out == src and iu == len(comp) and crc == (zlib.crc32(src) & 0xffffffff), (mode, kind, hint)
+    co = zlib.compressobj(9, zlib.DEFLATED, -15)
+    src = datagen.gen_bytes("text", 500000, 1)
+    comp = co.compress(src) + co.flush()
+    iu, out, crc = _inflate(ctx, comp, len(src))
+    assert out == src

@@ -73,3 +73,36 @@ def test_deflate_not_last(sim):
     src = datagen.gen_bytes("text", 40000, 2)
     out, _ = _sim_deflate(sim, src, 16384, last=0)
     assert out == O.sw_compress("RAW", src, 16384, 1, last=0)[2]
+
+
+def test_lane_kernels_match_oracle(sim):
+    """K1b (one chunk per lane) and K3b (one segment per lane): same contracts, opposite mapping."""
+    sim.sim_deflate_lane.argtypes = sim.sim_deflate.argtypes
+    sim.sim_inflate_lane.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    seg_dt = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
+    res_dt = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
+    for kind in datagen.KINDS:
+        for n, chunk in ((0, 65536), (70000, 16384), (65400, 65536), (140000, 131072), (9000, 1024)):
+            if kind == "lzmix" and n > 70000:
+                n = 66000
+            src = datagen.gen_bytes(kind, n, 8)
+            nch = max(1, (n + chunk - 1) // chunk)
+            cap = n * 9 // 8 + 4096 * (nch + 1)
+            out = C.create_string_buffer(cap); ol = C.c_uint64(0); crcs = np.zeros(nch, np.uint32)
+            sim.sim_deflate_lane(src, n, chunk, 1, out, C.byref(ol), crcs.ctypes.data)
+            comp = out.raw[:ol.value]
+            assert comp == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 8192)[2], (kind, n, chunk)
+            # decode every chunk's segment with the lane inflate kernel
+            import refcalls as R
+            pieces = R.raw_chunks(src, chunk, 1, 1) if zlib.ZLIB_RUNTIME_VERSION == "1.2.11" else None
+            if pieces is None or n == 0:
+                continue
+            segs, off, oo = [], 0, 0
+            for pc in pieces:
+                ln = min(chunk, n - oo)
+                segs.append((off, oo, len(comp) - off, ln, 0, 0)); off += len(pc); oo += ln
+            cbuf = np.frombuffer(comp + b"\0" * 64, np.uint8).copy(); obuf = np.zeros(n + 64, np.uint8)
+            sa = np.array(segs, dtype=seg_dt); res = np.zeros(len(segs), res_dt)
+            sim.sim_inflate_lane(cbuf.ctypes.data, obuf.ctypes.data, sa.ctypes.data, res.ctypes.data, len(segs))
+            assert bytes(obuf[:n]) == src and (res["status"] >= 0).all(), (kind, n, chunk)
+            assert [int(r["in_used"]) for r in res] == [len(pc) for pc in pieces]
