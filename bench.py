@@ -26,7 +26,7 @@ import numpy as np  # noqa: E402
 
 CHUNK = 65536
 CALL_BYTES = 1 << 31            # one qzCompress-sized call (2 GiB)
-BATCH_CHUNKS = 2048             # chunks per K1 launch (QZD_BATCH in qatzip_amd/csrc/qzd_internal.h)
+BATCH_CHUNKS = 8192             # chunks per K1 launch (QZD_BATCH in qatzip_amd/csrc/qzd_internal.h)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -144,6 +144,17 @@ def main():
     tc = allreduce(pg, tc, "MAX"); td = allreduce(pg, td, "MAX")
 
     if rank == 0:
+        # HBM traffic of one K1 launch: PMC counters cannot be read from inside this process; they come from the
+        # committed rocprofv3 --pmc passes of this same command (profiles/r1_pmc.json, tools/pmc_summary.py),
+        # FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as f:
+                pk = json.load(f)["kernels"].get("qzk_lz77_kernel[grid=%d]" % (BATCH_CHUNKS * 64))
+            if pk and probe_n == BATCH_CHUNKS * CHUNK:
+                traffic = pk["hbm_bytes_fetch_x2"]
+        except (OSError, KeyError, ValueError):
+            pass
         value = 2.0 * raw_total * args.steps / dt / 1e9
         ratio = comp_total / raw_total
         alg_bytes = probe_n + probe_out                       # U + C of one K1 launch
@@ -161,7 +172,8 @@ def main():
                        "compress_GBps": round(raw_total / tc / 1e9, 3), "decompress_GBps": round(raw_total / td / 1e9, 3)},
             "roofline": {"bound": "hbm", "kernel": "qzk_lz77_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": None, "launch_ms": round(k_ms[0], 3), "launch_chunks": probe_n // CHUNK,
+                         "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
+                         "launch_ms": round(k_ms[0], 3), "launch_chunks": probe_n // CHUNK,
                          "other_kernels_ms": {"qzk_huff_kernel": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
                                               "qzk_inflate_kernel(last call)": round(inf_ms[0], 3),
                                               "qzk_crc_kernel(last call)": round(inf_ms[1], 3)}},

@@ -120,6 +120,7 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
     for (int i = 0; i < QZD_NBUF; i++) {
         if (hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking) != hipSuccess) return QZD_ERR_HIP;
         hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&c->k1done[i], hipEventDisableTiming);
         for (int k = 0; k < 4; k++) hipEventCreate(&c->ev[i][k]);
     }
     hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
@@ -138,7 +139,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     for (int i = 0; i < QZD_NBUF; i++) {
         hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
         if (c->head[i]) hipFree(c->head[i]);
-        hipStreamDestroy(c->st[i]); hipEventDestroy(c->done[i]);
+        hipStreamDestroy(c->st[i]); hipEventDestroy(c->done[i]); hipEventDestroy(c->k1done[i]);
         for (int k = 0; k < 4; k++) hipEventDestroy(c->ev[i][k]);
     }
     hipEventDestroy(c->ev_begin); hipEventDestroy(c->ev_end);
@@ -312,9 +313,13 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
         const uint32_t final_chunk = (last && b + bn == nchunks) ? bn - 1 : ~0u;
         hipStream_t st = c->st[s];
         const bool timed = k < QZD_NBUF;     /* events of the first use of each buffer set */
+        /* K1 already fills every CU's LDS (two workgroups each): two K1 launches side by side would only take turns,
+         * so K1 of batch k starts when K1 of batch k-1 is done; what overlaps with it is K2/scan/gather of batch k-1 */
+        if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->k1done[so], 0));
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
         hipLaunchKernelGGL(qzk_lz77_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn,
                            c->sym_lc[s], c->sym_dist[s], c->meta[s], c->head[s]);
+        HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
         hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn,
                            c->sym_lc[s], c->sym_dist[s], c->meta[s], c->slots[s], stride, final_chunk,

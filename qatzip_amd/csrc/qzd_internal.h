@@ -7,13 +7,13 @@
 #include "../../include/qzamd_device.h"
 #include "qzk_deflate_lz77.h"
 
-#define QZD_BATCH 2048u
+#define QZD_BATCH 8192u
 #define QZD_NBUF 2
 
 struct qzd_ctx {
     int device;
     hipStream_t st[QZD_NBUF];
-    hipEvent_t done[QZD_NBUF];
+    hipEvent_t done[QZD_NBUF], k1done[QZD_NBUF];
     /* scratch per buffer set */
     uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];
     qzk_lzmeta *meta[QZD_NBUF];

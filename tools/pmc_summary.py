@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are collected in SEPARATE runs, as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes) into profiles/<round>_pmc.json.
+
+usage: tools/pmc_summary.py <fetch_dir> <write_dir> <out.json>
+Units: rocprofv3 reports both counters in KiB.  gfx950 correction (guide, §HBM): FETCH_SIZE counts 128-B requests
+as 64 B for wide coalesced streaming reads => x2; calibrated here on qzk_crc_kernel, a pure 16-B/lane streaming read
+whose byte count is known.  For gather-heavy kernels the factor is between 1 and 2; both figures are kept."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d, name):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == name:
+            agg[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+
+
+def main():
+    fd, wd, out = sys.argv[1:4]
+    fetch, nf = load(fd, "FETCH_SIZE")
+    write, nw = load(wd, "WRITE_SIZE")
+    res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --mb 256 --steps 1 --warmup 1 --no-cpu",
+           "unit": "bytes per launch (average over the launches of the run)", "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        if not k[0].startswith("qzk_"):
+            continue
+        f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
+        res["kernels"]["%s[grid=%d]" % k] = {
+            "launches": nf.get(k, nw.get(k, 0)), "fetch_size_kib": round(f_kib, 1), "write_size_kib": round(w_kib, 1),
+            "hbm_bytes_raw": int((f_kib + w_kib) * 1024), "hbm_bytes_fetch_x2": int((2 * f_kib + w_kib) * 1024)}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
