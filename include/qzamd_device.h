@@ -118,8 +118,9 @@ int qzd_lz4_compress_frames(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint
 int qzd_lz4_decompress_frames(qzd_ctx *ctx, const uint8_t *d_comp, uint8_t *d_out, const void *h_segs,
                               uint32_t nsegs, void *h_res);
 
-/* GPU time (ms) spent in [0] inflate kernels, [1] crc kernels by the last qzd_inflate_stream call */
-int qzd_last_inflate_timing(qzd_ctx *ctx, float ms[2]);
+/* GPU time (ms) of the last qzd_inflate_stream call: [0] inflate kernels, [1] crc kernels, [2] the part of [0]
+ * spent in the match-resolve phase of the two-phase path (0 on the wave-per-segment path), [3] reserved (0) */
+int qzd_last_inflate_timing(qzd_ctx *ctx, float ms[4]);
 
 #ifdef __cplusplus
 }

@@ -47,7 +47,7 @@ def load(build_if_missing=True):
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.qzd_crc32.argtypes = [vp, u8p, C.c_uint64, C.POINTER(C.c_uint32)]
     L.qzd_crc32_ranges.argtypes = [vp, u8p, vp, C.c_uint32, vp]
-    L.qzd_last_inflate_timing.argtypes = [vp, C.POINTER(C.c_float * 2)]
+    L.qzd_last_inflate_timing.argtypes = [vp, C.POINTER(C.c_float * 4)]
     L.qzd_lz4_compress_frames.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
     L.qzd_lz4_decompress_frames.argtypes = [vp, u8p, u8p, vp, C.c_uint32, vp]
     L.qzd_chunk_lens.argtypes = [vp, vp, C.c_uint32]
@@ -190,7 +190,7 @@ class Context:
         return res
 
     def inflate_timing(self):
-        ms = (C.c_float * 2)()
+        ms = (C.c_float * 4)()
         self.L.qzd_last_inflate_timing(self.h, C.byref(ms))
         return list(ms)
 

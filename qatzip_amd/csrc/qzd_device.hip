@@ -124,6 +124,29 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         for (int k = 0; k < 4; k++) hipEventCreate(&c->ev[i][k]);
     }
     hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
+    {
+        /* K1 residency (measured): a batch that fits two single-wave workgroups per CU runs the
+         * prev-in-LDS variant (lowest latency per chunk); anything larger runs QZD_K1_HBM_PER_CU workgroups per CU of
+         * the prev-in-HBM variant, which trades per-wave latency for six times the waves in flight.
+         * QATZIP_AMD_K1_WGS="<lds>,<hbm>" forces a fixed mix of the two (they share one chunk counter). */
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return QZD_ERR_HIP;
+        const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+        c->k1_wgs_lds = 2 * cus; c->k1_wgs_hbm = QZD_K1_HBM_PER_CU * cus; c->k1_fixed_mix = 0;
+        const char *e = getenv("QATZIP_AMD_K1_WGS");
+        unsigned a = 0, b = 0;
+        if (e && sscanf(e, "%u,%u", &a, &b) == 2 && a + b > 0 && a <= 65536 && b <= 65536) {
+            c->k1_wgs_lds = a; c->k1_wgs_hbm = b; c->k1_fixed_mix = 1;
+        }
+        if (hipStreamCreateWithFlags(&c->st_k1b, hipStreamNonBlocking) != hipSuccess) return QZD_ERR_HIP;
+        for (int i = 0; i < QZD_NBUF; i++) {
+            hipEventCreateWithFlags(&c->k1go[i], hipEventDisableTiming);
+            hipEventCreateWithFlags(&c->k1bdone[i], hipEventDisableTiming);
+        }
+        if (hipMalloc(&c->k1_head, (size_t)(c->k1_wgs_lds + c->k1_wgs_hbm) * QZK_HSIZE * 2) != hipSuccess ||
+            hipMalloc(&c->k1_prev, (size_t)(c->k1_wgs_hbm ? c->k1_wgs_hbm : 1) * QZK_WSIZE * 2) != hipSuccess ||
+            hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) return QZD_ERR_HIP;
+    }
     if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) return QZD_ERR_HIP;
     hipHostMalloc((void **)&c->h_running, 8, hipHostMallocDefault);
     hipHostMalloc((void **)&c->h_overflow, 4, hipHostMallocDefault);
@@ -138,11 +161,13 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     hipDeviceSynchronize();
     for (int i = 0; i < QZD_NBUF; i++) {
         hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
-        if (c->head[i]) hipFree(c->head[i]);
         hipStreamDestroy(c->st[i]); hipEventDestroy(c->done[i]); hipEventDestroy(c->k1done[i]);
+        hipEventDestroy(c->k1go[i]); hipEventDestroy(c->k1bdone[i]);
         for (int k = 0; k < 4; k++) hipEventDestroy(c->ev[i][k]);
     }
     hipEventDestroy(c->ev_begin); hipEventDestroy(c->ev_end);
+    hipStreamDestroy(c->st_k1b);
+    hipFree(c->k1_head); hipFree(c->k1_prev); hipFree(c->k1_counter);
     hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
     hipHostFree(c->h_running); hipHostFree(c->h_overflow);
     if (c->d_aux) hipFree(c->d_aux);
@@ -197,9 +222,6 @@ static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
             HIPCHK(c, hipMalloc(&c->sym_dist[i], sym * 2));
             HIPCHK(c, hipMalloc(&c->slots[i], slot));
             HIPCHK(c, hipMalloc(&c->meta[i], (size_t)batch * sizeof(qzk_lzmeta)));
-            if (c->head[i]) hipFree(c->head[i]);
-            c->head[i] = NULL;
-            HIPCHK(c, hipMalloc(&c->head[i], (size_t)batch * QZK_HSIZE * sizeof(uint16_t)));
         }
         c->sym_cap = sym; c->slot_cap = slot; c->meta_cap = batch;
     }
@@ -313,12 +335,31 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
         const uint32_t final_chunk = (last && b + bn == nchunks) ? bn - 1 : ~0u;
         hipStream_t st = c->st[s];
         const bool timed = k < QZD_NBUF;     /* events of the first use of each buffer set */
-        /* K1 already fills every CU's LDS (two workgroups each): two K1 launches side by side would only take turns,
-         * so K1 of batch k starts when K1 of batch k-1 is done; what overlaps with it is K2/scan/gather of batch k-1 */
+        /* K1 already fills every CU's LDS: two K1 batches side by side would only take turns, and they share the
+         * per-workgroup table slices, so K1 of batch k starts when K1 of batch k-1 is done; what overlaps with it
+         * is K2/scan/gather of batch k-1.  Both variants pull chunk numbers from counter[s]. */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->k1done[so], 0));
+        uint32_t wg_lds, wg_hbm;
+        if (c->k1_fixed_mix) {
+            wg_lds = bn < c->k1_wgs_lds ? bn : c->k1_wgs_lds;
+            wg_hbm = bn - wg_lds < c->k1_wgs_hbm ? bn - wg_lds : c->k1_wgs_hbm;
+        } else if (bn <= c->k1_wgs_lds) { wg_lds = bn; wg_hbm = 0; }
+        else { wg_lds = 0; wg_hbm = bn < c->k1_wgs_hbm ? bn : c->k1_wgs_hbm; }
+        HIPCHK(c, hipMemsetAsync(c->k1_counter + s, 0, 4, st));
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
-        hipLaunchKernelGGL(qzk_lz77_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn,
-                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->head[s]);
+        if (wg_hbm) {
+            HIPCHK(c, hipEventRecord(c->k1go[s], st));
+            HIPCHK(c, hipStreamWaitEvent(c->st_k1b, c->k1go[s], 0));
+            hipLaunchKernelGGL(qzk_lz77_pull_kernel<false>, dim3(wg_hbm), dim3(64), 0, c->st_k1b, d_src + boff, blen,
+                               chunk_sz, bn, c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_head, c->k1_prev,
+                               c->k1_wgs_lds, c->k1_counter + s);
+            HIPCHK(c, hipEventRecord(c->k1bdone[s], c->st_k1b));
+        }
+        if (wg_lds)
+            hipLaunchKernelGGL(qzk_lz77_pull_kernel<true>, dim3(wg_lds), dim3(64), 0, st, d_src + boff, blen, chunk_sz,
+                               bn, c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_head, c->k1_prev, 0u,
+                               c->k1_counter + s);
+        if (wg_hbm) HIPCHK(c, hipStreamWaitEvent(st, c->k1bdone[s], 0));
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
         hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn,

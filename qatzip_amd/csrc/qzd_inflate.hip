@@ -32,6 +32,7 @@
 /* a lane needs ~60 ms per 64 KB segment whatever the segment count, the wave kernel does ~300 segments/ms
  * (bound by the CUs' scalar units): lanes win from ~18 000 segments on (measured) */
 #define QZD_LANE_MIN_SEGS 20000u
+#define QZD_LANE_SEGS_PER_WAVE 16u
 
 /* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF */
 __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list, uint32_t cap, uint32_t *count)
@@ -63,17 +64,48 @@ extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *
      * kernel is bound by the CU's scalar unit, K3b spreads the serial work over the vector lanes) */
     const char *force = getenv("QATZIP_AMD_INFLATE");
     const bool lanes = force ? force[0] == 'l' : nsegs >= QZD_LANE_MIN_SEGS;
+    std::vector<qzk_tokseg> tsv;                /* outlives the stream sync below: its async upload reads it */
     if (lanes) {
-        const size_t tb = (size_t)nsegs * sizeof(qzk_inf_tab);
-        if (tb > c->big_cap) {
+        /* two phases (qzk_inflate_lane.h): A decodes into per-segment literal streams + sequence records, B resolves */
+        const qzk_infseg *hs = (const qzk_infseg *)h_segs;
+        tsv.resize(nsegs);
+        uint64_t lit_total = 0, seq_total = 0;
+        for (uint32_t i = 0; i < nsegs; i++) {
+            tsv[i].lit_off = lit_total; tsv[i].seq_off = seq_total;
+            if (!(hs[i].flags & QZK_INF_COUNT_ONLY)) { lit_total += QZK_TOK_LITCAP(hs[i].out_cap); seq_total += QZK_TOK_SEQCAP(hs[i].out_cap); }
+        }
+        const size_t tabb = ((size_t)nsegs * sizeof(qzk_inf_tab) + 255) & ~(size_t)255;
+        const size_t tsb = ((size_t)nsegs * sizeof(qzk_tokseg) + 255) & ~(size_t)255;
+        const size_t nsb = ((size_t)nsegs * 4 + 255) & ~(size_t)255;
+        const size_t litb = (lit_total + 255) & ~(uint64_t)255, seqb = seq_total * sizeof(qzk_seq);
+        const size_t need = tabb + tsb + nsb + litb + seqb + 256;
+        if (need > c->big_cap) {
             hipDeviceSynchronize();
             if (c->d_big) hipFree(c->d_big);
             c->d_big = NULL; c->big_cap = 0;
-            HIPCHK(c, hipMalloc(&c->d_big, tb));
-            c->big_cap = tb;
+            HIPCHK(c, hipMalloc(&c->d_big, need));
+            c->big_cap = need;
         }
-        hipLaunchKernelGGL(qzk_inflate_lane_kernel, dim3((nsegs + 63) / 64), dim3(64), 0, st, d_comp, d_out, d_segs, d_res,
-                           nsegs, (qzk_inf_tab *)c->d_big);
+        uint8_t *pb = c->d_big;
+        qzk_inf_tab *tb_d = (qzk_inf_tab *)pb; pb += tabb;
+        qzk_tokseg *ts_d = (qzk_tokseg *)pb; pb += tsb;
+        uint32_t *ns_d = (uint32_t *)pb; pb += nsb;
+        uint8_t *lit_d = pb; pb += litb;
+        qzk_seq *seq_d = (qzk_seq *)pb;
+        HIPCHK(c, hipMemcpyAsync(ts_d, tsv.data(), (size_t)nsegs * sizeof(qzk_tokseg), hipMemcpyHostToDevice, st));
+        /* segments per single-wave workgroup of phase A: each lane keeps 1.25 KiB of root tables in LDS, and partly
+         * filled waves give the serial decode loops more waves to hide behind (measured in DESIGN.md §K3b) */
+        uint32_t lpw = QZD_LANE_SEGS_PER_WAVE;
+        const char *le = getenv("QATZIP_AMD_INFLATE_LPW");
+        if (le) { int v = atoi(le); if (v == 8 || v == 16 || v == 32 || v == 64) lpw = (uint32_t)v; }
+        const dim3 grid((nsegs + lpw - 1) / lpw), blk(lpw);
+#define QZD_TOK_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_tok_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
+                                            ts_d, lit_d, seq_d, ns_d)
+        if (lpw == 8) QZD_TOK_LAUNCH(8); else if (lpw == 32) QZD_TOK_LAUNCH(32); else if (lpw == 64) QZD_TOK_LAUNCH(64); else QZD_TOK_LAUNCH(16);
+#undef QZD_TOK_LAUNCH
+        HIPCHK(c, hipEventRecord(c->ev[1][0], st));
+        hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
+                           d_out, d_segs, d_res, nsegs, ts_d, lit_d, seq_d, ns_d);
     } else
     hipLaunchKernelGGL(qzk_inflate_kernel, dim3((nsegs + QZK_INF_WAVES - 1) / QZK_INF_WAVES), dim3(64 * QZK_INF_WAVES),
                        0, st, d_comp, d_out, d_segs, d_res, nsegs);
@@ -83,6 +115,7 @@ extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *
     HIPCHK(c, hipGetLastError());
     float t = 0;
     if (hipEventElapsedTime(&t, c->ev[0][0], c->ev[0][1]) == hipSuccess) c->inf_ms[0] += t;
+    if (lanes && hipEventElapsedTime(&t, c->ev[1][0], c->ev[0][1]) == hipSuccess) c->inf_ms[2] += t;   /* phase B share */
     return QZD_OK;
 }
 
@@ -183,7 +216,7 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
     if (!c || !d_src || !h_in_used || !h_out_len) return QZD_ERR_PARAM;
     if (n == 0 || n > 0xffffffffull) return QZD_ERR_PARAM;
     hipSetDevice(c->device);
-    c->inf_ms[0] = c->inf_ms[1] = 0;
+    c->inf_ms[0] = c->inf_ms[1] = c->inf_ms[2] = 0;
     *h_in_used = 0; *h_out_len = 0;
     std::vector<uint32_t> mk;
     int rc = find_markers(c, d_src, n, mk);
@@ -272,9 +305,9 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
     return QZD_OK;
 }
 
-extern "C" int qzd_last_inflate_timing(qzd_ctx *c, float ms[2])
+extern "C" int qzd_last_inflate_timing(qzd_ctx *c, float ms[4])
 {
     if (!c || !ms) return QZD_ERR_PARAM;
-    ms[0] = c->inf_ms[0]; ms[1] = c->inf_ms[1];
+    ms[0] = c->inf_ms[0]; ms[1] = c->inf_ms[1]; ms[2] = c->inf_ms[2]; ms[3] = 0;
     return QZD_OK;
 }

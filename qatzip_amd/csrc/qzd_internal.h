@@ -9,6 +9,7 @@
 
 #define QZD_BATCH 8192u
 #define QZD_NBUF 2
+#define QZD_K1_HBM_PER_CU 12u
 
 struct qzd_ctx {
     int device;
@@ -17,7 +18,11 @@ struct qzd_ctx {
     /* scratch per buffer set */
     uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];
     qzk_lzmeta *meta[QZD_NBUF];
-    uint16_t *head[QZD_NBUF];                       /* K1's zlib head[] tables, 128 KiB per chunk of a batch */
+    /* K1 (persistent pull kernels): table slices per resident workgroup, one chunk counter per buffer set */
+    hipStream_t st_k1b; hipEvent_t k1go[QZD_NBUF], k1bdone[QZD_NBUF];
+    uint16_t *k1_head, *k1_prev; uint32_t *k1_counter;
+    uint32_t k1_wgs_lds, k1_wgs_hbm;                /* workgroups of the prev-in-LDS / prev-in-HBM variant */
+    int k1_fixed_mix;                               /* QATZIP_AMD_K1_WGS given: always launch that mix */
     size_t sym_cap, slot_cap; uint32_t meta_cap;
     /* per-call arrays */
     uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;

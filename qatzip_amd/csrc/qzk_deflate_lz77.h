@@ -38,7 +38,7 @@
 #define QZK_NICE 8
 #define QZK_MAXINS 4
 #define QZK_HSIZE 65536            /* zlib hash_bits 16 at memLevel 9 */
-#define QZK_NSLOT 1024
+#define QZK_NSLOT 512
 
 #if defined(QZK_PROF) && !defined(QZ_SIM)
 #define QZK_T(k) do { uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; } while (0)
@@ -86,25 +86,27 @@ QZ_DEV int qzk_wave_matchlen(const uint8_t *src, uint64_t src_len, uint64_t a, u
     return maxlen;
 }
 
-QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
-                          uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint16_t *head_all)
+/* One chunk, one wave.  PL selects where zlib's prev[] lives: true = this workgroup's LDS (64 KiB, two such
+ * workgroups fit a CU), false = a per-workgroup slice of HBM/L2 (4 KiB of LDS left, so several more of these
+ * fit beside the LDS ones and hide each other's latency).  head[] is always a per-workgroup 128 KiB slice. */
+template <bool PL>
+QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t chunk,
+                           uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint16_t *head, uint16_t *prev_g)
 {
-    QZ_LDS uint16_t prevt[QZK_WSIZE];      /* [pos & 32767] = distance to the previous inserted position with the same hash (0 = none) */
+    QZ_LDS uint16_t prev_l[PL ? QZK_WSIZE : 2];  /* [pos & 32767] = distance to the previous inserted position with the same hash (0 = none) */
     QZ_LDS uint32_t slot[QZK_NSLOT];       /* per-window: min(lane<<16 | hash) over the lanes on a hash key */
     QZ_LDS uint32_t scnt[QZK_NSLOT];       /* per-window: number of lanes on the key */
+#define QZK_PREV(i) (*(PL ? &prev_l[(i) & (PL ? QZK_WSIZE - 1 : 1)] : &prev_g[(i)]))
 
     const int lane = qz_lane();
-    const uint32_t chunk = blockIdx.x;
-    if (chunk >= nchunks) return;
     const uint64_t coff = (uint64_t)chunk * chunk_sz;
     const uint32_t n = (uint32_t)((src_len - coff) < chunk_sz ? (src_len - coff) : chunk_sz);
     uint8_t *olc = sym_lc + coff;
     uint16_t *odist = sym_dist + coff;
     qzk_lzmeta *mt = meta + chunk;
-    /* zlib's head[]: 16-bit hash -> last inserted window position (0 = NIL).  It lives in HBM/L2 (128 KiB per
-     * chunk, one gather + one scatter per window); prev[] stays in LDS.  72 KiB of LDS => two chunks per CU. */
-    uint16_t *head = head_all + (uint64_t)chunk * QZK_HSIZE;
 
+    /* zlib's head[]: 16-bit hash -> last inserted window position (0 = NIL); one gather + one scatter per window */
+    qz_wave_sync();
     for (int i = lane; i < QZK_HSIZE / 4; i += 64) ((uint64_t *)head)[i] = 0;
     qz_wave_sync();
 
@@ -113,7 +115,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
     uint32_t avail_in = n - fill;
     uint32_t pos = 0;                               /* next parse point (chunk offset) */
     uint32_t nsym = 0, nfull = 0, cur_bstart = 0, can_store = 0;
-    if (lane == 0) mt->bstart[0] = 0;
+    mt->bstart[0] = 0;                              /* wave-uniform values: every lane stores the same word */
 #if defined(QZK_PROF) && !defined(QZ_SIM)
     uint64_t prof[16] = {0}; uint64_t tprev = __builtin_readcyclecounter();
 #endif
@@ -188,15 +190,15 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
             const bool ok0 = canh && q0 != 0 && (int)p - q0 <= QZK_MAXDIST;
             c0 = ok0 ? q0 : (int)p;
             QZK_LDC(0, c0);
-            int d = prevt[c0 & (QZK_WSIZE - 1)], q = c0 - d;
+            int d = QZK_PREV(c0 & (QZK_WSIZE - 1)), q = c0 - d;
             const bool ok1 = ok0 && d != 0 && q > lo;
             c1 = ok1 ? q : (int)p;
             QZK_LDC(1, c1);
-            d = prevt[c1 & (QZK_WSIZE - 1)]; q = c1 - d;
+            d = QZK_PREV(c1 & (QZK_WSIZE - 1)); q = c1 - d;
             const bool ok2 = ok1 && d != 0 && q > lo;
             c2 = ok2 ? q : (int)p;
             QZK_LDC(2, c2);
-            d = prevt[c2 & (QZK_WSIZE - 1)]; q = c2 - d;
+            d = QZK_PREV(c2 & (QZK_WSIZE - 1)); q = c2 - d;
             const bool ok3 = ok2 && d != 0 && q > lo;
             c3 = ok3 ? q : (int)p;
             QZK_LDC(3, c3);
@@ -368,7 +370,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
                 if (cur_bstart >= base) can_store |= 1u << nfull;
                 nfull++;
                 cur_bstart = nb;
-                if (lane == 0 && nfull < QZK_MAXBLK) mt->bstart[nfull] = nb;
+                if (nfull < QZK_MAXBLK) mt->bstart[nfull] = nb;
             }
         }
         nsym += (uint32_t)qz_popc64(Pm);
@@ -377,7 +379,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         /* clean inserted lanes: link to the table head seen at window start */
         if (isI && !suspect) {
             uint32_t d = (q0 != 0 && p - (uint32_t)q0 <= 32767u) ? p - (uint32_t)q0 : 0;
-            prevt[p & (QZK_WSIZE - 1)] = (uint16_t)d;
+            QZK_PREV(p & (QZK_WSIZE - 1)) = (uint16_t)d;
             head[bucket] = (uint16_t)p;
         }
         qz_lds_sync();
@@ -396,7 +398,7 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
                     d = (q0j != 0 && pj - q0j <= 32767u) ? pj - q0j : 0;
                 }
                 if (lane == j) {
-                    prevt[p & (QZK_WSIZE - 1)] = (uint16_t)d;
+                    QZK_PREV(p & (QZK_WSIZE - 1)) = (uint16_t)d;
                     head[bucket] = (uint16_t)p;
                 }
             }
@@ -408,11 +410,32 @@ QZ_KERNEL qzk_lz77_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
 
     /* zlib's final loop top (lookahead == 0) may still slide before the last flush */
     if (cur_bstart >= base) can_store |= 1u << nfull;
-    if (lane == 0) {
-        mt->nsym = nsym; mt->nfull = nfull; mt->can_store = can_store; mt->n = n;
+    mt->nsym = nsym; mt->nfull = nfull; mt->can_store = can_store; mt->n = n;      /* uniform, all lanes */
 #if defined(QZK_PROF) && !defined(QZ_SIM)
-        for (int k = 0; k < 16; k++) mt->prof[k] = prof[k];
+    for (int k = 0; k < 16; k++) mt->prof[k] = prof[k];
 #endif
+#undef QZK_PREV
+}
+
+/* K1 launch shape: persistent single-wave workgroups pull chunk numbers from one counter shared by the two
+ * variants (launched side by side on two streams), so the table slices are per resident workgroup - they stay
+ * warm in L2/MALL - and uneven chunks balance themselves.  head_slots: (slot_base + blockIdx.x) * 128 KiB;
+ * prev_slots (HBM variant only): blockIdx.x * 64 KiB. */
+template <bool PL>
+QZ_KERNEL qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
+                               uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint16_t *head_slots,
+                               uint16_t *prev_slots, uint32_t slot_base, uint32_t *counter)
+{
+    uint16_t *head = head_slots + (uint64_t)(slot_base + blockIdx.x) * QZK_HSIZE;
+    uint16_t *prev_g = PL ? (uint16_t *)0 : prev_slots + (uint64_t)blockIdx.x * QZK_WSIZE;
+    for (;;) {
+        /* no `if (lane == 0)` anywhere on this loop's path: the compiler threads lane-0-only blocks of consecutive
+         * iterations together, after which the other 63 lanes would run readfirstlane without lane 0 (seen on
+         * gfx950: the wave re-parses chunk 0 forever).  Every lane takes part; only lane 0 adds. */
+        uint32_t chunk = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);
+        chunk = qz_readfirstlane(chunk);
+        if (chunk >= nchunks) break;
+        qzk_lz77_chunk<PL>(src, src_len, chunk_sz, chunk, sym_lc, sym_dist, meta, head, prev_g);
     }
 }
 

@@ -1,29 +1,40 @@
 /*
- * qzk_inflate_lane.h — K3b: raw inflate with ONE SEGMENT PER LANE, gfx950.
+ * qzk_inflate_lane.h — K3b: raw inflate of many segments in TWO PHASES, gfx950.
  *
  * Same contract as qzk_inflate_kernel (qzk_inflate.h: segment records, status codes,
- * count-only / through-flush flags) and the same place in the reference
- * (zlib inflate(), src/qatzip_sw.c:339), but the opposite mapping: Huffman decoding
- * is bit-serial, and a 2 GiB call is 32 768 independent segments, so every LANE
- * decodes its own segment (64 segments per wave, no cross-lane traffic, no LDS).
- * The wave-per-segment kernel is bound by the CU's single scalar unit; this one
- * spreads the same serial work over the vector lanes and wins as soon as a call has
- * thousands of segments (the host picks the kernel by segment count).
+ * count-only / through-flush flags) and the same place in the reference (zlib
+ * inflate(), src/qatzip_sw.c:339), laid out for a call that holds thousands of
+ * independent segments (a 2 GiB call = 32 768 chunks):
  *
- * Per lane: a 64-bit bit buffer refilled with 4-byte loads from its own stream,
- * decode tables in a per-segment HBM scratch record (11-bit / 9-bit root tables +
- * canonical ranges, 6.3 KiB, L2/Infinity-Cache resident), output bytes to its own
- * region.  Divergence is bounded by a small state machine: per loop trip a lane
- * either parses a block header, decodes one symbol, or copies <= 8 bytes of its
- * pending match / stored run, so a long copy in one lane does not stall the others.
+ *   phase A  qzk_inflate_tok_kernel   ONE SEGMENT PER LANE.  Huffman decoding is
+ *            bit-serial, so every lane decodes its own segment - but only decodes:
+ *            literals go to a per-segment literal stream, matches become 8-byte
+ *            sequence records (literal run, length, distance).  No match copies,
+ *            no reads of its own output, one hot state (symbol decode) => short,
+ *            barely divergent loop.  Root tables (9-bit literal/length, 7-bit
+ *            distance) sit in LDS, 1.25 KiB per lane; the canonical ranges for the
+ *            rare longer codes stay in a per-segment HBM record.
+ *   phase B  qzk_lz_resolve_kernel    ONE SEGMENT PER WAVE.  64 sequences at a time:
+ *            wave prefix sums give every sequence its output offset, the literals
+ *            of the batch are scattered cooperatively (one byte per lane per step),
+ *            then the matches are copied by their lanes in dependency order (a match
+ *            is ready when its source lies below the first unfinished match).
+ *
+ * The single-phase ancestor of this file decoded AND copied in the lane: 6.6 M wave
+ * instructions per 64 KiB segment, 47 % of the wave's time parked on its own
+ * store->load round trips (profiles/).
  */
 #ifndef QZK_INFLATE_LANE_H
 #define QZK_INFLATE_LANE_H
 #include "qzk_inflate.h"
 
+/* root tables (the per-symbol lookups) live in LDS; the canonical ranges for longer codes and the code lengths
+ * stay in a per-segment HBM record */
+#define QZK_LLROOT 9
+#define QZK_LDROOT 7
+#define QZK_LANE_ROOTSZ ((1 << QZK_LLROOT) + (1 << QZK_LDROOT))
+
 typedef struct {
-    uint16_t lroot[1 << QZK_LROOT];
-    uint16_t droot[1 << QZK_DROOT];
     uint16_t lsorted[288], dsorted[32];
     uint16_t lcount[16], lfirst[16], lindex[16];
     uint16_t dcount[16], dfirst[16], dindex[16];
@@ -63,13 +74,26 @@ QZ_DEV int qzk_lane_build(const uint8_t *lens, int n, uint16_t *root, int rootbi
     return left > 0 ? 1 : 0;
 }
 
-typedef struct { const uint8_t *p; uint32_t pos, end; uint64_t bb; int bc; } qzk_lbits;
+/* per-lane bit reader.  The next input word is always already in flight (pw): a refill consumes it and issues the
+ * load for the one after, so the load's latency is hidden behind the symbols decoded in between - and, vector
+ * memory operations completing in order, it is issued ahead of this trip's stores instead of queueing behind them */
+typedef struct { const uint8_t *p; uint32_t pos, end; uint64_t bb; int bc; uint32_t pw; bool pv; } qzk_lbits;
+
+QZ_DEV void qzk_lseek(qzk_lbits *b, uint32_t pos)
+{
+    b->pos = pos; b->bb = 0; b->bc = 0;
+    b->pv = pos + 4 <= b->end;
+    b->pw = b->pv ? qz_ld32(b->p + pos) : 0;
+}
 
 QZ_DEV void qzk_lrefill(qzk_lbits *b)
 {
     if (b->bc <= 32) {
-        if (b->pos + 4 <= b->end) { b->bb |= (uint64_t)qz_ld32(b->p + b->pos) << b->bc; b->pos += 4; b->bc += 32; }
-        else while (b->bc <= 56 && b->pos < b->end) { b->bb |= (uint64_t)b->p[b->pos++] << b->bc; b->bc += 8; }
+        if (b->pv) {
+            b->bb |= (uint64_t)b->pw << b->bc; b->pos += 4; b->bc += 32;
+            b->pv = b->pos + 4 <= b->end;
+            if (b->pv) b->pw = qz_ld32(b->p + b->pos);
+        } else while (b->bc <= 56 && b->pos < b->end) { b->bb |= (uint64_t)b->p[b->pos++] << b->bc; b->bc += 8; }
     }
 }
 
@@ -94,195 +118,409 @@ QZ_DEV int qzk_ldecode(qzk_lbits *b, const uint16_t *root, int rootbits, const u
     return -1;
 }
 
-/* per-lane output staging: bytes are collected in a 64-bit register and leave as one 8-byte store, so a lane
- * issues one memory request per 8 output bytes instead of one per byte */
 typedef struct __attribute__((packed, aligned(1))) { uint64_t v; } qz_u64u;
-typedef struct { uint8_t *o; uint32_t opf, on, cap; uint64_t buf; } qzk_lout;
+QZ_DEV uint64_t qzk_ld64u(const uint8_t *p) { return ((const qz_u64u *)p)->v; }
+QZ_DEV void qzk_st64u(uint8_t *p, uint64_t v) { ((qz_u64u *)p)->v = v; }
 
-/* make everything appended so far visible in memory (a match is about to read it back) */
-QZ_DEV void qzk_lout_sync(qzk_lout *w)
+/* phase A -> phase B hand-over, per segment: literal bytes + sequence records */
+typedef struct { uint32_t litrun; uint16_t mlen; uint16_t dm1; } qzk_seq;      /* mlen 0: literals only (tail) */
+typedef struct { uint64_t lit_off; uint64_t seq_off; } qzk_tokseg;             /* bytes into lits / records into seqs */
+/* scratch a segment needs: literals <= out_cap (+ staging slack), sequences <= out_cap / 3 (+ tail) */
+#define QZK_TOK_LITCAP(out_cap) ((((uint64_t)(out_cap) + 31) & ~(uint64_t)31) + 32)
+#define QZK_TOK_SEQCAP(out_cap) ((uint64_t)(out_cap) / 3 + 2)
+
+enum { QZK_LS_HDR = 0, QZK_LS_SYM, QZK_LS_RAW, QZK_LS_DONE };
+
+/* slow half of a symbol decode: the root entry was empty (code longer than the root) */
+QZ_DEV int qzk_ldecode_long(qzk_lbits *b, int rootbits, const uint16_t *sorted, const uint16_t *count,
+                            const uint16_t *first, const uint16_t *index, int maxlen)
 {
-    if (!w->on) return;
-    if (w->opf + 8 <= w->cap) ((qz_u64u *)(w->o + w->opf))->v = w->buf;      /* bytes beyond `on` get rewritten later */
-    else for (uint32_t i = 0; i < w->on; i++) w->o[w->opf + i] = (uint8_t)(w->buf >> (8 * i));
+    uint32_t code = qzk_rev((uint32_t)b->bb & ((1u << rootbits) - 1), rootbits);
+    uint64_t bits = b->bb >> rootbits;
+    int sym = -1;
+    for (int l = rootbits + 1; l <= maxlen && sym < 0 && l <= b->bc; l++) {
+        code = (code << 1) | (uint32_t)(bits & 1); bits >>= 1;
+        const uint32_t c = count[l], f = first[l];
+        if (c && code >= f && code - f < c) { QZK_DROP(b, l); sym = sorted[index[l] + code - f]; }
+    }
+    return sym;
+}
+
+/* per-lane decode state that the cold paths (block header, stored run) share with the kernel */
+typedef struct {
+    qzk_lbits b;
+    uint32_t op, nblocks, last, clen, rpos, out_cap;
+    int lmax, dmax, status, state;
+    bool through;
+} qzk_lane_st;
+
+/* one block header: stored -> RAW (or the end of the segment), fixed / dynamic -> tables built, SYM */
+QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uint16_t *droot)
+{
+    qzk_lbits *b = &S->b;
+    S->state = QZK_LS_DONE; S->status = QZK_INF_EDATA;       /* every early return below is a failure */
+    qzk_lrefill(b);
+    if (b->bc < 3) { S->status = QZK_INF_EIN; return; }
+    S->last = QZK_GETBITS(b, 1); QZK_DROP(b, 1);
+    const uint32_t type = QZK_GETBITS(b, 2); QZK_DROP(b, 2);
+    S->nblocks++;
+    if (type == 0) {
+        QZK_DROP(b, b->bc & 7);
+        qzk_lrefill(b);
+        if (b->bc < 32) { S->status = QZK_INF_EIN; return; }
+        const uint32_t len = QZK_GETBITS(b, 16); QZK_DROP(b, 16);
+        const uint32_t nlen = QZK_GETBITS(b, 16); QZK_DROP(b, 16);
+        if ((len ^ 0xffff) != nlen) return;
+        const uint32_t ipos = b->pos - (uint32_t)(b->bc >> 3);
+        if (ipos + len > b->end) { S->status = QZK_INF_EIN; return; }
+        qzk_lseek(b, ipos + len);
+        if (S->op + len > S->out_cap) { S->status = QZK_INF_EOUT; return; }
+        if (len == 0) {
+            if (S->last) S->status = QZK_INF_FINAL;
+            else if (!S->through) S->status = QZK_INF_FLUSH;
+            else S->state = QZK_LS_HDR;
+            return;
+        }
+        S->clen = len; S->rpos = ipos; S->state = QZK_LS_RAW;
+        return;
+    }
+    if (type == 3) return;
+    if (type == 1) {
+        for (int i = 0; i < 288; i++) T->lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+        qzk_lane_build(T->lens, 288, lroot, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &S->lmax);
+        for (int i = 0; i < 30; i++) T->lens[i] = 5;
+        qzk_lane_build(T->lens, 30, droot, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &S->dmax);
+        S->state = QZK_LS_SYM;
+        return;
+    }
+    qzk_lrefill(b);
+    if (b->bc < 14) { S->status = QZK_INF_EIN; return; }
+    const uint32_t nlen = QZK_GETBITS(b, 5) + 257; QZK_DROP(b, 5);
+    const uint32_t ndist = QZK_GETBITS(b, 5) + 1; QZK_DROP(b, 5);
+    const uint32_t ncode = QZK_GETBITS(b, 4) + 4; QZK_DROP(b, 4);
+    if (nlen > 286 || ndist > 30) return;
+    for (int i = 0; i < 19; i++) T->lens[i] = 0;
+    for (uint32_t i = 0; i < ncode; i++) {
+        qzk_lrefill(b);
+        if (b->bc < 3) { S->status = QZK_INF_EIN; return; }
+        const uint32_t v = QZK_GETBITS(b, 3); QZK_DROP(b, 3);
+        const uint32_t ord = i < 6 ? ((16u | 17u << 5 | 18u << 10 | 0u << 15 | 8u << 20 | 7u << 25) >> (5 * i)) & 31
+                           : i < 12 ? ((9u | 6u << 5 | 10u << 10 | 5u << 15 | 11u << 20 | 4u << 25) >> (5 * (i - 6))) & 31
+                           : i < 18 ? ((12u | 3u << 5 | 13u << 10 | 2u << 15 | 14u << 20 | 1u << 25) >> (5 * (i - 12))) & 31 : 15u;
+        T->lens[ord] = (uint8_t)v;
+    }
+    int clmax = 0;
+    /* the 7-bit code-length code borrows the distance-table arrays */
+    if (qzk_lane_build(T->lens, 19, droot, 7, T->dsorted, T->dcount, T->dfirst, T->dindex, &clmax) != 0) return;
+    uint32_t i = 0, prev = 0;
+    uint8_t *L = T->lens;               /* final place: [0, nlen) lit/len, [nlen, nlen+ndist) distance */
+    while (i < nlen + ndist) {
+        qzk_lrefill(b);
+        const int sym = qzk_ldecode(b, droot, 7, T->dsorted, T->dcount, T->dfirst, T->dindex, clmax);
+        if (sym < 0) return;
+        if (sym < 16) { L[i++] = (uint8_t)sym; prev = (uint32_t)sym; continue; }
+        uint32_t rep, val;
+        if (sym == 16) { if (i == 0 || b->bc < 2) return; val = prev; rep = 3 + QZK_GETBITS(b, 2); QZK_DROP(b, 2); }
+        else if (sym == 17) { if (b->bc < 3) return; val = 0; rep = 3 + QZK_GETBITS(b, 3); QZK_DROP(b, 3); }
+        else { if (b->bc < 7) return; val = 0; rep = 11 + QZK_GETBITS(b, 7); QZK_DROP(b, 7); }
+        if (i + rep > nlen + ndist) return;
+        for (uint32_t k = 0; k < rep; k++) L[i + k] = (uint8_t)val;
+        prev = val; i += rep;
+    }
+    if (L[256] == 0) return;
+    int r = qzk_lane_build(L, (int)nlen, lroot, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &S->lmax);
+    if (r < 0 || (r > 0 && S->lmax != 1)) return;
+    r = qzk_lane_build(L + nlen, (int)ndist, droot, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &S->dmax);
+    if (r < 0 || (r > 0 && S->dmax > 1)) return;
+    S->state = QZK_LS_SYM;
+}
+
+/* What phase A writes, per lane.  A lane's next input load queues behind its own outstanding stores (vector memory
+ * completes in order), so stores must be rare: literals leave 32 bytes at a time and sequence records 8 at a time,
+ * staged in registers picked by compare-selects. */
+typedef struct {
+    uint8_t *lp; qzk_seq *sq;
+    uint32_t lrun, nseq;                /* literals since the last sequence, sequences so far */
+    uint32_t lw, ln, lq;                /* literal bytes in HBM, bytes (0..7) in lbuf, words (0..3) in lq0..2 */
+    uint64_t lbuf, lq0, lq1, lq2;
+    uint64_t s0, s1, s2, s3, s4, s5, s6;
+    bool count_only;
+} qzk_tok_out;
+
+QZ_DEV void qzk_tok_word(qzk_tok_out *O, uint64_t w)
+{
+    if (O->lq == 3) {
+        uint64_t *d = (uint64_t *)(O->lp + O->lw);
+        d[0] = O->lq0; d[1] = O->lq1; d[2] = O->lq2; d[3] = w;
+        O->lw += 32; O->lq = 0;
+    } else {
+        O->lq0 = O->lq == 0 ? w : O->lq0; O->lq1 = O->lq == 1 ? w : O->lq1; O->lq2 = O->lq == 2 ? w : O->lq2;
+        O->lq++;
+    }
+}
+QZ_DEV void qzk_tok_byte(qzk_tok_out *O, uint32_t byte)
+{
+    if (!O->count_only) {
+        O->lbuf |= (uint64_t)byte << (8 * O->ln);
+        if (++O->ln == 8) { qzk_tok_word(O, O->lbuf); O->lbuf = 0; O->ln = 0; }
+    }
+    O->lrun++;
 }
 /* append the low k (1..8) bytes of v */
-QZ_DEV void qzk_lout_put(qzk_lout *w, uint64_t v, uint32_t k)
+QZ_DEV void qzk_tok_bytes(qzk_tok_out *O, uint64_t v, uint32_t k)
 {
-    if (k < 8) v &= (1ull << (8 * k)) - 1;
-    w->buf |= v << (8 * w->on);
-    const uint32_t tot = w->on + k;
-    if (tot >= 8) {
-        if (w->opf + 8 <= w->cap) ((qz_u64u *)(w->o + w->opf))->v = w->buf;
-        else for (uint32_t i = 0; i < 8 && w->opf + i < w->cap; i++) w->o[w->opf + i] = (uint8_t)(w->buf >> (8 * i));
-        w->buf = w->on ? v >> (8 * (8 - w->on)) : 0;
-        w->opf += 8; w->on = tot - 8;
-    } else w->on = tot;
+    if (!O->count_only) {
+        if (k < 8) v &= (1ull << (8 * k)) - 1;
+        O->lbuf |= v << (8 * O->ln);
+        if (O->ln + k >= 8) {
+            qzk_tok_word(O, O->lbuf);
+            O->lbuf = O->ln ? v >> (8 * (8 - O->ln)) : 0; O->ln = O->ln + k - 8;
+        } else O->ln += k;
+    }
+    O->lrun += k;
 }
-QZ_DEV uint64_t qzk_ld64u(const uint8_t *p) { return ((const qz_u64u *)p)->v; }
-
-enum { QZK_LS_HDR = 0, QZK_LS_SYM, QZK_LS_COPY, QZK_LS_RAW, QZK_LS_DONE };
-
-QZ_KERNEL qzk_inflate_lane_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res,
-                                  uint32_t nsegs, qzk_inf_tab *tabs)
+QZ_DEV void qzk_tok_seq(qzk_tok_out *O, uint32_t mlen, uint32_t dm1)
 {
-    const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!O->count_only) {
+        const uint64_t w = (uint64_t)O->lrun | (uint64_t)mlen << 32 | (uint64_t)dm1 << 48;
+        const uint32_t k = O->nseq & 7;
+        if (k == 7) {
+            uint64_t *d = (uint64_t *)(O->sq + O->nseq - 7);
+            d[0] = O->s0; d[1] = O->s1; d[2] = O->s2; d[3] = O->s3; d[4] = O->s4; d[5] = O->s5; d[6] = O->s6; d[7] = w;
+        } else {
+            O->s0 = k == 0 ? w : O->s0; O->s1 = k == 1 ? w : O->s1; O->s2 = k == 2 ? w : O->s2; O->s3 = k == 3 ? w : O->s3;
+            O->s4 = k == 4 ? w : O->s4; O->s5 = k == 5 ? w : O->s5; O->s6 = k == 6 ? w : O->s6;
+        }
+    }
+    O->nseq++; O->lrun = 0;
+}
+QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
+{
+    if (O->count_only) return;
+    uint64_t *d = (uint64_t *)(O->lp + O->lw);
+    if (O->lq > 0) d[0] = O->lq0;
+    if (O->lq > 1) d[1] = O->lq1;
+    if (O->lq > 2) d[2] = O->lq2;
+    O->lw += 8 * O->lq;
+    for (uint32_t i = 0; i < O->ln; i++) O->lp[O->lw + i] = (uint8_t)(O->lbuf >> (8 * i));
+    if (O->lrun) qzk_tok_seq(O, 0u, 0u);
+    const uint32_t k = O->nseq & 7;
+    d = (uint64_t *)(O->sq + (O->nseq & ~7u));
+    if (k > 0) d[0] = O->s0;
+    if (k > 1) d[1] = O->s1;
+    if (k > 2) d[2] = O->s2;
+    if (k > 3) d[3] = O->s3;
+    if (k > 4) d[4] = O->s4;
+    if (k > 5) d[5] = O->s5;
+    if (k > 6) d[6] = O->s6;
+}
+
+/* one symbol from an already refilled bit buffer; structured (no early exits) so that it compiles to predicated
+ * straight-line code.  MIDREFILL: the caller's reader guarantees < 48 valid bits, refill before the distance code. */
+template <bool MIDREFILL>
+QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, const uint16_t *lroot,
+                            const uint16_t *droot, uint64_t out_off)
+{
+    qzk_lbits *b = &S->b;
+    const uint32_t e = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
+    int sym;
+    if (e != 0 && (int)(e & 15) <= b->bc) { QZK_DROP(b, e & 15); sym = (int)(e >> 4); }
+    else sym = e ? -1 : qzk_ldecode_long(b, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, S->lmax);
+    if (sym < 256) {
+        if (sym < 0) { S->status = b->pos >= b->end && b->bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA; S->state = QZK_LS_DONE; }
+        else if (S->op >= S->out_cap) { S->status = QZK_INF_EOUT; S->state = QZK_LS_DONE; }
+        else { qzk_tok_byte(O, (uint32_t)sym); S->op++; }
+    } else if (sym == 256) {
+        if (S->last) { S->status = QZK_INF_FINAL; S->state = QZK_LS_DONE; } else S->state = QZK_LS_HDR;
+    } else {
+        sym -= 257;
+        uint32_t xb = (sym < 8 || sym >= 28) ? 0u : (uint32_t)(sym - 4) >> 2;
+        uint32_t len = sym < 8 ? 3u + (uint32_t)sym : sym >= 28 ? 258u : 3u + ((4u + ((uint32_t)sym & 3)) << xb);
+        int err = sym >= 29 ? QZK_INF_EDATA : (int)xb > b->bc ? QZK_INF_EIN : 0;
+        len += QZK_GETBITS(b, xb); QZK_DROP(b, xb);
+        if (MIDREFILL) qzk_lrefill(b);
+        const uint32_t de = droot[(uint32_t)b->bb & ((1u << QZK_LDROOT) - 1)];
+        int ds;
+        if (de != 0 && (int)(de & 15) <= b->bc) { QZK_DROP(b, de & 15); ds = (int)(de >> 4); }
+        else ds = de ? -1 : qzk_ldecode_long(b, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, S->dmax);
+        if (!err && (ds < 0 || ds >= 30)) err = b->pos >= b->end && b->bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA;
+        if (ds < 0 || ds >= 30) ds = 0;
+        xb = ds < 4 ? 0u : (uint32_t)(ds - 2) >> 1;
+        uint32_t dist = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1)) << xb);
+        if (!err && (int)xb > b->bc) err = QZK_INF_EIN;
+        dist += QZK_GETBITS(b, xb); QZK_DROP(b, xb);
+        if (!err && dist > S->op && (!S->through || (uint64_t)dist > out_off + S->op)) err = QZK_INF_EHIST;
+        if (!err && S->op + len > S->out_cap) err = QZK_INF_EOUT;
+        if (err) { S->status = err; S->state = QZK_LS_DONE; }
+        else { qzk_tok_seq(O, len, dist - 1); S->op += len; }
+    }
+}
+
+/* LPW = segments (active lanes) per single-wave workgroup: LPW * 1.25 KiB of LDS (16 -> eight workgroups per CU) */
+template <int LPW>
+QZ_KERNEL qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
+                                 qzk_inf_tab *tabs, const qzk_tokseg *ts, uint8_t *lits, qzk_seq *seqs,
+                                 uint32_t *nseqs)
+{
+    QZ_LDS uint16_t roots[LPW][QZK_LANE_ROOTSZ];
+    const uint32_t sidx = blockIdx.x * LPW + threadIdx.x;
     if (sidx >= nsegs) return;
     const qzk_infseg sg = segs[sidx];
     qzk_inf_tab *T = tabs + sidx;
-    const bool count_only = sg.flags & QZK_INF_COUNT_ONLY, through = sg.flags & QZK_INF_THROUGH_FLUSH;
-    uint8_t *o = out + sg.out_off;
-    qzk_lbits b; b.p = comp + sg.in_off; b.pos = 0; b.end = sg.in_len; b.bb = 0; b.bc = 0;
-    uint32_t op = 0, nblocks = 0, last = 0;
-    uint32_t clen = 0, cdist = 0, rpos = 0;             /* pending copy: length, distance (match) / input position (raw) */
-    int lmax = 0, dmax = 0, status = QZK_INF_EDATA, state = QZK_LS_HDR;
-    qzk_lout w; w.o = o; w.opf = 0; w.on = 0; w.cap = sg.out_cap; w.buf = 0;
+    uint16_t *const lroot = roots[threadIdx.x], *const droot = lroot + (1 << QZK_LLROOT);
+    qzk_lane_st S;
+    S.b.p = comp + sg.in_off; S.b.end = sg.in_len; qzk_lseek(&S.b, 0);
+    S.op = 0; S.nblocks = 0; S.last = 0; S.clen = 0; S.rpos = 0; S.out_cap = sg.out_cap;
+    S.lmax = 0; S.dmax = 0; S.status = QZK_INF_EDATA; S.state = QZK_LS_HDR;
+    S.through = sg.flags & QZK_INF_THROUGH_FLUSH;
+    qzk_tok_out O;
+    O.count_only = sg.flags & QZK_INF_COUNT_ONLY;
+    O.lp = lits; O.sq = seqs;
+    if (!O.count_only) { O.lp += ts[sidx].lit_off; O.sq += ts[sidx].seq_off; }
+    O.lrun = 0; O.nseq = 0; O.lw = 0; O.ln = 0; O.lq = 0; O.lbuf = 0; O.lq0 = O.lq1 = O.lq2 = 0;
+    O.s0 = O.s1 = O.s2 = O.s3 = O.s4 = O.s5 = O.s6 = 0;
 
-    while (state != QZK_LS_DONE) {
-        if (state == QZK_LS_COPY) {
-            /* <= 8 bytes of the pending match; source bytes all precede op (i mod dist), so no intra-step hazard */
-            const uint32_t k = clen < 8 ? clen : 8;
-            if (!count_only) {
-                const uint8_t *s = o + ((int64_t)op - (int64_t)cdist);     /* may reach before o in through mode */
-                uint64_t v;
-                if (cdist >= 8) v = qzk_ld64u(s);
-                else { v = 0; for (uint32_t i = 0; i < k; i++) v |= (uint64_t)s[i % cdist] << (8 * i); }
-                qzk_lout_put(&w, v, k);
-                /* the next step of this copy may read what this one produced */
-                if (cdist < 16) qzk_lout_sync(&w);
+    while (S.state != QZK_LS_DONE) {
+        qzk_lbits *b = &S.b;
+        if (S.state == QZK_LS_SYM && b->pos + 16 <= b->end) {
+            /* ---- the hot loop.  Branch-free refill: the 8 bytes at the read position are always already in flight
+             * (pw), each trip ORs them in above the valid bits, steps over the bytes that fitted and issues the load
+             * for the next trip, whose latency the symbol decode then covers; >= 56 valid bits per trip is a whole
+             * symbol (15 + 5 + 15 + 13).  Bounded so that lanes parked in a cold state get their turn. ---- */
+            b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;     /* hand whole bytes back */
+            uint64_t pw = qzk_ld64u(b->p + b->pos);
+            for (int trip = 0; trip < 256 && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
+                b->bb |= pw << b->bc;
+                b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
+                pw = qzk_ld64u(b->p + b->pos);
+                qzk_lane_symbol<false>(&S, &O, T, lroot, droot, sg.out_off);
             }
-            op += k; clen -= k;
-            if (!clen) state = QZK_LS_SYM;
-            continue;
-        }
-        if (state == QZK_LS_RAW) {
-            const uint32_t k = clen < 8 ? clen : 8;
-            if (!count_only) {
+            b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;
+            const uint32_t keep = (uint32_t)b->bc; const uint64_t low = b->bb;
+            qzk_lseek(b, b->pos);                      /* back to the careful reader: its prefetch word */
+            b->bb = low; b->bc = (int)keep;
+        } else if (S.state == QZK_LS_SYM) {
+            /* last bytes of the input: the careful reader */
+            for (int trip = 0; trip < 64 && S.state == QZK_LS_SYM; trip++) {
+                qzk_lrefill(b);
+                qzk_lane_symbol<true>(&S, &O, T, lroot, droot, sg.out_off);
+            }
+        } else if (S.state == QZK_LS_HDR) qzk_lane_header(&S, T, lroot, droot);
+        else if (S.state == QZK_LS_RAW) {
+            /* stored block: its bytes join the literal stream, <= 8 per trip, <= 512 per visit */
+            for (int trip = 0; trip < 64 && S.clen; trip++) {
+                const uint32_t k = S.clen < 8 ? S.clen : 8;
                 uint64_t v = 0;
-                if (rpos + 8 <= b.end) v = qzk_ld64u(b.p + rpos);
-                else for (uint32_t i = 0; i < k; i++) v |= (uint64_t)b.p[rpos + i] << (8 * i);
-                qzk_lout_put(&w, v, k);
-            }
-            op += k; rpos += k; clen -= k;
-            if (!clen) { if (last) { status = QZK_INF_FINAL; state = QZK_LS_DONE; } else state = QZK_LS_HDR; }
-            continue;
-        }
-        if (state == QZK_LS_HDR) {
-            qzk_lrefill(&b);
-            if (b.bc < 3) { status = QZK_INF_EIN; break; }
-            last = QZK_GETBITS(&b, 1); QZK_DROP(&b, 1);
-            const uint32_t type = QZK_GETBITS(&b, 2); QZK_DROP(&b, 2);
-            nblocks++;
-            if (type == 0) {
-                QZK_DROP(&b, b.bc & 7);
-                qzk_lrefill(&b);
-                if (b.bc < 32) { status = QZK_INF_EIN; break; }
-                const uint32_t len = QZK_GETBITS(&b, 16); QZK_DROP(&b, 16);
-                const uint32_t nlen = QZK_GETBITS(&b, 16); QZK_DROP(&b, 16);
-                if ((len ^ 0xffff) != nlen) { status = QZK_INF_EDATA; break; }
-                const uint32_t ipos = b.pos - (uint32_t)(b.bc >> 3);
-                b.bb = 0; b.bc = 0; b.pos = ipos + len;
-                if (ipos + len > b.end) { status = QZK_INF_EIN; break; }
-                if (op + len > sg.out_cap) { status = QZK_INF_EOUT; break; }
-                if (len == 0) {
-                    if (last) { status = QZK_INF_FINAL; break; }
-                    if (!through) { status = QZK_INF_FLUSH; break; }
-                    continue;
+                if (!O.count_only) {
+                    if (S.rpos + 8 <= b->end) v = qzk_ld64u(b->p + S.rpos);
+                    else for (uint32_t i = 0; i < k; i++) v |= (uint64_t)b->p[S.rpos + i] << (8 * i);
                 }
-                clen = len; rpos = ipos; state = QZK_LS_RAW;
-                continue;
+                qzk_tok_bytes(&O, v, k);
+                S.op += k; S.rpos += k; S.clen -= k;
             }
-            if (type == 3) { status = QZK_INF_EDATA; break; }
-            if (type == 1) {
-                for (int i = 0; i < 288; i++) T->lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-                qzk_lane_build(T->lens, 288, T->lroot, QZK_LROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &lmax);
-                for (int i = 0; i < 30; i++) T->lens[i] = 5;
-                qzk_lane_build(T->lens, 30, T->droot, QZK_DROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &dmax);
-            } else {
-                qzk_lrefill(&b);
-                if (b.bc < 14) { status = QZK_INF_EIN; break; }
-                const uint32_t nlen = QZK_GETBITS(&b, 5) + 257; QZK_DROP(&b, 5);
-                const uint32_t ndist = QZK_GETBITS(&b, 5) + 1; QZK_DROP(&b, 5);
-                const uint32_t ncode = QZK_GETBITS(&b, 4) + 4; QZK_DROP(&b, 4);
-                if (nlen > 286 || ndist > 30) { status = QZK_INF_EDATA; break; }
-                for (int i = 0; i < 19; i++) T->lens[i] = 0;
-                bool bad = false;
-                for (uint32_t i = 0; i < ncode; i++) {
-                    qzk_lrefill(&b);
-                    if (b.bc < 3) { bad = true; break; }
-                    const uint32_t v = QZK_GETBITS(&b, 3); QZK_DROP(&b, 3);
-                    const uint32_t ord = i < 6 ? ((16u | 17u << 5 | 18u << 10 | 0u << 15 | 8u << 20 | 7u << 25) >> (5 * i)) & 31
-                                       : i < 12 ? ((9u | 6u << 5 | 10u << 10 | 5u << 15 | 11u << 20 | 4u << 25) >> (5 * (i - 6))) & 31
-                                       : i < 18 ? ((12u | 3u << 5 | 13u << 10 | 2u << 15 | 14u << 20 | 1u << 25) >> (5 * (i - 12))) & 31 : 15u;
-                    T->lens[ord] = (uint8_t)v;
-                }
-                if (bad) { status = QZK_INF_EIN; break; }
-                int clmax = 0;
-                /* the 7-bit code-length code borrows the distance-table arrays */
-                if (qzk_lane_build(T->lens, 19, T->droot, 7, T->dsorted, T->dcount, T->dfirst, T->dindex, &clmax) != 0) { status = QZK_INF_EDATA; break; }
-                uint32_t i = 0, prev = 0;
-                uint8_t *L = T->lens;               /* final place: [0, nlen) lit/len, [nlen, nlen+ndist) distance */
-                while (i < nlen + ndist) {
-                    qzk_lrefill(&b);
-                    const int sym = qzk_ldecode(&b, T->droot, 7, T->dsorted, T->dcount, T->dfirst, T->dindex, clmax);
-                    if (sym < 0) { bad = true; break; }
-                    if (sym < 16) { L[i++] = (uint8_t)sym; prev = (uint32_t)sym; continue; }
-                    uint32_t rep, val;
-                    if (sym == 16) { if (i == 0 || b.bc < 2) { bad = true; break; } val = prev; rep = 3 + QZK_GETBITS(&b, 2); QZK_DROP(&b, 2); }
-                    else if (sym == 17) { if (b.bc < 3) { bad = true; break; } val = 0; rep = 3 + QZK_GETBITS(&b, 3); QZK_DROP(&b, 3); }
-                    else { if (b.bc < 7) { bad = true; break; } val = 0; rep = 11 + QZK_GETBITS(&b, 7); QZK_DROP(&b, 7); }
-                    if (i + rep > nlen + ndist) { bad = true; break; }
-                    for (uint32_t k = 0; k < rep; k++) L[i + k] = (uint8_t)val;
-                    prev = val; i += rep;
-                }
-                if (bad) { status = QZK_INF_EDATA; break; }
-                if (L[256] == 0) { status = QZK_INF_EDATA; break; }
-                int r = qzk_lane_build(L, (int)nlen, T->lroot, QZK_LROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &lmax);
-                if (r < 0 || (r > 0 && lmax != 1)) { status = QZK_INF_EDATA; break; }
-                r = qzk_lane_build(L + nlen, (int)ndist, T->droot, QZK_DROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &dmax);
-                if (r < 0 || (r > 0 && dmax > 1)) { status = QZK_INF_EDATA; break; }
-            }
-            state = QZK_LS_SYM;
-            continue;
+            if (!S.clen) { if (S.last) { S.status = QZK_INF_FINAL; S.state = QZK_LS_DONE; } else S.state = QZK_LS_HDR; }
         }
-        /* ---- QZK_LS_SYM: one symbol ---- */
-        qzk_lrefill(&b);
-        int sym = qzk_ldecode(&b, T->lroot, QZK_LROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, lmax);
-        if (sym < 0) { status = b.pos >= b.end && b.bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA; break; }
-        if (sym < 256) {
-            if (op >= sg.out_cap) { status = QZK_INF_EOUT; break; }
-            if (!count_only) qzk_lout_put(&w, (uint64_t)sym, 1);
-            op++;
-            continue;
-        }
-        if (sym == 256) {
-            if (last) { status = QZK_INF_FINAL; break; }
-            state = QZK_LS_HDR;
-            continue;
-        }
-        sym -= 257;
-        if (sym >= 29) { status = QZK_INF_EDATA; break; }
-        uint32_t xb = (sym < 8 || sym == 28) ? 0u : (uint32_t)(sym - 4) >> 2;
-        uint32_t len = sym < 8 ? 3u + (uint32_t)sym : sym == 28 ? 258u : 3u + ((4u + ((uint32_t)sym & 3)) << xb);
-        if (xb) { if ((int)xb > b.bc) { status = QZK_INF_EIN; break; } len += QZK_GETBITS(&b, xb); QZK_DROP(&b, xb); }
-        qzk_lrefill(&b);
-        const int ds = qzk_ldecode(&b, T->droot, QZK_DROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, dmax);
-        if (ds < 0 || ds >= 30) { status = b.pos >= b.end && b.bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA; break; }
-        xb = ds < 4 ? 0u : (uint32_t)(ds - 2) >> 1;
-        uint32_t dist = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1)) << xb);
-        if (xb) { if ((int)xb > b.bc) { status = QZK_INF_EIN; break; } dist += QZK_GETBITS(&b, xb); QZK_DROP(&b, xb); }
-        if (dist > op) {
-            if (!through || (uint64_t)dist > sg.out_off + op) { status = QZK_INF_EHIST; break; }
-        }
-        if (op + len > sg.out_cap) { status = QZK_INF_EOUT; break; }
-        clen = len; cdist = dist; state = QZK_LS_COPY;
-        if (!count_only) qzk_lout_sync(&w);            /* the source of the copy may still be in the staging register */
     }
-    if (!count_only) for (uint32_t i = 0; i < w.on; i++) w.o[w.opf + i] = (uint8_t)(w.buf >> (8 * i));
+    qzk_tok_finish(&O);
+    if (!O.count_only) nseqs[sidx] = O.nseq;
     qzk_infres r;
-    r.status = status; r.out_len = op; r.nblocks = nblocks;
-    r.in_used = b.pos - (uint32_t)(b.bc >> 3);
+    r.status = S.status; r.out_len = S.op; r.nblocks = S.nblocks;
+    r.in_used = S.b.pos - (uint32_t)(S.b.bc >> 3);
     res[sidx] = r;
+}
+
+/* ------------------------------------------------------------------ phase B */
+QZ_DEV uint32_t qzk_wave_scan_incl(uint32_t v, int lane)
+{
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = qz_shfl(v, lane - d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+/* copy one match inside the output: len bytes from d - dist to d (the classic overlapping LZ77 copy) */
+QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
+{
+    const uint8_t *s = d - dist;
+    if (dist >= 8) {
+        if (len >= 8) {
+            uint32_t i = 0;
+            for (; i + 8 <= len; i += 8) qzk_st64u(d + i, qzk_ld64u(s + i));
+            if (i < len) qzk_st64u(d + len - 8, qzk_ld64u(s + len - 8));     /* overlapping tail, same bytes again */
+        } else {
+            if (len & 4) { ((qz_u32u *)d)->v = qz_ld32(s); d += 4; s += 4; }
+            if (len & 2) { ((qz_u16u *)d)->v = (uint16_t)qz_ld16(s); d += 2; s += 2; }
+            if (len & 1) *d = *s;
+        }
+        return;
+    }
+    /* period < 8: build 16 bytes of the periodic pattern in registers, then every 8-byte step is a funnel shift */
+    uint64_t P = 0;
+    for (uint32_t i = 0; i < dist; i++) P |= (uint64_t)s[i] << (8 * i);
+    uint64_t q0 = 0, q1 = 0;
+    for (uint32_t t = 0, ph = 0; t < 16; t++) {
+        const uint64_t byte = (P >> (8 * ph)) & 0xff;
+        if (t < 8) q0 |= byte << (8 * t); else q1 |= byte << (8 * (t - 8));
+        if (++ph == dist) ph = 0;
+    }
+    uint32_t ph = 0, i = 0;
+    for (; i + 8 <= len; i += 8) {
+        qzk_st64u(d + i, ph ? (q0 >> (8 * ph)) | (q1 << (64 - 8 * ph)) : q0);
+        ph += 8; while (ph >= dist) ph -= dist;
+    }
+    if (i < len) {
+        const uint64_t v = ph ? (q0 >> (8 * ph)) | (q1 << (64 - 8 * ph)) : q0;
+        for (uint32_t k = 0; i + k < len; k++) d[i + k] = (uint8_t)(v >> (8 * k));
+    }
+}
+
+/* one wave per segment; QZK_RES_WAVES segments per workgroup */
+#define QZK_RES_WAVES 4
+QZ_KERNEL qzk_lz_resolve_kernel(uint8_t *out, const qzk_infseg *segs, const qzk_infres *res, uint32_t nsegs,
+                                const qzk_tokseg *ts, const uint8_t *lits, const qzk_seq *seqs, const uint32_t *nseqs)
+{
+    const int lane = qz_lane();
+    const uint32_t sidx = blockIdx.x * QZK_RES_WAVES + (threadIdx.x >> 6);
+    if (sidx >= nsegs) return;
+    const qzk_infseg sg = segs[sidx];
+    if (res[sidx].status < 0 || (sg.flags & QZK_INF_COUNT_ONLY)) return;
+    uint8_t *o = out + sg.out_off;
+    const uint8_t *lp = lits + ts[sidx].lit_off;
+    const qzk_seq *sq = seqs + ts[sidx].seq_off;
+    const uint32_t ns = nseqs[sidx];
+    uint32_t obase = 0, lbase = 0;                     /* output / literal bytes consumed by earlier batches */
+    for (uint32_t b0 = 0; b0 < ns; b0 += 64) {
+        const uint32_t i = b0 + (uint32_t)lane;
+        uint32_t litrun = 0, mlen = 0, dist = 1;
+        if (i < ns) { const qzk_seq q = sq[i]; litrun = q.litrun; mlen = q.mlen; dist = (uint32_t)q.dm1 + 1; }
+        const uint32_t s_tot = qzk_wave_scan_incl(litrun + mlen, lane), s_lit = qzk_wave_scan_incl(litrun, lane);
+        const uint32_t Tb = qz_readlane(s_tot, 63), Lb = qz_readlane(s_lit, 63);
+        const uint32_t my_o = obase + s_tot - (litrun + mlen);       /* where my literals land */
+        const uint32_t my_l0 = s_lit - litrun;                       /* my first literal, batch-relative */
+        /* literal k of the batch belongs to the first sequence whose inclusive literal count exceeds k */
+        for (uint32_t k0 = 0; k0 < Lb; k0 += 64) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            int j = 0;
+            for (int step = 32; step; step >>= 1) if (qz_shfl(s_lit, j + step - 1) <= k) j += step;
+            const uint32_t oj = qz_shfl(my_o, j), lj = qz_shfl(my_l0, j);
+            if (k < Lb) o[oj + (k - lj)] = lp[lbase + k];
+        }
+        qz_wave_sync();                                             /* matches may read these literals */
+        const uint32_t my_m = my_o + litrun;                         /* where my match lands */
+        const uint32_t src_end = my_m - dist + (mlen < dist ? mlen : dist);
+        uint64_t pending = qz_ballot(mlen != 0);
+        while (pending) {
+            /* everything below the first unfinished match is final: it and every match reading only from there go now */
+            const int f = qz_ctz64(pending);
+            const uint32_t m_f = qz_readlane(my_m, f);
+            const bool ready = ((pending >> lane) & 1) && (lane == f || src_end <= m_f);
+            if (ready) qzk_copy_match(o + (int64_t)my_m, dist, mlen);
+            pending &= ~qz_ballot(ready);
+            qz_wave_sync();
+        }
+        obase += Tb; lbase += Lb;
+    }
 }
 
 #endif

@@ -37,6 +37,7 @@ struct Fiber { void *sp; char *stack; bool done; int wait_kind; unsigned wait_ge
 struct Wave {
     unsigned gen, arrived, live; int tag;
     uint64_t a[2][64], b[2][64];      /* double-buffered exchange slots */
+    uint64_t part[2];                 /* lanes that took part in the rendezvous (snapshot when it completed) */
 };
 static Fiber fib[MAXT];
 static Wave waves[MAXT / 64];
@@ -45,6 +46,13 @@ static int cur, nthreads;
 static unsigned blk_gen, blk_arrived, blk_live;
 static std::function<void()> *body;
 static char *dyn_lds;
+
+static inline uint64_t live_mask(int wave)
+{
+    uint64_t m = 0;
+    for (int i = 0; i < 64; i++) if (wave * 64 + i < nthreads && !fib[wave * 64 + i].done) m |= 1ull << i;
+    return m;
+}
 
 static void fiber_main()
 {
@@ -55,7 +63,7 @@ static void fiber_main()
     blk_live--;
     /* a lane leaving may complete a pending rendezvous */
     Wave &w = waves[cur / 64];
-    if (w.live && w.arrived == w.live) { w.arrived = 0; w.gen++; }
+    if (w.live && w.arrived == w.live) { w.part[w.gen & 1] = live_mask(cur / 64); w.arrived = 0; w.gen++; }
     if (blk_live && blk_arrived == blk_live) { blk_arrived = 0; blk_gen++; }
     sim_switch(&f.sp, sched_sp);
     abort();
@@ -73,7 +81,7 @@ static inline unsigned wave_arrive(int tag, uint64_t va, uint64_t vb)
     if (w.arrived == 0) w.tag = tag;
     else if (w.tag != tag) { fprintf(stderr, "hipsim: divergent cross-lane op (tag %d vs %d) lane %d\n", w.tag, tag, lane()); abort(); }
     w.a[par][lane()] = va; w.b[par][lane()] = vb;
-    if (++w.arrived == w.live) { w.arrived = 0; w.gen++; }
+    if (++w.arrived == w.live) { w.part[par] = live_mask(cur / 64); w.arrived = 0; w.gen++; }
     else { fib[cur].wait_kind = 1; fib[cur].wait_gen = g; while (waves[cur / 64].gen == g) yield(); }
     return par;
 }
@@ -133,7 +141,7 @@ static inline uint64_t qz_ballot(bool p)
     unsigned par = sim::wave_arrive(1, p, 0);
     sim::Wave &w = sim::waves[sim::cur / 64];
     uint64_t m = 0;
-    for (int i = 0; i < 64; i++) if (!sim::fib[(sim::cur & ~63) + i].done && w.a[par][i]) m |= 1ull << i;
+    for (int i = 0; i < 64; i++) if (((w.part[par] >> i) & 1) && w.a[par][i]) m |= 1ull << i;
     return m;
 }
 static inline uint32_t qz_shfl(uint32_t v, int src)
@@ -146,7 +154,7 @@ static inline uint32_t qz_readlane(uint32_t v, int src)
     unsigned par = sim::wave_arrive(3, v, (uint64_t)src);
     sim::Wave &w = sim::waves[sim::cur / 64];
     for (int i = 0; i < 64; i++)
-        if (!sim::fib[(sim::cur & ~63) + i].done && (int)w.b[par][i] != src) {
+        if (((w.part[par] >> i) & 1) && (int)w.b[par][i] != src) {
             fprintf(stderr, "hipsim: readlane with non-uniform lane index\n"); abort();
         }
     return (uint32_t)w.a[par][src & 63];
@@ -155,7 +163,7 @@ static inline uint32_t qz_readfirstlane(uint32_t v)
 {
     unsigned par = sim::wave_arrive(4, v, 0);
     sim::Wave &w = sim::waves[sim::cur / 64];
-    for (int i = 0; i < 64; i++) if (!sim::fib[(sim::cur & ~63) + i].done) return (uint32_t)w.a[par][i];
+    for (int i = 0; i < 64; i++) if ((w.part[par] >> i) & 1) return (uint32_t)w.a[par][i];
     return v;
 }
 static inline void qz_wave_sync() { sim::wave_arrive(5, 0, 0); }

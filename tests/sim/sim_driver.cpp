@@ -17,18 +17,31 @@
 
 extern "C" {
 
+/* K1 through its persistent pull kernel: `wgs` workgroups share the chunk counter (the emulator runs them one after
+ * the other, so the first one takes every chunk and its table slices are reused dirty - the interesting case).
+ * variant 0: prev[] in LDS, 1: prev[] in a global slice. */
+static void run_k1(int variant, uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint32_t nchunks,
+                   uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta)
+{
+    std::vector<uint16_t> head((size_t)wgs * QZK_HSIZE, 0xabcd), prev((size_t)wgs * QZK_WSIZE, 0x5a5a);
+    uint32_t counter = 0;
+    if (variant == 0)
+        sim::launch(wgs, 64, 0, [&] { qzk_lz77_pull_kernel<true>(src, n, chunk_sz, nchunks, lc, dist, meta, head.data(), prev.data(), 0u, &counter); });
+    else
+        sim::launch(wgs, 64, 0, [&] { qzk_lz77_pull_kernel<false>(src, n, chunk_sz, nchunks, lc, dist, meta, head.data(), prev.data(), 0u, &counter); });
+}
+
 /* K1 only: symbols + meta of every chunk */
 int sim_lz77(const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta)
 {
     uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
-    std::vector<uint16_t> head((size_t)nchunks * QZK_HSIZE, 0xabcd);   /* the kernel clears its own slice */
-    sim::launch(nchunks, 64, 0, [&] { qzk_lz77_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, head.data()); });
+    run_k1(0, 2, src, n, chunk_sz, nchunks, lc, dist, meta);
     return (int)nchunks;
 }
 
 /* K1 + K2: raw deflate stream of all chunks (last: final chunk carries BFINAL) */
-int sim_deflate(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len,
-                uint32_t *crcs)
+static int deflate_variant(int variant, const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out,
+                           uint64_t *out_len, uint32_t *crcs)
 {
     uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
     std::vector<uint8_t> lc(n + 64);
@@ -37,8 +50,7 @@ int sim_deflate(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uin
     uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
     std::vector<uint8_t> slots((size_t)nchunks * stride);
     std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
-    std::vector<uint16_t> head((size_t)nchunks * QZK_HSIZE, 0xabcd);
-    sim::launch(nchunks, 64, 0, [&] { qzk_lz77_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), head.data()); });
+    run_k1(variant, 2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data());
     sim::launch(nchunks, QZK_HT, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
                         last ? nchunks - 1 : ~0u, olen.data(), ocrc.data());
@@ -51,6 +63,16 @@ int sim_deflate(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uin
     }
     *out_len = pos;
     return (int)nchunks;
+}
+
+int sim_deflate(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len, uint32_t *crcs)
+{
+    return deflate_variant(0, src, n, chunk_sz, last, out, out_len, crcs);
+}
+
+int sim_deflate_hbm(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len, uint32_t *crcs)
+{
+    return deflate_variant(1, src, n, chunk_sz, last, out, out_len, crcs);
 }
 
 /* K1b (one chunk per lane) + K2 */
@@ -107,11 +129,26 @@ int sim_lz4d(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *segs, qzk_lz4r
     return 0;
 }
 
-/* K3b: one segment per lane */
+/* K3b: phase A (one segment per lane -> literal streams + sequence records), phase B (one wave per segment) */
 int sim_inflate_lane(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
 {
     std::vector<qzk_inf_tab> tabs(nsegs);
-    sim::launch((nsegs + 63) / 64, 64, 0, [&] { qzk_inflate_lane_kernel(comp, out, segs, res, nsegs, tabs.data()); });
+    std::vector<qzk_tokseg> ts(nsegs);
+    uint64_t lt = 0, sqt = 0;
+    for (uint32_t i = 0; i < nsegs; i++) {
+        ts[i].lit_off = lt; ts[i].seq_off = sqt;
+        if (!(segs[i].flags & QZK_INF_COUNT_ONLY)) { lt += QZK_TOK_LITCAP(segs[i].out_cap); sqt += QZK_TOK_SEQCAP(segs[i].out_cap); }
+    }
+    std::vector<uint8_t> lits(lt + 64, 0xee);
+    std::vector<qzk_seq> seqs(sqt + 8);
+    std::vector<uint32_t> nseqs(nsegs, 0xdeadbeef);
+    /* 16 segments per workgroup like the device launch; the emulator wants whole waves, the kernel bounds-checks */
+    sim::launch((nsegs + 15) / 16, 64, 0, [&] {
+        if (threadIdx.x < 16) qzk_inflate_tok_kernel<16>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), nseqs.data());
+    });
+    sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
+        qzk_lz_resolve_kernel(out, segs, res, nsegs, ts.data(), lits.data(), seqs.data(), nseqs.data());
+    });
     return 0;
 }
 

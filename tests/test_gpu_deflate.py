@@ -80,3 +80,20 @@ def test_lane_per_chunk_kernel_is_bit_exact_too(ctx, monkeypatch):
         src = datagen.gen_bytes(kind, n, 123)
         got, crcs = _gpu_raw(ctx, src, chunk)
         assert got == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2], (kind, n, chunk)
+
+
+@pytest.mark.parametrize("mix", ["3,0", "0,5", "2,3", "0,3072"])
+def test_k1_residency_variants_are_bit_exact(monkeypatch, mix):
+    # K1's persistent workgroups come in two variants (prev[] in LDS / in an HBM slice) that pull chunks from one
+    # counter; force each one, and a mix, with few workgroups so every workgroup reuses its table slices many times
+    import qatzip_amd
+    monkeypatch.setenv("QATZIP_AMD_K1_WGS", mix)
+    c = qatzip_amd.Context(0)
+    try:
+        for kind, n, chunk in (("silesia", 3 << 20, 65536), ("lzmix", 140000, 16384), ("text", 300000, 131072),
+                               ("runs", 65400, 65536), ("records", 1 << 20, 65536), ("rand", 0, 65536)):
+            src = datagen.gen_bytes(kind, n, 321)
+            got, crcs = _gpu_raw(c, src, chunk)
+            assert got == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2], (mix, kind, n, chunk)
+    finally:
+        c.close()
