@@ -26,7 +26,6 @@ import numpy as np  # noqa: E402
 
 CHUNK = 65536
 CALL_BYTES = 1 << 31            # one qzCompress-sized call (2 GiB)
-BATCH_CHUNKS = 8192             # chunks per K1 launch (QZD_BATCH in qatzip_amd/csrc/qzd_internal.h)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -135,7 +134,8 @@ def main():
     ctx.sync(); t1 = time.perf_counter(); compress_all(); ctx.sync(); tc = time.perf_counter() - t1
     t1 = time.perf_counter(); decompress_all(); ctx.sync(); td = time.perf_counter() - t1
     inf_ms = ctx.inflate_timing()
-    probe_n = min(BATCH_CHUNKS * CHUNK, call_n[0])
+    batch_chunks = ctx.batch_chunks()         # chunks per K1 launch (three rounds over the resident workgroups)
+    probe_n = min(batch_chunks * CHUNK, call_n[0])
     ctx.deflate_raw_async(view(d_src, 0, probe_n), probe_n, CHUNK, 1, 1, d_comp[0]); ctx.sync()
     probe_out = ctx.result()
     k_ms = ctx.timing()                      # single batch => K1 ran alone on the chip
@@ -150,8 +150,9 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as f:
-                pk = json.load(f)["kernels"].get("qzk_lz77_kernel[grid=%d]" % (BATCH_CHUNKS * 64))
-            if pk and probe_n == BATCH_CHUNKS * CHUNK:
+                pj = json.load(f)
+            pk = pj["kernels"].get(pj.get("k1_key", ""))
+            if pk and probe_n == batch_chunks * CHUNK and pj.get("k1_launch_chunks") == batch_chunks:
                 traffic = pk["hbm_bytes_fetch_x2"]
         except (OSError, KeyError, ValueError):
             pass
@@ -170,12 +171,13 @@ def main():
                        "chunk": CHUNK, "ratio": round(ratio, 4), "parallelism": "chunks sharded over %d rank(s), "
                        "no data-path collective" % world,
                        "compress_GBps": round(raw_total / tc / 1e9, 3), "decompress_GBps": round(raw_total / td / 1e9, 3)},
-            "roofline": {"bound": "hbm", "kernel": "qzk_lz77_kernel", "achieved": round(achieved, 3),
+            "roofline": {"bound": "hbm", "kernel": "qzk_lz77_pull_kernel<false>", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
                          "launch_ms": round(k_ms[0], 3), "launch_chunks": probe_n // CHUNK,
                          "other_kernels_ms": {"qzk_huff_kernel": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
-                                              "qzk_inflate_kernel(last call)": round(inf_ms[0], 3),
+                                              "qzk_inflate_tok_kernel+qzk_lz_resolve_kernel(last call)": round(inf_ms[0], 3),
+                                              "of which qzk_lz_resolve_kernel": round(inf_ms[2], 3),
                                               "qzk_crc_kernel(last call)": round(inf_ms[1], 3)}},
         }
         if not args.no_cpu:

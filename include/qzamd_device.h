@@ -36,6 +36,9 @@ int qzd_create(int device, qzd_ctx **ctx);
 void qzd_destroy(qzd_ctx *ctx);
 const char *qzd_last_error(qzd_ctx *ctx);
 int qzd_device_count(void);
+/* chunks the compress path hands to one launch of its LZ77 kernel on this device (a whole number of rounds over
+ * the resident workgroups); callers that pipeline their own work can size it in these units */
+uint32_t qzd_batch_chunks(qzd_ctx *ctx);
 
 /* plain HBM / pinned-host memory helpers (replace qaeMemAllocNUMA, src/qatzip_mem.c:169-224) */
 void *qzd_dev_alloc(qzd_ctx *ctx, size_t n);

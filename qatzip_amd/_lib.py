@@ -32,6 +32,7 @@ def load(build_if_missing=True):
     L.qzd_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.qzd_destroy.argtypes = [vp]
     L.qzd_last_error.argtypes = [vp]; L.qzd_last_error.restype = C.c_char_p
+    L.qzd_batch_chunks.argtypes = [vp]; L.qzd_batch_chunks.restype = C.c_uint32
     L.qzd_dev_alloc.argtypes = [vp, C.c_size_t]; L.qzd_dev_alloc.restype = vp
     L.qzd_dev_free.argtypes = [vp, vp]
     L.qzd_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -68,7 +69,7 @@ def exported_symbols():
             "qzd_h2d", "qzd_d2h", "qzd_host_alloc_pinned", "qzd_host_free_pinned", "qzd_deflate_raw",
             "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing", "qzd_inflate_segments",
             "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing",
-            "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens"]
+            "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks"]
 
 
 class DevBuf:
@@ -146,6 +147,9 @@ class Context:
         out_len = C.c_uint64(0)
         self._chk(self.L.qzd_result(self.h, C.byref(out_len), None, 0))
         return out_len.value
+
+    def batch_chunks(self):
+        return int(self.L.qzd_batch_chunks(self.h))
 
     def timing(self):
         ms = (C.c_float * 4)()

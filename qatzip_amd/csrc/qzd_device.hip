@@ -2,7 +2,7 @@
  * qzd_device.hip — host side of the device-resident C ABI (include/qzamd_device.h)
  * and the small utility kernels (size scan, slot gather).  gfx950 only.
  *
- * A call is cut into batches of QZD_BATCH chunks.  Per batch, on one stream:
+ * A call is cut into batches of qzd_ctx::batch_chunks chunks.  Per batch, on one stream:
  *   K1 qzk_lz77_kernel  (1 wave / chunk, 132 KiB LDS => one workgroup per CU)
  *   K2 qzk_huff_kernel  (256 threads / chunk) -> per-chunk slot + length + crc32
  *   scan of the lengths (running total carried in HBM, no host round trip)
@@ -138,6 +138,7 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         if (e && sscanf(e, "%u,%u", &a, &b) == 2 && a + b > 0 && a <= 65536 && b <= 65536) {
             c->k1_wgs_lds = a; c->k1_wgs_hbm = b; c->k1_fixed_mix = 1;
         }
+        c->batch_chunks = QZD_BATCH_ROUNDS * (c->k1_fixed_mix ? c->k1_wgs_lds + c->k1_wgs_hbm : c->k1_wgs_hbm);
         if (hipStreamCreateWithFlags(&c->st_k1b, hipStreamNonBlocking) != hipSuccess) return QZD_ERR_HIP;
         for (int i = 0; i < QZD_NBUF; i++) {
             hipEventCreateWithFlags(&c->k1go[i], hipEventDisableTiming);
@@ -177,6 +178,8 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     delete c;
 }
 
+extern "C" uint32_t qzd_batch_chunks(qzd_ctx *c) { return c ? c->batch_chunks : 0; }
+
 extern "C" const char *qzd_last_error(qzd_ctx *c) { return c ? c->err : "no context"; }
 
 extern "C" void *qzd_dev_alloc(qzd_ctx *c, size_t n)
@@ -211,7 +214,7 @@ static uint32_t slot_stride_for(uint32_t chunk_sz) { return (chunk_sz / 8u * 9u 
 
 static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
 {
-    uint32_t batch = nchunks < QZD_BATCH ? nchunks : QZD_BATCH;
+    uint32_t batch = nchunks < c->batch_chunks ? nchunks : c->batch_chunks;
     size_t sym = (size_t)batch * chunk_sz + 256, slot = (size_t)batch * slot_stride_for(chunk_sz);
     if (sym > c->sym_cap || slot > c->slot_cap || batch > c->meta_cap) {
         hipDeviceSynchronize();
@@ -319,7 +322,8 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
     if (rc) return rc;
     const uint32_t stride = slot_stride_for(chunk_sz);
     c->last_nchunks = nchunks;
-    c->nbatches = (nchunks + QZD_BATCH - 1) / QZD_BATCH;
+    const uint32_t BATCH = c->batch_chunks;
+    c->nbatches = (nchunks + BATCH - 1) / BATCH;
 
     HIPCHK(c, hipMemsetAsync(c->d_running, 0, 8, c->st[0]));
     HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, c->st[0]));
@@ -327,9 +331,9 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
     HIPCHK(c, hipEventRecord(c->done[0], c->st[0]));
     HIPCHK(c, hipStreamWaitEvent(c->st[1], c->done[0], 0));
 
-    for (uint32_t b = 0, k = 0; b < nchunks; b += QZD_BATCH, k++) {
+    for (uint32_t b = 0, k = 0; b < nchunks; b += BATCH, k++) {
         const int s = (int)(k % QZD_NBUF), so = (int)((k + 1) % QZD_NBUF);
-        const uint32_t bn = nchunks - b < QZD_BATCH ? nchunks - b : QZD_BATCH;
+        const uint32_t bn = nchunks - b < BATCH ? nchunks - b : BATCH;
         const uint64_t boff = (uint64_t)b * chunk_sz;
         const uint64_t blen = n - boff;      /* bytes from this batch's first chunk to the end of the call */
         const uint32_t final_chunk = (last && b + bn == nchunks) ? bn - 1 : ~0u;

@@ -20,6 +20,7 @@
  *      or have no markers are decoded by one wave straight through.
  */
 #include <algorithm>
+#include <chrono>
 #include <string.h>
 #include <vector>
 
@@ -32,7 +33,7 @@
 /* a lane needs ~60 ms per 64 KB segment whatever the segment count, the wave kernel does ~300 segments/ms
  * (bound by the CUs' scalar units): lanes win from ~18 000 segments on (measured) */
 #define QZD_LANE_MIN_SEGS 20000u
-#define QZD_LANE_SEGS_PER_WAVE 16u
+#define QZD_LANE_SEGS_PER_WAVE 32u
 
 /* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF */
 __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list, uint32_t cap, uint32_t *count)
@@ -101,7 +102,7 @@ extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *
         const dim3 grid((nsegs + lpw - 1) / lpw), blk(lpw);
 #define QZD_TOK_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_tok_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
                                             ts_d, lit_d, seq_d, ns_d)
-        if (lpw == 8) QZD_TOK_LAUNCH(8); else if (lpw == 32) QZD_TOK_LAUNCH(32); else if (lpw == 64) QZD_TOK_LAUNCH(64); else QZD_TOK_LAUNCH(16);
+        if (lpw == 8) QZD_TOK_LAUNCH(8); else if (lpw == 16) QZD_TOK_LAUNCH(16); else if (lpw == 64) QZD_TOK_LAUNCH(64); else QZD_TOK_LAUNCH(32);
 #undef QZD_TOK_LAUNCH
         HIPCHK(c, hipEventRecord(c->ev[1][0], st));
         hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
@@ -190,9 +191,16 @@ static int inflate_grouped(qzd_ctx *c, const uint8_t *d_src, uint8_t *d_dst, std
 {
     const uint32_t ns = (uint32_t)segs.size();
     std::vector<uint32_t> order(ns);
-    for (uint32_t i = 0; i < ns; i++) order[i] = i;
     auto clen = [&](uint32_t k) { return (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k]; };
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { uint32_t la = clen(a), lb = clen(b); return la != lb ? la < lb : a < b; });
+    {   /* stable counting sort on the compressed length in 32-byte classes: grouping only needs "similar", and an exact
+         * sort would seat byte-identical segments (tiled test data) in the same wave, where they never diverge */
+        const uint32_t NB = 8192;
+        std::vector<uint32_t> cnt(NB + 1, 0);
+        auto cls = [&](uint32_t k) { uint32_t v = clen(k) >> 5; return v < NB ? v : NB - 1; };
+        for (uint32_t i = 0; i < ns; i++) cnt[cls(i) + 1]++;
+        for (uint32_t i = 0; i < NB; i++) cnt[i + 1] += cnt[i];
+        for (uint32_t i = 0; i < ns; i++) order[cnt[cls(i)]++] = i;
+    }
     std::vector<qzk_infseg> ps(ns);
     std::vector<qzk_infres> pr(ns);
     for (uint32_t i = 0; i < ns; i++) ps[i] = segs[order[i]];
@@ -218,8 +226,18 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
     hipSetDevice(c->device);
     c->inf_ms[0] = c->inf_ms[1] = c->inf_ms[2] = 0;
     *h_in_used = 0; *h_out_len = 0;
+    /* QATZIP_AMD_TRACE=1: wall-clock of the host-side steps on stderr (developer aid) */
+    static const bool trace = getenv("QATZIP_AMD_TRACE") != NULL;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[qzd_inflate_stream] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     std::vector<uint32_t> mk;
     int rc = find_markers(c, d_src, n, mk);
+    lap("marker scan + sort");
     if (rc < 0) return rc;
     const bool scan_ok = rc == 0;
     std::vector<uint32_t> start;            /* candidate segment starts */
@@ -240,8 +258,10 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
             segs[k].out_cap = (uint32_t)std::min<uint64_t>(seg_hint, dst_cap - segs[k].out_off);
             segs[k].flags = 0; segs[k].pad = 0;
         }
+        lap("segment records");
         rc = inflate_grouped(c, d_src, d_dst, segs, res, start, n);
         if (rc) return rc;
+        lap("inflate (optimistic)");
         bool ok = true; uint32_t k = 0;
         for (;; k++) {
             if (k >= ns) { ok = false; break; }
@@ -301,7 +321,8 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
         total_out = r.out_len; total_in = r.in_used;
     }
     *h_in_used = total_in; *h_out_len = total_out;
-    if (h_crc) return qzd_crc32(c, d_dst, total_out, h_crc);
+    lap("chain check / rest");
+    if (h_crc) { rc = qzd_crc32(c, d_dst, total_out, h_crc); lap("crc32"); return rc; }
     return QZD_OK;
 }
 

@@ -7,7 +7,9 @@
 #include "../../include/qzamd_device.h"
 #include "qzk_deflate_lz77.h"
 
-#define QZD_BATCH 8192u
+/* chunks per batch = QZD_BATCH_ROUNDS chunks for every resident K1 workgroup (qzd_ctx::batch_chunks): a batch whose size
+ * is not a multiple of the workgroup count leaves part of the chip idle during its last round */
+#define QZD_BATCH_ROUNDS 3u
 #define QZD_NBUF 2
 #define QZD_K1_HBM_PER_CU 12u
 
@@ -23,6 +25,7 @@ struct qzd_ctx {
     uint16_t *k1_head, *k1_prev; uint32_t *k1_counter;
     uint32_t k1_wgs_lds, k1_wgs_hbm;                /* workgroups of the prev-in-LDS / prev-in-HBM variant */
     int k1_fixed_mix;                               /* QATZIP_AMD_K1_WGS given: always launch that mix */
+    uint32_t batch_chunks;
     size_t sym_cap, slot_cap; uint32_t meta_cap;
     /* per-call arrays */
     uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;

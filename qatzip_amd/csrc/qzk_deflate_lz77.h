@@ -187,21 +187,27 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 #define QZK_LDC(k, ck) do { uint64_t g_ = coff + base + (uint32_t)(ck); \
         if (!guard) { x[k][0] = qz_ld32(src + g_); x[k][1] = qz_ld32(src + g_ + 4); x[k][2] = qz_ld32(src + g_ + 8); x[k][3] = qz_ld32(src + g_ + 12); } \
         else { x[k][0] = qzk_ld32g(src, g_, src_len); x[k][1] = qzk_ld32g(src, g_ + 4, src_len); x[k][2] = qzk_ld32g(src, g_ + 8, src_len); x[k][3] = qzk_ld32g(src, g_ + 12, src_len); } } while (0)
+            /* loads are predicated on the link being live: with a dozen waves per CU the kernel is bound by the
+             * texture path (TA/TD ~ one lane-line per cycle), so dead lanes must not ride along */
+            for (int k = 0; k < 4; k++) x[k][0] = x[k][1] = x[k][2] = x[k][3] = 0;
             const bool ok0 = canh && q0 != 0 && (int)p - q0 <= QZK_MAXDIST;
             c0 = ok0 ? q0 : (int)p;
-            QZK_LDC(0, c0);
-            int d = QZK_PREV(c0 & (QZK_WSIZE - 1)), q = c0 - d;
+            int d = 0, q;
+            if (ok0) { QZK_LDC(0, c0); d = QZK_PREV(c0 & (QZK_WSIZE - 1)); }
+            q = c0 - d;
             const bool ok1 = ok0 && d != 0 && q > lo;
             c1 = ok1 ? q : (int)p;
-            QZK_LDC(1, c1);
-            d = QZK_PREV(c1 & (QZK_WSIZE - 1)); q = c1 - d;
+            d = 0;
+            if (ok1) { QZK_LDC(1, c1); d = QZK_PREV(c1 & (QZK_WSIZE - 1)); }
+            q = c1 - d;
             const bool ok2 = ok1 && d != 0 && q > lo;
             c2 = ok2 ? q : (int)p;
-            QZK_LDC(2, c2);
-            d = QZK_PREV(c2 & (QZK_WSIZE - 1)); q = c2 - d;
+            d = 0;
+            if (ok2) { QZK_LDC(2, c2); d = QZK_PREV(c2 & (QZK_WSIZE - 1)); }
+            q = c2 - d;
             const bool ok3 = ok2 && d != 0 && q > lo;
             c3 = ok3 ? q : (int)p;
-            QZK_LDC(3, c3);
+            if (ok3) QZK_LDC(3, c3);
 #undef QZK_LDC
             nc = (int)ok0 + (int)ok1 + (int)ok2 + (int)ok3;
             QZK_T(2);
