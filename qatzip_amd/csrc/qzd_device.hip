@@ -19,6 +19,7 @@
 
 #include "qzd_internal.h"
 #include "qzk_deflate_huff.h"
+#include "qzk_checksum.h"
 
 /* ------------------------------------------------------------------ utility kernels */
 /* offs[i] = *running + sum(len[0..i)); then *running += sum.  One 1024-thread workgroup. */
@@ -289,7 +290,8 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
                        sym_lc, sym_dist, meta, head, prev);
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
     hipLaunchKernelGGL(qzk_huff_kernel, dim3(nchunks), dim3(QZK_HT), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist,
-                       meta, slots, stride, last ? nchunks - 1 : ~0u, c->d_len, c->d_crc);
+                       meta, slots, stride, last ? nchunks - 1 : ~0u, c->d_len);
+    hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(nchunks), dim3(QZK_HT), 0, st, d_src, n, chunk_sz, nchunks, c->d_crc);
     HIPCHK(c, hipEventRecord(c->ev[0][2], st));
     hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len, nchunks, c->d_offs, c->d_running);
     hipLaunchKernelGGL(qzk_gather_kernel, dim3(nchunks), dim3(256), 0, st, slots, stride, c->d_len, c->d_offs, nchunks,
@@ -368,7 +370,8 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
         hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn,
                            c->sym_lc[s], c->sym_dist[s], c->meta[s], c->slots[s], stride, final_chunk,
-                           c->d_len + b, c->d_crc + b);
+                           c->d_len + b);
+        hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn, c->d_crc + b);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][2], st));
         /* the running total serialises scan/gather of consecutive batches across the two streams */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->done[so], 0));

@@ -1,7 +1,9 @@
 /*
  * qzk_deflate_huff.h — K2: zlib-exact block coding (trees.c behaviour) of the
- * symbol stream K1 produced, one chunk per 256-thread workgroup, gfx950; plus
- * the chunk's CRC32 (K6) since the chunk is being touched anyway.
+ * symbol stream K1 produced, one chunk per 256-thread workgroup, gfx950.  The
+ * workgroup CRC-32 routine (K6) also lives here; the chunk CRCs themselves are a
+ * separate launch (qzk_crc_chunks_kernel) so that this kernel's LDS stays below the
+ * 16 KiB a CU has left beside twelve resident K1 workgroups.
  *
  * Replaces, on the reference's software path, the _tr_flush_block() half of
  * zlib's deflate() (src/qatzip_sw.c:197) and the running crc32 zlib keeps for
@@ -48,7 +50,6 @@ typedef struct {
     /* output staging */
     uint32_t stage[420];
     uint32_t scan[8];
-    qzk_crc_lds crc;
 } qzk_huff_lds;
 
 QZ_DEV uint32_t qzk_bitrev(uint32_t code, int len)
@@ -444,7 +445,7 @@ QZ_DEV uint32_t qzk_block_crc32(qzk_crc_lds *S, const uint8_t *src, uint32_t n)
 QZ_KERNEL qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                           const uint8_t *sym_lc, const uint16_t *sym_dist, const qzk_lzmeta *meta,
                           uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk /* index or ~0u */,
-                          uint32_t *out_len, uint32_t *out_crc)
+                          uint32_t *out_len)
 {
     QZ_LDS qzk_huff_lds S;
     const int t = (int)threadIdx.x;
@@ -461,8 +462,6 @@ QZ_KERNEL qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
 
     qzk_bitout bo;
     bo.out = slots + (uint64_t)chunk * slot_stride; bo.nbytes = 0; bo.cbits = 0; bo.carry = 0;
-
-    const uint32_t crc = qzk_block_crc32(&S.crc, in, n);
 
     /* blocks 0..nfull-1 are full; block nfull is the remainder (possibly empty) */
     const uint32_t nblocks = nfull + ((is_final || nsym > nfull * QZK_LITBUF) ? 1 : 0);
@@ -537,7 +536,7 @@ QZ_KERNEL qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         if (t < 4) bo.out[bo.nbytes + (uint32_t)t] = t < 2 ? 0x00 : 0xff;
         bo.nbytes += 4;
     }
-    if (t == 0) { out_len[chunk] = bo.nbytes; out_crc[chunk] = crc; }
+    if (t == 0) out_len[chunk] = bo.nbytes;
 }
 
 #endif

@@ -39,6 +39,8 @@
 #define QZK_MAXINS 4
 #define QZK_HSIZE 65536            /* zlib hash_bits 16 at memLevel 9 */
 #define QZK_NSLOT 512
+#define QZK_RING 8192              /* bytes of recent input kept in LDS by the prev-in-HBM variant */
+#define QZK_RINGW (QZK_RING / 4)
 
 #if defined(QZK_PROF) && !defined(QZ_SIM)
 #define QZK_T(k) do { uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; } while (0)
@@ -65,6 +67,16 @@ QZ_DEV uint32_t qzk_ld32g(const uint8_t *src, uint64_t off, uint64_t src_len)
     uint32_t v = 0;
     for (int k = 0; k < 4; k++) if (off + k < src_len) v |= (uint32_t)src[off + k] << (8 * k);
     return v;
+}
+
+/* low dword of {hi,lo} >> 8*s, s in 0..3 (v_alignbyte_b32) */
+QZ_DEV uint32_t qzk_alignbyte(uint32_t hi, uint32_t lo, uint32_t s)
+{
+#ifdef QZ_SIM
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * s));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, s);
+#endif
 }
 
 /* common-prefix length of src[a..] and src[b..], at most maxlen; whole wave cooperates */
@@ -96,6 +108,16 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     QZ_LDS uint16_t prev_l[PL ? QZK_WSIZE : 2];  /* [pos & 32767] = distance to the previous inserted position with the same hash (0 = none) */
     QZ_LDS uint32_t slot[QZK_NSLOT];       /* per-window: min(lane<<16 | hash) over the lanes on a hash key */
     QZ_LDS uint32_t scnt[QZK_NSLOT];       /* per-window: number of lanes on the key */
+    /* prev-in-HBM variant: the last QZK_RING bytes of input (and ~100 ahead of the parse point) sit in LDS.  Every
+     * candidate compare drags a 128-byte line through L2 for 16 bytes, 86 % of them less than 8 KiB back; with a
+     * dozen waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
+    QZ_LDS uint32_t ring[PL ? 1 : QZK_RINGW];
+    uint32_t rhi = 0;                      /* chunk offset the ring is filled up to (multiple of 256) */
+#define QZK_RING16(dst, ca) do { const uint32_t r_ = (ca) & (QZK_RING - 1), i_ = r_ >> 2, s_ = r_ & 3; \
+        const uint32_t d0_ = ring[i_ & (QZK_RINGW - 1)], d1_ = ring[(i_ + 1) & (QZK_RINGW - 1)], d2_ = ring[(i_ + 2) & (QZK_RINGW - 1)], \
+                       d3_ = ring[(i_ + 3) & (QZK_RINGW - 1)], d4_ = ring[(i_ + 4) & (QZK_RINGW - 1)]; \
+        (dst)[0] = qzk_alignbyte(d1_, d0_, s_); (dst)[1] = qzk_alignbyte(d2_, d1_, s_); \
+        (dst)[2] = qzk_alignbyte(d3_, d2_, s_); (dst)[3] = qzk_alignbyte(d4_, d3_, s_); } while (0)
 #define QZK_PREV(i) (*(PL ? &prev_l[(i) & (PL ? QZK_WSIZE - 1 : 1)] : &prev_g[(i)]))
 
     const int lane = qz_lane();
@@ -154,7 +176,21 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         /* all of this window's loads stay inside the buffer unless it sits at the very end of it */
         const bool guard = coff + pos + 64 + 2 * QZK_CAP > src_len;
         uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        if (!guard) {
+        if (!PL) {
+            /* top the ring up to 96 bytes past the window start: one coalesced 256-byte load every few windows */
+            if (rhi < pos + 64 + 2 * QZK_CAP) {
+                do {
+                    const uint32_t a = rhi + 4 * (uint32_t)lane;
+                    const uint64_t g = coff + a;
+                    ring[(a >> 2) & (QZK_RINGW - 1)] = g + 4 <= src_len ? qz_ld32(src + g) : qzk_ld32g(src, g, src_len);
+                    rhi += 256;
+                } while (rhi < pos + 64 + 2 * QZK_CAP);
+                qz_lds_sync();
+            }
+            uint32_t w[4];
+            QZK_RING16(w, pa);
+            w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
+        } else if (!guard) {
             const uint8_t *o = src + coff + pa;
             w0 = qz_ld32(o); w1 = qz_ld32(o + 4); w2 = qz_ld32(o + 8); w3 = qz_ld32(o + 12);
         } else if (avail > 0) {
@@ -184,8 +220,9 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         int nc, c0, c1, c2, c3;
         {
             uint32_t x[4][4];
-#define QZK_LDC(k, ck) do { uint64_t g_ = coff + base + (uint32_t)(ck); \
-        if (!guard) { x[k][0] = qz_ld32(src + g_); x[k][1] = qz_ld32(src + g_ + 4); x[k][2] = qz_ld32(src + g_ + 8); x[k][3] = qz_ld32(src + g_ + 12); } \
+#define QZK_LDC(k, ck) do { const uint32_t ca_ = base + (uint32_t)(ck); uint64_t g_ = coff + ca_; \
+        if (!PL && (int64_t)ca_ >= (int64_t)rhi - QZK_RING) QZK_RING16(x[k], ca_); \
+        else if (!guard) { x[k][0] = qz_ld32(src + g_); x[k][1] = qz_ld32(src + g_ + 4); x[k][2] = qz_ld32(src + g_ + 8); x[k][3] = qz_ld32(src + g_ + 12); } \
         else { x[k][0] = qzk_ld32g(src, g_, src_len); x[k][1] = qzk_ld32g(src, g_ + 4, src_len); x[k][2] = qzk_ld32g(src, g_ + 8, src_len); x[k][3] = qzk_ld32g(src, g_ + 12, src_len); } } while (0)
             /* loads are predicated on the link being live: with a dozen waves per CU the kernel is bound by the
              * texture path (TA/TD ~ one lane-line per cycle), so dead lanes must not ride along */
@@ -421,6 +458,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     for (int k = 0; k < 16; k++) mt->prof[k] = prof[k];
 #endif
 #undef QZK_PREV
+#undef QZK_RING16
 }
 
 /* K1 launch shape: persistent single-wave workgroups pull chunk numbers from one counter shared by the two

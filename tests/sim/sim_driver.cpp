@@ -53,8 +53,9 @@ static int deflate_variant(int variant, const uint8_t *src, uint64_t n, uint32_t
     run_k1(variant, 2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data());
     sim::launch(nchunks, QZK_HT, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
-                        last ? nchunks - 1 : ~0u, olen.data(), ocrc.data());
+                        last ? nchunks - 1 : ~0u, olen.data());
     });
+    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data()); });
     uint64_t pos = 0;
     for (uint32_t c = 0; c < nchunks; c++) {
         memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);
@@ -92,8 +93,9 @@ int sim_deflate_lane(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last
     });
     sim::launch(nchunks, QZK_HT, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
-                        last ? nchunks - 1 : ~0u, olen.data(), ocrc.data());
+                        last ? nchunks - 1 : ~0u, olen.data());
     });
+    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data()); });
     uint64_t pos = 0;
     for (uint32_t c = 0; c < nchunks; c++) {
         memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);
