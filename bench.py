@@ -123,43 +123,50 @@ def main():
     # parity guard outside the timed region: what came back is what went in
     assert ctx.crc32(d_back, call_n[-1]) == ctx.crc32(view(d_src, (ncalls - 1) * CALL_BYTES, call_n[-1]), call_n[-1])
 
+    ctx.k1_stats(reset=True)
     barrier(pg); ctx.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     ctx.sync(); barrier(pg)
     dt = allreduce(pg, time.perf_counter() - t0, "MAX")
+    # dominant kernel (K1, the LZ77 parse): HIP events around every launch of the timed region, on its own stream
+    k1_ms, k1_launches, k1_chunks = ctx.k1_stats()
 
-    # per-direction split and the K1 roofline probe (untimed by the contract, reported alongside)
+    # per-direction split (untimed by the contract, reported alongside) and one K1 launch alone on the chip
     ctx.sync(); t1 = time.perf_counter(); compress_all(); ctx.sync(); tc = time.perf_counter() - t1
     t1 = time.perf_counter(); decompress_all(); ctx.sync(); td = time.perf_counter() - t1
     inf_ms = ctx.inflate_timing()
-    batch_chunks = ctx.batch_chunks()         # chunks per K1 launch (three rounds over the resident workgroups)
+    batch_chunks = ctx.batch_chunks()         # chunks per full K1 launch (three rounds over the resident workgroups)
     probe_n = min(batch_chunks * CHUNK, call_n[0])
     ctx.deflate_raw_async(view(d_src, 0, probe_n), probe_n, CHUNK, 1, 1, d_comp[0]); ctx.sync()
-    probe_out = ctx.result()
     k_ms = ctx.timing()                      # single batch => K1 ran alone on the chip
     comp_total = allreduce(pg, float(sum(comp_len)), "SUM")
     raw_total = float(total) * world
     tc = allreduce(pg, tc, "MAX"); td = allreduce(pg, td, "MAX")
 
     if rank == 0:
-        # HBM traffic of one K1 launch: PMC counters cannot be read from inside this process; they come from the
-        # committed rocprofv3 --pmc passes of this same command (profiles/r1_pmc.json, tools/pmc_summary.py),
-        # FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note.
+        # HBM traffic per K1 launch: PMC counters cannot be read from inside this process; they come from the committed
+        # rocprofv3 --pmc passes of this same command (profiles/r1_pmc.json, tools/pmc_summary.py): FETCH_SIZE and
+        # WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note; quoted only when the
+        # profiled command had the same launch mix (same --mb).
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as f:
                 pj = json.load(f)
             pk = pj["kernels"].get(pj.get("k1_key", ""))
-            if pk and probe_n == batch_chunks * CHUNK and pj.get("k1_launch_chunks") == batch_chunks:
+            if pk and pj.get("bench_mb") == args.mb and pj.get("k1_launch_chunks") == batch_chunks:
                 traffic = pk["hbm_bytes_fetch_x2"]
         except (OSError, KeyError, ValueError):
             pass
         value = 2.0 * raw_total * args.steps / dt / 1e9
         ratio = comp_total / raw_total
-        alg_bytes = probe_n + probe_out                       # U + C of one K1 launch
-        achieved = alg_bytes / (k_ms[0] * 1e-3) / 1e9 if k_ms[0] > 0 else 0.0
+        # algorithmic bytes of the K1 launches of the timed region: every input byte read once, every compressed byte
+        # written once (U + C per chunk), divided over the launches; rank 0's own launches and time
+        alg_total = args.steps * (float(total) + float(sum(comp_len)))
+        alg_bytes = alg_total / max(k1_launches, 1)
+        launch_ms = k1_ms / max(k1_launches, 1)
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         res = {
             "metric": "compress + decompress GB/s (input bytes), QZ_DEFLATE_GZIP_EXT L1, 64 KB chunks",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -174,7 +181,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "qzk_lz77_pull_kernel<false>", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
-                         "launch_ms": round(k_ms[0], 3), "launch_chunks": probe_n // CHUNK,
+                         "launch_ms": round(launch_ms, 3), "launches": int(k1_launches),
+                         "chunks_per_launch": round(k1_chunks / max(k1_launches, 1), 1),
+                         "full_launch_alone_ms": round(k_ms[0], 3), "full_launch_chunks": probe_n // CHUNK,
                          "other_kernels_ms": {"qzk_huff_kernel": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
                                               "qzk_inflate_tok_kernel+qzk_lz_resolve_kernel(last call)": round(inf_ms[0], 3),
                                               "of which qzk_lz_resolve_kernel": round(inf_ms[2], 3),

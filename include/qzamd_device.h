@@ -39,6 +39,9 @@ int qzd_device_count(void);
 /* chunks the compress path hands to one launch of its LZ77 kernel on this device (a whole number of rounds over
  * the resident workgroups); callers that pipeline their own work can size it in these units */
 uint32_t qzd_batch_chunks(qzd_ctx *ctx);
+/* accumulated duration (HIP events on the launching stream), count and chunk total of the LZ77 kernel launches
+ * since the last reset; harvested whenever qzd_sync() completes a compress call */
+int qzd_k1_stats(qzd_ctx *ctx, double *ms, uint64_t *launches, uint64_t *chunks, int reset);
 
 /* plain HBM / pinned-host memory helpers (replace qaeMemAllocNUMA, src/qatzip_mem.c:169-224) */
 void *qzd_dev_alloc(qzd_ctx *ctx, size_t n);

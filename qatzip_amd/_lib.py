@@ -33,6 +33,7 @@ def load(build_if_missing=True):
     L.qzd_destroy.argtypes = [vp]
     L.qzd_last_error.argtypes = [vp]; L.qzd_last_error.restype = C.c_char_p
     L.qzd_batch_chunks.argtypes = [vp]; L.qzd_batch_chunks.restype = C.c_uint32
+    L.qzd_k1_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
     L.qzd_dev_alloc.argtypes = [vp, C.c_size_t]; L.qzd_dev_alloc.restype = vp
     L.qzd_dev_free.argtypes = [vp, vp]
     L.qzd_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -69,7 +70,7 @@ def exported_symbols():
             "qzd_h2d", "qzd_d2h", "qzd_host_alloc_pinned", "qzd_host_free_pinned", "qzd_deflate_raw",
             "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing", "qzd_inflate_segments",
             "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing",
-            "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks"]
+            "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats"]
 
 
 class DevBuf:
@@ -150,6 +151,12 @@ class Context:
 
     def batch_chunks(self):
         return int(self.L.qzd_batch_chunks(self.h))
+
+    def k1_stats(self, reset=False):
+        """(total ms, launches, chunks) of the LZ77 kernel since the last reset"""
+        ms, ln, ch = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        self.L.qzd_k1_stats(self.h, C.byref(ms), C.byref(ln), C.byref(ch), 1 if reset else 0)
+        return ms.value, ln.value, ch.value
 
     def timing(self):
         ms = (C.c_float * 4)()

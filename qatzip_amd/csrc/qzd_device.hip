@@ -125,6 +125,7 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         for (int k = 0; k < 4; k++) hipEventCreate(&c->ev[i][k]);
     }
     hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
+    for (int i = 0; i < QZD_K1EV; i++) { hipEventCreate(&c->k1ev[i][0]); hipEventCreate(&c->k1ev[i][1]); }
     {
         /* K1 residency (measured): a batch that fits two single-wave workgroups per CU runs the
          * prev-in-LDS variant (lowest latency per chunk); anything larger runs QZD_K1_HBM_PER_CU workgroups per CU of
@@ -168,6 +169,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
         for (int k = 0; k < 4; k++) hipEventDestroy(c->ev[i][k]);
     }
     hipEventDestroy(c->ev_begin); hipEventDestroy(c->ev_end);
+    for (int i = 0; i < QZD_K1EV; i++) { hipEventDestroy(c->k1ev[i][0]); hipEventDestroy(c->k1ev[i][1]); }
     hipStreamDestroy(c->st_k1b);
     hipFree(c->k1_head); hipFree(c->k1_prev); hipFree(c->k1_counter);
     hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
@@ -325,6 +327,7 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
     const uint32_t stride = slot_stride_for(chunk_sz);
     c->last_nchunks = nchunks;
     const uint32_t BATCH = c->batch_chunks;
+    c->k1ev_n = 0;
     c->nbatches = (nchunks + BATCH - 1) / BATCH;
 
     HIPCHK(c, hipMemsetAsync(c->d_running, 0, 8, c->st[0]));
@@ -353,6 +356,7 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
         else { wg_lds = 0; wg_hbm = bn < c->k1_wgs_hbm ? bn : c->k1_wgs_hbm; }
         HIPCHK(c, hipMemsetAsync(c->k1_counter + s, 0, 4, st));
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
+        if (k < QZD_K1EV) HIPCHK(c, hipEventRecord(c->k1ev[k][0], st));
         if (wg_hbm) {
             HIPCHK(c, hipEventRecord(c->k1go[s], st));
             HIPCHK(c, hipStreamWaitEvent(c->st_k1b, c->k1go[s], 0));
@@ -367,6 +371,7 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
                                c->k1_counter + s);
         if (wg_hbm) HIPCHK(c, hipStreamWaitEvent(st, c->k1bdone[s], 0));
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
+        if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
         hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn,
                            c->sym_lc[s], c->sym_dist[s], c->meta[s], c->slots[s], stride, final_chunk,
@@ -397,6 +402,23 @@ extern "C" int qzd_sync(qzd_ctx *c)
     hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->st[0]));
     HIPCHK(c, hipStreamSynchronize(c->st[1]));
+    for (uint32_t k = 0; k < c->k1ev_n; k++) {      /* harvest the K1 launch timings of the call that just finished */
+        float t = 0;
+        if (hipEventElapsedTime(&t, c->k1ev[k][0], c->k1ev[k][1]) == hipSuccess) {
+            c->k1_ms_acc += t; c->k1_launch_acc++; c->k1_chunk_acc += c->k1ev_chunks[k];
+        }
+    }
+    c->k1ev_n = 0;
+    return QZD_OK;
+}
+
+extern "C" int qzd_k1_stats(qzd_ctx *c, double *ms, uint64_t *launches, uint64_t *chunks, int reset)
+{
+    if (!c) return QZD_ERR_PARAM;
+    if (ms) *ms = c->k1_ms_acc;
+    if (launches) *launches = c->k1_launch_acc;
+    if (chunks) *chunks = c->k1_chunk_acc;
+    if (reset) { c->k1_ms_acc = 0; c->k1_launch_acc = 0; c->k1_chunk_acc = 0; }
     return QZD_OK;
 }
 

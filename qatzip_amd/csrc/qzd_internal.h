@@ -11,6 +11,7 @@
  * is not a multiple of the workgroup count leaves part of the chip idle during its last round */
 #define QZD_BATCH_ROUNDS 3u
 #define QZD_NBUF 2
+#define QZD_K1EV 64                  /* K1 launches per call that get their own pair of timing events */
 #define QZD_K1_HBM_PER_CU 12u
 
 struct qzd_ctx {
@@ -26,6 +27,9 @@ struct qzd_ctx {
     uint32_t k1_wgs_lds, k1_wgs_hbm;                /* workgroups of the prev-in-LDS / prev-in-HBM variant */
     int k1_fixed_mix;                               /* QATZIP_AMD_K1_WGS given: always launch that mix */
     uint32_t batch_chunks;
+    /* K1 launch durations (HIP events around every K1 launch, harvested at qzd_sync): bench.py's roofline input */
+    hipEvent_t k1ev[QZD_K1EV][2]; uint32_t k1ev_chunks[QZD_K1EV]; uint32_t k1ev_n;
+    double k1_ms_acc; uint64_t k1_launch_acc, k1_chunk_acc;
     size_t sym_cap, slot_cap; uint32_t meta_cap;
     /* per-call arrays */
     uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;

@@ -25,6 +25,7 @@ def load(d, name):
 def main():
     fd, wd, out = sys.argv[1:4]
     k1_chunks = int(sys.argv[4]); cmd = sys.argv[5]
+    bench_mb = int(cmd.split("--mb")[1].split()[0]) if "--mb" in cmd else 4096
     fetch, nf = load(fd, "FETCH_SIZE")
     write, nw = load(wd, "WRITE_SIZE")
     res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- " + cmd,
@@ -41,6 +42,7 @@ def main():
     if k1:
         res["k1_key"] = max(k1, key=lambda k: int(k.split("grid=")[1].rstrip("]")))
         res["k1_launch_chunks"] = k1_chunks
+        res["bench_mb"] = bench_mb
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -5,7 +5,7 @@
 # then tools/pmc_summary.py turns 2. into profiles/<round>_pmc.json (run on the build box afterwards).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-MB=${1:-1152}
+MB=${1:-4096}
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --mb 4096 --steps 2 --warmup 1 --no-cpu > $R/gpurun_out/prof_stats.log 2>&1
 grep '^{' $R/gpurun_out/prof_stats.log | tail -1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_fetch -- python $R/bench.py --mb $MB --steps 1 --warmup 1 --no-cpu > $R/gpurun_out/prof_fetch.log 2>&1
