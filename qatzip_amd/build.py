@@ -13,6 +13,7 @@ def _sources():
     for f in sorted(os.listdir(CSRC)):
         if f.endswith((".hip", ".cpp", ".c", ".h")):
             out.append(os.path.join(CSRC, f))
+    out.append(os.path.join(HERE, "cli", "qzip_amd.c"))
     out.append(os.path.join(os.path.dirname(HERE), "include", "qzamd_device.h"))
     q = os.path.join(os.path.dirname(HERE), "include", "qatzip.h")
     if os.path.exists(q):
@@ -21,7 +22,7 @@ def _sources():
 
 
 def needs_build():
-    if not os.path.exists(SO):
+    if not os.path.exists(SO) or not os.path.exists(os.path.join(HERE, "qzip-amd")):
         return True
     t = os.path.getmtime(SO)
     return any(os.path.getmtime(s) > t for s in _sources())
@@ -41,7 +42,21 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_cli(verbose)
     return SO
+
+
+CLI = os.path.join(HERE, "qzip-amd")
+
+
+def build_cli(verbose=False):
+    """the qzip-style file front end: plain C against include/qatzip.h, linked like any application"""
+    cmd = ["gcc", "-O2", "-std=gnu99", "-Wall", "-I", os.path.join(os.path.dirname(HERE), "include"),
+           os.path.join(HERE, "cli", "qzip_amd.c"), "-o", CLI, "-L", HERE, "-lqatzip_amd", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == "__main__":

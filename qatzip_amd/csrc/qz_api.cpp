@@ -496,7 +496,10 @@ static int decompress_lz4(QzSession_T *sess, Sess *s, const unsigned char *src, 
     while (ti < n && to < cap) {                                    /* frame loop, src/qatzip_sw.c:555-571 */
         uint64_t content; bool hc;
         int64_t ext = lz4_frame_extent(src + ti, n - ti, &content, &hc);
-        if (ext < 0) return QZ_FAIL;                                /* SW path: LZ4F error => QZ_FAIL */
+        if (ext < 0) {                                              /* SW path: LZ4F error => QZ_FAIL */
+            if (segs.empty()) return QZ_FAIL;
+            break;                                                  /* complete frames first; the caller comes back with the rest */
+        }
         if (!hc) content = cap - to;                                /* unknown: give it the rest */
         if (to + content > cap) { if (segs.empty()) return QZ_BUF_ERROR; break; }
         qzd_lz4seg g; g.in_off = ti; g.out_off = to; g.in_len = (uint32_t)ext; g.out_cap = (uint32_t)content;
@@ -609,6 +612,10 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
         s->end_of_stream = 1;
         if (s->p.stop_at_stream_end) break;
     }
+    /* a later member that is cut short or damaged does not undo the complete ones before it: partial consumption,
+     * QZ_OK, and the next call (which starts at that member) reports the error - the member-granular version of what
+     * the software path's kept inflate state does ("first half of the stream => QZ_OK, partial output") */
+    if (ret == QZ_DATA_ERROR && ti > 0) ret = QZ_OK;
     if (ret != QZ_OK && !(ret == QZ_BUF_ERROR && to > 0)) { *src_len = 0; *dest_len = 0; return ret; }
     if (to && qzd_d2h(s->ctx, dest, s->d_out, to) != QZD_OK) return QZ_FAIL;
     *src_len = ti; *dest_len = to;

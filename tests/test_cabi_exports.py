@@ -21,3 +21,14 @@ def test_library_builds_and_exports_device_abi():
     for n in names:
         assert hasattr(L, n), "missing export: " + n
     assert L.qzd_device_count() >= 0
+
+
+def test_cli_builds_and_prints_usage_without_a_gpu():
+    """the qzip-style front end is plain C against include/qatzip.h; -h needs neither a session nor a device"""
+    import subprocess
+    import qatzip_amd.build as B
+    B.build()
+    r = subprocess.run([B.CLI, "-h"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "-O <fmt>" in r.stdout
+    r = subprocess.run([B.CLI, "-O", "zstd", "x"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "not offered" in r.stderr
