@@ -104,6 +104,11 @@ int qzd_inflate_segments(qzd_ctx *ctx, const uint8_t *d_comp, uint8_t *d_out, co
 int qzd_inflate_stream(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
                        uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc);
 
+/* Adler-32 (zlib adler32(), what the DEFLATE_ZLIB trailer carries: deflateInit2 with windowBits 15,
+ * src/qatzip_sw.c:147) of every chunk_sz chunk of HBM-resident data; fold with qzd_adler32_combine */
+int qzd_adler32_chunks(qzd_ctx *ctx, const uint8_t *d_data, uint64_t n, uint32_t chunk_sz, uint32_t *h_adler);
+uint32_t qzd_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2);
+
 /* CRC-32 (zlib crc32()) of HBM-resident data */
 int qzd_crc32(qzd_ctx *ctx, const uint8_t *d_data, uint64_t n, uint32_t *h_crc);
 int qzd_crc32_ranges(qzd_ctx *ctx, const uint8_t *d_data, const void *h_ranges, uint32_t nranges, uint32_t *h_crc);

@@ -70,7 +70,8 @@ def exported_symbols():
             "qzd_h2d", "qzd_d2h", "qzd_host_alloc_pinned", "qzd_host_free_pinned", "qzd_deflate_raw",
             "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing", "qzd_inflate_segments",
             "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing",
-            "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats"]
+            "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats",
+            "qzd_adler32_chunks", "qzd_adler32_combine"]
 
 
 class DevBuf:

@@ -37,6 +37,11 @@ class QzSessionParamsDeflate(C.Structure):
     _fields_ = [("common_params", QzSessionParamsCommon), ("huffman_hdr", C.c_int), ("data_fmt", C.c_int)]
 
 
+class QzSessionParamsDeflateExt(C.Structure):
+    _fields_ = [("deflate_params", QzSessionParamsDeflate), ("stop_decompression_stream_end", C.c_ubyte),
+                ("zlib_format", C.c_ubyte)]
+
+
 class QzSessionParamsLZ4(C.Structure):
     _fields_ = [("common_params", QzSessionParamsCommon)]
 
@@ -46,6 +51,13 @@ class QzStream(C.Structure):
                 ("pending_in", C.c_uint), ("pending_out", C.c_uint), ("crc_type", C.c_int), ("crc_32", C.c_uint),
                 ("reserved", C.c_ulonglong), ("opaque", C.c_void_p)]
 
+
+class QzResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("cb_tag", C.c_void_p), ("src_len", C.c_uint), ("dest_len", C.c_uint),
+                ("ext_rc", C.c_uint64), ("crc", C.c_void_p), ("extension_result", C.c_void_p)]
+
+
+QzAsyncCallback = C.CFUNCTYPE(C.c_int, C.POINTER(QzResult))
 
 _bound = False
 
@@ -63,6 +75,8 @@ def lib():
         L.qzSetDefaults.argtypes = [P(QzSessionParams)]
         L.qzGetDefaultsDeflate.argtypes = [P(QzSessionParamsDeflate)]
         L.qzGetDefaultsLZ4.argtypes = [P(QzSessionParamsLZ4)]
+        L.qzGetDefaultsDeflateExt.argtypes = [P(QzSessionParamsDeflateExt)]
+        L.qzSetupSessionDeflateExt.argtypes = [P(QzSession), P(QzSessionParamsDeflateExt)]
         L.qzCompress.argtypes = [P(QzSession), u8p, up, C.c_void_p, up, C.c_uint]
         L.qzCompressCrc.argtypes = [P(QzSession), u8p, up, C.c_void_p, up, C.c_uint, P(C.c_ulong)]
         L.qzDecompress.argtypes = [P(QzSession), u8p, up, C.c_void_p, up]
@@ -78,6 +92,8 @@ def lib():
         L.qzDecompressStream.argtypes = [P(QzSession), P(QzStream), C.c_uint]
         L.qzEndStream.argtypes = [P(QzSession), P(QzStream)]
         L.qzSetLogLevel.argtypes = [C.c_int]
+        L.qzCompress2.argtypes = [P(QzSession), C.c_void_p, C.c_void_p, C.c_void_p, P(QzResult)]
+        L.qzDecompress2.argtypes = [P(QzSession), C.c_void_p, C.c_void_p, C.c_void_p, P(QzResult)]
         _bound = True
     return L
 
@@ -85,10 +101,16 @@ def lib():
 class Session:
     """A QzSession_T set up the way test/main.c does it: qzGetDefaults -> tweak -> qzSetupSession."""
 
-    def __init__(self, data_fmt=QZ_DEFLATE_GZIP_EXT, hw_buff_sz=65536, comp_lvl=1, lz4=False, strm_buff_sz=None):
+    def __init__(self, data_fmt=QZ_DEFLATE_GZIP_EXT, hw_buff_sz=65536, comp_lvl=1, lz4=False, strm_buff_sz=None,
+                 zlib_format=False):
         self.L = lib()
         self.s = QzSession()
-        if lz4:
+        if zlib_format:                        # qzSetupSessionDeflateExt(zlib_format = 1): RFC 1950 wrapper, Adler-32 trailer
+            p = QzSessionParamsDeflateExt(); self.L.qzGetDefaultsDeflateExt(C.byref(p))
+            p.deflate_params.data_fmt = QZ_DEFLATE_RAW; p.zlib_format = 1
+            p.deflate_params.common_params.hw_buff_sz = hw_buff_sz; p.deflate_params.common_params.comp_lvl = comp_lvl
+            self.rc_setup = self.L.qzSetupSessionDeflateExt(C.byref(self.s), C.byref(p))
+        elif lz4:
             p = QzSessionParamsLZ4(); self.L.qzGetDefaultsLZ4(C.byref(p))
             p.common_params.comp_algorithm = QZ_LZ4
             p.common_params.hw_buff_sz = hw_buff_sz; p.common_params.comp_lvl = comp_lvl

@@ -47,7 +47,7 @@ struct Sess {
     /* open deflate stream (qzCompress with last == 0 keeps it open, src/qatzip_sw.c:115,233-253) */
     bool open; uint32_t run_sum; uint64_t st_in, st_out;
     unsigned char end_of_stream;
-    std::vector<uint32_t> lens, crcs;
+    std::vector<uint32_t> lens, crcs, adlers;
 };
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER, g_mem_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -282,9 +282,12 @@ extern "C" int qzSetupSessionLZ4S(QzSession_T *sess, QzSessionParamsLZ4S_T *para
     return QZ_NOT_SUPPORTED;        /* LZ4s is a QAT-2.0 hardware format with no software path in the reference */
 }
 
+static void async_drain(QzSession_T *sess);   /* queued qzCompress2/qzDecompress2 requests of a session finish first */
+
 extern "C" int qzTeardownSession(QzSession_T *sess)
 {
     if (!sess) return QZ_PARAMS;
+    async_drain(sess);
     Sess *s = (Sess *)sess->internal;
     if (s) {
         if (s->ctx) {
@@ -368,6 +371,7 @@ static unsigned hdr_len(int fmt) { return fmt == F_GZIP ? 10 : fmt == F_GZIP_EXT
 static unsigned ftr_len(int fmt) { return (fmt == F_GZIP || fmt == F_GZIP_EXT) ? 8 : fmt == F_ZLIB ? 4 : 0; }
 
 extern "C" uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);   /* qzd_device.hip */
+static void wr32be(unsigned char *p, uint32_t v) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; }
 
 /* ------------------------------------------------------------------ compress */
 static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
@@ -375,7 +379,6 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
 {
     const int fmt = s->p.fmt;
     const uint32_t n = *src_len, cap = *dest_len, hw = s->p.hw_buff_sz;
-    if (fmt == F_ZLIB) return QZ_NOT_SUPPORTED;                     /* Adler-32 trailer: not on the GPU path yet */
     if (s->p.comp_lvl != 1) { logmsg(LOG_ERROR, "comp_lvl %u: only level 1 runs on the GPU path\n", s->p.comp_lvl); return QZ_NOT_SUPPORTED; }
     const bool opening = !s->open;
     const unsigned hl = opening ? hdr_len(fmt) : 0;
@@ -391,6 +394,10 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
     if (qzd_deflate_raw(s->ctx, s->d_in, n, hw, (int)s->p.comp_lvl, (int)last, s->d_out, s->out_cap, &produced, s->crcs.data()) != QZD_OK) {
         logmsg(LOG_ERROR, "GPU deflate failed: %s\n", qzd_last_error(s->ctx));
         return QZ_FAIL;
+    }
+    if (fmt == F_ZLIB) {                                            /* the zlib wrapper's trailer is an Adler-32, not a CRC */
+        s->adlers.resize(nchunks);
+        if (qzd_adler32_chunks(s->ctx, s->d_in, n, hw, s->adlers.data()) != QZD_OK) return QZ_FAIL;
     }
     /* how many whole chunks fit into dest (header now, trailer only with the final chunk)? */
     uint32_t take = nchunks; uint64_t bytes = produced;
@@ -408,7 +415,8 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
         if (fmt == F_GZIP) { static const unsigned char h[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 3}; memcpy(dest, h, 10); }
         else if (fmt == F_GZIP_EXT) { static const unsigned char h[24] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0, 'Q', 'Z', 8, 0}; memcpy(dest, h, 24); }
         else if (fmt == F_4B) wr32(dest, 0);
-        s->open = true; s->run_sum = 0; s->st_in = 0; s->st_out = hl;
+        else if (fmt == F_ZLIB) { dest[0] = 0x78; dest[1] = 0x01; }  /* CMF deflate/32K window, FLEVEL 0 (level 1), FCHECK */
+        s->open = true; s->run_sum = fmt == F_ZLIB ? 1u : 0u; s->st_in = 0; s->st_out = hl;
     }
     if (bytes && qzd_d2h(s->ctx, dest + hl, s->d_out, bytes) != QZD_OK) return QZ_FAIL;
     /* running CRC-32 of the stream (zlib's strm->adler for gzip) + the crc out-parameter of
@@ -417,6 +425,7 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
     for (uint32_t k = 0; k < take; k++) {
         uint32_t cl = std::min<uint32_t>(hw, n - k * hw);
         if (fmt == F_GZIP || fmt == F_GZIP_EXT) s->run_sum = qzd_crc32_combine(s->run_sum, s->crcs[k], cl);
+        else if (fmt == F_ZLIB) s->run_sum = qzd_adler32_combine(s->run_sum, s->adlers[k], cl);
         done_in += cl;
         if (crc) {
             if (fmt == F_RAW) *crc = qzd_crc32_combine((uint32_t)*crc, s->crcs[k], cl);
@@ -430,6 +439,7 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
     uint32_t out_total = hl + (uint32_t)bytes;
     if (complete && last) {
         if (fmt == F_GZIP || fmt == F_GZIP_EXT) { wr32(dest + out_total, s->run_sum); wr32(dest + out_total + 4, (uint32_t)s->st_in); out_total += 8; s->st_out += 8; }
+        if (fmt == F_ZLIB) { wr32be(dest + out_total, s->run_sum); out_total += 4; s->st_out += 4; }
         if (opening && fmt == F_GZIP_EXT) { wr32(dest + 16, (uint32_t)s->st_in); wr32(dest + 20, (uint32_t)(s->st_out - 24 - 8)); }
         if (opening && fmt == F_4B) wr32(dest, (uint32_t)(s->st_out - 4));
         s->open = false;
@@ -606,7 +616,16 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
         if (fmt == F_GZIP || fmt == F_GZIP_EXT) {
             if (pos + 8 > n || rd32(src + pos) != c32 || rd32(src + pos + 4) != (uint32_t)ol) { ret = QZ_DATA_ERROR; break; }
             pos += 8;
-        } else if (fmt == F_ZLIB) { ret = QZ_NOT_SUPPORTED; break; }
+        } else if (fmt == F_ZLIB) {
+            const uint32_t R = 256 * 1024, nr = ol ? (uint32_t)((ol + R - 1) / R) : 1;
+            std::vector<uint32_t> ad(nr);
+            if (pos + 4 > n || qzd_adler32_chunks(s->ctx, s->d_out + to, ol, R, ad.data()) != QZD_OK) { ret = QZ_DATA_ERROR; break; }
+            uint32_t a = 1;
+            for (uint32_t k = 0; k < nr; k++) a = qzd_adler32_combine(a, ad[k], std::min<uint64_t>(R, ol - (uint64_t)k * R));
+            const uint32_t want = (uint32_t)src[pos] << 24 | (uint32_t)src[pos + 1] << 16 | (uint32_t)src[pos + 2] << 8 | src[pos + 3];
+            if (a != want) { ret = QZ_DATA_ERROR; break; }
+            pos += 4;
+        }
         if (crc) *crc = (to == 0 && *crc == 0) ? c32 : qzd_crc32_combine((uint32_t)*crc, c32, ol);
         ti = pos; to += (uint32_t)ol;
         s->end_of_stream = 1;
@@ -776,10 +795,89 @@ extern "C" int qzEndStream(QzSession_T *sess, QzStream_T *strm)
     return QZ_OK;
 }
 
+/* ------------------------------------------------------------------ qzCompress2 / qzDecompress2
+ * src/qatzip.c:4112-4196: callback == NULL => the synchronous call (last = 1, optional input CRC-32 through
+ * QzResult_T.crc); otherwise the request is queued and a library thread retires it and calls callback(res)
+ * (the reference's ring + consumer thread, src/qatzip.c:3103-4110).  Here: one FIFO and one consumer thread per
+ * process; requests retire in submission order, so a session's requests never run concurrently. */
+struct AsyncReq { QzSession_T *sess; const unsigned char *src; unsigned char *dest; qzAsyncCallbackFn cb; QzResult_T *res; bool compress; };
+static pthread_mutex_t g_aq_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_aq_more = PTHREAD_COND_INITIALIZER, g_aq_idle = PTHREAD_COND_INITIALIZER;
+static std::vector<AsyncReq> g_aq;          /* pending, oldest first */
+static size_t g_aq_head = 0;
+static QzSession_T *g_aq_running = NULL;    /* session of the request being executed */
+static bool g_aq_thread = false;
+
+static int run_sync2(QzSession_T *sess, const unsigned char *src, unsigned char *dest, QzResult_T *r, bool compress)
+{
+    unsigned long *crc = (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
+    int rc = compress ? qzCompressCrcExt(sess, src, &r->src_len, dest, &r->dest_len, 1, crc, &r->ext_rc)
+                      : qzDecompressCrcExt(sess, src, &r->src_len, dest, &r->dest_len, crc, &r->ext_rc);
+    r->status = rc;
+    return rc;
+}
+
+static void *async_consumer(void *)
+{
+    for (;;) {
+        pthread_mutex_lock(&g_aq_lock);
+        while (g_aq_head == g_aq.size()) {
+            if (g_aq_head) { g_aq.clear(); g_aq_head = 0; }
+            pthread_cond_broadcast(&g_aq_idle);
+            pthread_cond_wait(&g_aq_more, &g_aq_lock);
+        }
+        AsyncReq q = g_aq[g_aq_head++];
+        g_aq_running = q.sess;
+        pthread_mutex_unlock(&g_aq_lock);
+        run_sync2(q.sess, q.src, q.dest, q.res, q.compress);
+        q.cb(q.res);
+        pthread_mutex_lock(&g_aq_lock);
+        g_aq_running = NULL;
+        pthread_cond_broadcast(&g_aq_idle);
+        pthread_mutex_unlock(&g_aq_lock);
+    }
+    return NULL;
+}
+
+/* wait until no queued or running request refers to sess (NULL: until the queue is empty) */
+static void async_drain(QzSession_T *sess)
+{
+    pthread_mutex_lock(&g_aq_lock);
+    for (;;) {
+        bool busy = g_aq_running && (!sess || g_aq_running == sess);
+        for (size_t i = g_aq_head; i < g_aq.size() && !busy; i++) busy = !sess || g_aq[i].sess == sess;
+        if (!busy) break;
+        pthread_cond_wait(&g_aq_idle, &g_aq_lock);
+    }
+    pthread_mutex_unlock(&g_aq_lock);
+}
+
+static int submit2(QzSession_T *sess, const unsigned char *src, unsigned char *dest, qzAsyncCallbackFn cb, QzResult_T *r, bool compress)
+{
+    if (!r) return QZ_PARAMS;
+    if (!cb) return run_sync2(sess, src, dest, r, compress);
+    if (!sess || !src || !dest) return QZ_PARAMS;
+    pthread_mutex_lock(&g_aq_lock);
+    if (!g_aq_thread) {
+        pthread_t th;
+        if (pthread_create(&th, NULL, async_consumer, NULL) != 0) { pthread_mutex_unlock(&g_aq_lock); return QZ_FAIL; }
+        pthread_detach(th);
+        g_aq_thread = true;
+    }
+    AsyncReq q = { sess, src, dest, cb, r, compress };
+    g_aq.push_back(q);
+    pthread_cond_signal(&g_aq_more);
+    pthread_mutex_unlock(&g_aq_lock);
+    return QZ_OK;
+}
+
+extern "C" int qzCompress2(QzSession_T *sess, const unsigned char *src, unsigned char *dest, qzAsyncCallbackFn callback, QzResult_T *qzResults)
+{ return submit2(sess, src, dest, callback, qzResults, true); }
+extern "C" int qzDecompress2(QzSession_T *sess, const unsigned char *src, unsigned char *dest, qzAsyncCallbackFn callback, QzResult_T *qzResults)
+{ return submit2(sess, src, dest, callback, qzResults, false); }
+
 /* ------------------------------------------------------------------ declared-only surface */
 #define NS(...) { return QZ_NOT_SUPPORTED; }
-extern "C" int qzCompress2(QzSession_T *, const unsigned char *, unsigned char *, qzAsyncCallbackFn, QzResult_T *) NS()
-extern "C" int qzDecompress2(QzSession_T *, const unsigned char *, unsigned char *, qzAsyncCallbackFn, QzResult_T *) NS()
 extern "C" int qzCompressCrc64(QzSession_T *, const unsigned char *, unsigned int *, unsigned char *, unsigned int *, unsigned int, uint64_t *) NS()
 extern "C" int qzCompressCrc64Ext(QzSession_T *, const unsigned char *, unsigned int *, unsigned char *, unsigned int *, unsigned int, uint64_t *, uint64_t *) NS()
 extern "C" int qzDecompressCrc64(QzSession_T *, const unsigned char *, unsigned int *, unsigned char *, unsigned int *, uint64_t *) NS()

@@ -143,6 +143,32 @@ extern "C" int qzd_crc32_ranges(qzd_ctx *c, const uint8_t *d_data, const void *h
     return QZD_OK;
 }
 
+/* zlib adler32_combine() */
+extern "C" uint32_t qzd_adler32_combine(uint32_t ad1, uint32_t ad2, uint64_t len2)
+{
+    const uint64_t M = 65521;
+    const uint64_t a1 = ad1 & 0xffff, b1 = ad1 >> 16, a2 = ad2 & 0xffff, b2 = ad2 >> 16;
+    const uint64_t a = (a1 + a2 + M - 1) % M;
+    const uint64_t b = (b1 + b2 + (len2 % M) * ((a1 + M - 1) % M)) % M;
+    return (uint32_t)(b << 16 | a);
+}
+
+/* Adler-32 of every chunk_sz chunk of d_data[0..n) (h_adler: one value per chunk; fold with qzd_adler32_combine) */
+extern "C" int qzd_adler32_chunks(qzd_ctx *c, const uint8_t *d_data, uint64_t n, uint32_t chunk_sz, uint32_t *h_adler)
+{
+    if (!c || !h_adler || (n && !d_data) || chunk_sz == 0 || chunk_sz > 512 * 1024) return QZD_ERR_PARAM;
+    const uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
+    hipSetDevice(c->device);
+    int rc = qzd_aux_reserve(c, (size_t)nchunks * 4 + 64);
+    if (rc) return rc;
+    hipStream_t st = c->st[0];
+    hipLaunchKernelGGL(qzk_adler_chunks_kernel, dim3(nchunks), dim3(QZK_HT), 0, st, d_data, n, chunk_sz, nchunks, (uint32_t *)c->d_aux);
+    HIPCHK(c, hipMemcpyAsync(h_adler, c->d_aux, (size_t)nchunks * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    return QZD_OK;
+}
+
 /* CRC-32 of d_data[0..n) folded on the host from 256 KiB ranges */
 extern "C" int qzd_crc32(qzd_ctx *c, const uint8_t *d_data, uint64_t n, uint32_t *h_crc)
 {

@@ -154,6 +154,13 @@ int sim_inflate_lane(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, 
     return 0;
 }
 
+int sim_adler(const uint8_t *data, uint64_t n, uint32_t chunk_sz, uint32_t *out)
+{
+    uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
+    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_adler_chunks_kernel(data, n, chunk_sz, nchunks, out); });
+    return (int)nchunks;
+}
+
 int sim_crc(const uint8_t *data, const qzk_range *ranges, uint32_t nranges, uint32_t *crc_out)
 {
     sim::launch(nranges, QZK_HT, 0, [&] { qzk_crc_kernel(data, ranges, nranges, crc_out); });

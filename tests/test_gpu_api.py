@@ -37,6 +37,85 @@ def test_compress_matches_sw_path_bit_for_bit(fmt):
         s.close()
 
 
+def test_zlib_format_sessions_match_sw_path():
+    """qzSetupSessionDeflateExt(zlib_format = 1): RFC 1950 header, the same chunked deflate body, Adler-32 trailer
+    (src/qatzip_sw.c:147 with windowBits 15) - bit-identical to the oracle, readable by zlib.decompress"""
+    for hw in (65536, 16384):
+        s = A.Session(hw_buff_sz=hw, zlib_format=True)
+        assert s.rc_setup == A.QZ_OK
+        for kind, n in (("silesia", 300123), ("text", 65536), ("rand", 70000), ("allA", 200000), ("text", 0), ("runs", 999)):
+            src = datagen.gen_bytes(kind, n, 23)
+            rc, used, out, crc = s.compress(src, 1, crc0=0)
+            erc, eused, exp, ecrc = O.sw_compress("ZLIB", src, hw, 1, cap=n * 9 // 8 + 65536)
+            assert rc == A.QZ_OK and used == n and out == exp and crc == ecrc, (hw, kind, n, rc)
+            assert zlib.decompress(out) == src
+            rc, cused, back = s.decompress(out, n + 16)
+            if n:
+                assert rc == A.QZ_OK and back == src and cused == len(out)
+        # two calls, one stream (last = 0 then 1), and a damaged trailer
+        src = datagen.gen_bytes("silesia", 200000, 5)
+        rc1, u1, o1, _ = s.compress(src[:131072], 0)
+        rc2, u2, o2, _ = s.compress(src[131072:], 1)
+        assert rc1 == A.QZ_OK and rc2 == A.QZ_OK and zlib.decompress(o1 + o2) == src
+        bad = bytearray(o1 + o2); bad[-1] ^= 1
+        rc, _, _ = s.decompress(bytes(bad), len(src) + 16)
+        assert rc == A.QZ_DATA_ERROR
+        foreign = zlib.compress(src, 6)                          # another producer's zlib stream
+        rc, cused, back = s.decompress(foreign, len(src) + 16)
+        assert rc == A.QZ_OK and back == src and cused == len(foreign)
+        s.close()
+
+
+def test_async_compress2_decompress2():
+    """qzCompress2 / qzDecompress2 (src/qatzip.c:4112-4196): callback == NULL is the synchronous call; with a callback
+    the request is queued, QZ_OK comes back at once, and a library thread retires it and reports through QzResult_T"""
+    import threading
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    L = s.L
+    srcs = [datagen.gen_bytes(k, n, 40 + i) for i, (k, n) in enumerate(
+        (("silesia", 300000), ("text", 65536), ("rand", 100000), ("runs", 5000), ("lzmix", 66000), ("records", 1 << 20)))]
+    bufs_in = [C.create_string_buffer(x, len(x)) for x in srcs]
+    bufs_out = [C.create_string_buffer(len(x) * 9 // 8 + 4096) for x in srcs]
+    results = [A.QzResult() for _ in srcs]
+    done, order = threading.Event(), []
+
+    def on_done(res):
+        order.append(res.contents.cb_tag)
+        if len(order) == len(srcs):
+            done.set()
+        return 0
+    cb = A.QzAsyncCallback(on_done)
+    for i, x in enumerate(srcs):
+        results[i].cb_tag = i + 1; results[i].src_len = len(x); results[i].dest_len = len(bufs_out[i])
+        assert L.qzCompress2(C.byref(s.s), bufs_in[i], bufs_out[i], cb, C.byref(results[i])) == A.QZ_OK
+    assert done.wait(120)
+    assert order == list(range(1, len(srcs) + 1))                # retired in submission order
+    comp = []
+    for i, x in enumerate(srcs):
+        r = results[i]
+        assert r.status == A.QZ_OK and r.src_len == len(x)
+        comp.append(bufs_out[i].raw[:r.dest_len])
+        assert comp[i] == O.sw_compress("GZIP_EXT", x, 65536, 1, cap=len(x) * 9 // 8 + 65536)[2]
+    # decompress: one asynchronous request, one synchronous (callback NULL)
+    done.clear(); order.clear()
+    back = C.create_string_buffer(len(srcs[0]) + 64)
+    r = A.QzResult(); r.cb_tag = 99; r.src_len = len(comp[0]); r.dest_len = len(back)
+    cin = C.create_string_buffer(comp[0], len(comp[0]))
+
+    def on_one(res):
+        done.set()
+        return 0
+    cb1 = A.QzAsyncCallback(on_one)
+    assert L.qzDecompress2(C.byref(s.s), cin, back, cb1, C.byref(r)) == A.QZ_OK
+    assert done.wait(120) and r.status == A.QZ_OK and back.raw[:r.dest_len] == srcs[0] and r.src_len == len(comp[0])
+    r2 = A.QzResult(); r2.src_len = len(comp[1]); r2.dest_len = len(back)
+    cin2 = C.create_string_buffer(comp[1], len(comp[1]))
+    assert L.qzDecompress2(C.byref(s.s), cin2, back, None, C.byref(r2)) == A.QZ_OK
+    assert r2.status == A.QZ_OK and back.raw[:r2.dest_len] == srcs[1]
+    assert L.qzCompress2(C.byref(s.s), cin2, back, None, None) == A.QZ_PARAMS
+    s.close()                                                    # teardown waits for the queue of this session
+
+
 def test_crc_known_answer_like_reference_test():
     # test/main.c:4283-4337: qzCompressCrc's crc == zlib crc32(src) for 64 KB and 1023 B
     s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)

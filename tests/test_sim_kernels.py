@@ -117,3 +117,16 @@ def test_lane_kernels_match_oracle(sim):
             sim.sim_inflate_lane(cbuf.ctypes.data, obuf.ctypes.data, sa.ctypes.data, res.ctypes.data, len(segs))
             assert bytes(obuf[:n]) == src and (res["status"] >= 0).all(), (kind, n, chunk)
             assert [int(r["in_used"]) for r in res] == [len(pc) for pc in pieces]
+
+
+def test_adler_chunks_kernel(sim):
+    """the DEFLATE_ZLIB trailer checksum: per-chunk Adler-32 on the emulator against zlib.adler32"""
+    sim.sim_adler.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    for kind, n, chunk in (("rand", 0, 65536), ("rand", 1, 65536), ("text", 255, 1024), ("silesia", 200001, 65536),
+                           ("allA", 524288, 524288), ("rand", 70000, 16384)):
+        src = datagen.gen_bytes(kind, n, 4) if kind != "allA" else b"\xff" * n
+        nch = max(1, (n + chunk - 1) // chunk)
+        out = np.zeros(nch, np.uint32)
+        sim.sim_adler(src, n, chunk, out.ctypes.data)
+        for i in range(nch):
+            assert out[i] == zlib.adler32(src[i * chunk:(i + 1) * chunk]), (kind, n, chunk, i)
