@@ -593,6 +593,58 @@ static int parse_header(int fmt, const unsigned char *p, uint32_t n, uint32_t *e
     return pos <= n ? (int)pos : QZ_DATA_ERROR;
 }
 
+/* Streams written by the reference's HARDWARE path (and by per-chunk callers of either path) are one gzip-ext member
+ * per hw_buff_sz chunk, each header carrying both sizes (qzGzipHeaderGen, src/qatzip_gzip.c:86-118; the engine walks
+ * them the same way in checkHeader, src/qatzip_utils.c:1232-1345).  The member boundaries are therefore known without
+ * decoding anything: hop header to header on the host, then inflate every member as one segment of a single launch and
+ * check all trailers with one CRC launch - the batch the QAT engine keeps in flight, made as wide as the call.
+ * Returns the number of members done (0 = not this kind of stream, the member loop takes over), < 0 on error. */
+static int decompress_sized_members(Sess *s, const unsigned char *src, uint32_t n, uint32_t cap, uint32_t *ti_out,
+                                    uint32_t *to_out, unsigned long *crc)
+{
+    struct Mem { uint32_t pay, csz, usz; };
+    std::vector<Mem> mem;
+    uint32_t pos = 0; uint64_t out = 0;
+    while (pos < n) {
+        uint32_t es = 0, ed = 0;
+        const int hl = parse_header(F_GZIP_EXT, src + pos, n - pos, &es, &ed);
+        if (hl < 0 || es == 0 || ed == 0) break;                    /* not a sized member (e.g. a software-path stream) */
+        if ((uint64_t)pos + hl + ed + 8 > n) break;                 /* cut short: the caller comes back with more */
+        if (out + es > cap) break;                                  /* destination full: whole members only */
+        Mem m = { pos + (uint32_t)hl, ed, es };
+        mem.push_back(m);
+        pos += (uint32_t)hl + ed + 8; out += es;
+    }
+    if (mem.size() < 2) return 0;
+    const uint32_t nm = (uint32_t)mem.size();
+    std::vector<qzd_infseg> segs(nm);
+    std::vector<qzd_infres> res(nm);
+    std::vector<qzd_range> rg(nm);
+    std::vector<uint32_t> c32(nm);
+    uint64_t oo = 0;
+    for (uint32_t i = 0; i < nm; i++) {
+        segs[i].in_off = mem[i].pay; segs[i].in_len = mem[i].csz; segs[i].out_off = oo; segs[i].out_cap = mem[i].usz;
+        segs[i].flags = 0; segs[i].pad = 0;
+        rg[i].off = oo; rg[i].len = mem[i].usz; rg[i].pad = 0;
+        oo += mem[i].usz;
+    }
+    if (qzd_inflate_segments(s->ctx, s->d_in, s->d_out, segs.data(), nm, res.data()) != QZD_OK) return QZ_FAIL;
+    if (qzd_crc32_ranges(s->ctx, s->d_out, rg.data(), nm, c32.data()) != QZD_OK) return QZ_FAIL;
+    uint32_t good = 0; uint64_t to = 0;
+    for (; good < nm; good++) {
+        const Mem &m = mem[good];
+        const unsigned char *tr = src + m.pay + m.csz;
+        if (res[good].status != 0 || res[good].out_len != m.usz || res[good].in_used != m.csz) break;
+        if (rd32(tr) != c32[good] || rd32(tr + 4) != m.usz) break;
+        if (crc) *crc = (to == 0 && *crc == 0) ? c32[good] : qzd_crc32_combine((uint32_t)*crc, c32[good], m.usz);
+        to += m.usz;
+    }
+    if (good == 0) return QZ_DATA_ERROR;
+    *ti_out = mem[good - 1].pay + mem[good - 1].csz + 8;            /* end of the last good member */
+    *to_out = (uint32_t)to;
+    return (int)good;
+}
+
 static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
                               unsigned char *dest, unsigned int *dest_len, unsigned long *crc)
 {
@@ -603,6 +655,11 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
     if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
     uint32_t ti = 0, to = 0; int ret = QZ_OK;
     s->end_of_stream = 0;
+    if (fmt == F_GZIP_EXT && !s->p.stop_at_stream_end) {
+        const int done = decompress_sized_members(s, src, n, cap, &ti, &to, crc);
+        if (done < 0) { *src_len = 0; *dest_len = 0; return done; }
+        if (done > 0) s->end_of_stream = 1;
+    }
     while (ti < n && to < cap) {                                    /* member loop, src/qatzip_sw.c:415-435 */
         uint32_t es, ed;
         int hl = parse_header(fmt, src + ti, n - ti, &es, &ed);

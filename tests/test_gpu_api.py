@@ -66,6 +66,51 @@ def test_zlib_format_sessions_match_sw_path():
         s.close()
 
 
+def _hw_path_stream(src, hw):
+    """what the reference's hardware path writes: one gzip-ext member per hw_buff_sz chunk, both sizes in the header
+    (src/qatzip_gzip.c:86-143), here with zlib as the per-chunk deflate engine"""
+    out = []
+    for off in range(0, len(src), hw):
+        chunk = src[off:off + hw]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        hdr = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 255, 12, 0]) + b"QZ" + (8).to_bytes(2, "little") + \
+            len(chunk).to_bytes(4, "little") + len(body).to_bytes(4, "little")
+        out.append(hdr + body + (zlib.crc32(chunk) & 0xffffffff).to_bytes(4, "little") + len(chunk).to_bytes(4, "little"))
+    return out
+
+
+def test_hardware_path_streams_decode_as_one_batch():
+    """interop with data compressed on real QAT boxes: thousands of sized members per call, decoded by one launch"""
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    src = datagen.gen_bytes("silesia", 20 << 20, 77) + datagen.gen_bytes("rand", 100000, 1) + datagen.gen_bytes("text", 12345, 2)
+    members = _hw_path_stream(src, 65536)
+    comp = b"".join(members)
+    crc = C.c_ulong(0)
+    sl, dl = C.c_uint(len(comp)), C.c_uint(len(src) + 64)
+    dst = C.create_string_buffer(len(src) + 64)
+    rc = s.L.qzDecompressCrc(C.byref(s.s), comp, C.byref(sl), dst, C.byref(dl), C.byref(crc))
+    assert rc == A.QZ_OK and sl.value == len(comp) and dst.raw[:dl.value] == src
+    assert crc.value == (zlib.crc32(src) & 0xffffffff)
+    # destination for 100 members only: whole members, QZ_BUF_ERROR, resumable
+    rc, used, out = s.decompress(comp, 100 * 65536 + 1000)
+    assert rc == A.QZ_BUF_ERROR and out == src[:100 * 65536] and used == sum(len(m) for m in members[:100])
+    rc, used2, out2 = s.decompress(comp[used:], len(src))
+    assert rc == A.QZ_OK and out + out2 == src
+    # a damaged member in the middle: the members before it come out, the next call reports the error
+    k = 150
+    bad = bytearray(comp); pos = sum(len(m) for m in members[:k]) + 24 + 10; bad[pos] ^= 0x5a
+    rc, used, out = s.decompress(bytes(bad), len(src) + 64)
+    assert rc == A.QZ_OK and out == src[:k * 65536] and used == sum(len(m) for m in members[:k])
+    rc, _, _ = s.decompress(bytes(bad[used:]), len(src))
+    assert rc == A.QZ_DATA_ERROR
+    # stream cut inside a member
+    cut = sum(len(m) for m in members[:40]) + 5000
+    rc, used, out = s.decompress(comp[:cut], len(src))
+    assert rc == A.QZ_OK and used == sum(len(m) for m in members[:40]) and out == src[:40 * 65536]
+    s.close()
+
+
 def test_async_compress2_decompress2():
     """qzCompress2 / qzDecompress2 (src/qatzip.c:4112-4196): callback == NULL is the synchronous call; with a callback
     the request is queued, QZ_OK comes back at once, and a library thread retires it and reports through QzResult_T"""
