@@ -291,7 +291,7 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     hipLaunchKernelGGL(qzk_lz77_lane_kernel, dim3((nchunks + 63) / 64), dim3(64), 0, st, d_src, n, chunk_sz, nchunks,
                        sym_lc, sym_dist, meta, head, prev);
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
-    hipLaunchKernelGGL(qzk_huff_kernel, dim3(nchunks), dim3(QZK_HT), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist,
+    hipLaunchKernelGGL(qzk_huff_kernel, dim3(nchunks), dim3(QZK_HW), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist,
                        meta, slots, stride, last ? nchunks - 1 : ~0u, c->d_len);
     hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(nchunks), dim3(QZK_HT), 0, st, d_src, n, chunk_sz, nchunks, c->d_crc);
     HIPCHK(c, hipEventRecord(c->ev[0][2], st));
@@ -373,7 +373,7 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
-        hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn,
+        hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HW), 0, st, d_src + boff, blen, chunk_sz, bn,
                            c->sym_lc[s], c->sym_dist[s], c->meta[s], c->slots[s], stride, final_chunk,
                            c->d_len + b);
         hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn, c->d_crc + b);

@@ -1,7 +1,8 @@
 /*
  * qzk_deflate_huff.h — K2: zlib-exact block coding (trees.c behaviour) of the
- * symbol stream K1 produced, one chunk per 256-thread workgroup, gfx950.  The
- * workgroup CRC-32 routine (K6) also lives here; the chunk CRCs themselves are a
+ * symbol stream K1 produced, ONE WAVE PER CHUNK (single-wave workgroups, no
+ * workgroup barriers: the serial tree build of one chunk stalls only its own wave),
+ * gfx950.  The workgroup CRC-32 routine (K6) also lives here; the chunk CRCs are a
  * separate launch (qzk_crc_chunks_kernel) so that this kernel's LDS stays below the
  * 16 KiB a CU has left beside twelve resident K1 workgroups.
  *
@@ -12,9 +13,9 @@
  * Per block (<= 32767 symbols): parallel histogram (LDS atomics) -> lane 0
  * builds the three Huffman trees with zlib's exact heap order / tie-break /
  * overflow repair, RLE-codes the code lengths, and picks stored / fixed /
- * dynamic with zlib's byte-count rule -> all 256 lanes turn symbols into bit
- * strings, a workgroup prefix-sum gives every symbol its bit offset, and the
- * bits are OR-ed into an LDS staging tile that is flushed as whole bytes.
+ * dynamic with zlib's byte-count rule -> 64 lanes at a time turn symbols into bit
+ * strings, a wave prefix-sum gives every symbol its bit offset, and the bits are
+ * OR-ed into an LDS staging tile that is flushed as whole bytes.
  * The chunk ends with the Z_FULL_FLUSH marker (000 + pad + 00 00 FF FF) or,
  * for the last chunk of a stream, BFINAL + byte padding.
  */
@@ -48,8 +49,7 @@ typedef struct {
     /* decisions */
     uint32_t btype, max_l, max_d;
     /* output staging */
-    uint32_t stage[420];
-    uint32_t scan[8];
+    uint32_t stage[104];               /* 64 lanes x 48 bits + the pending partial byte */
 } qzk_huff_lds;
 
 QZ_DEV uint32_t qzk_bitrev(uint32_t code, int len)
@@ -258,7 +258,7 @@ QZ_DEV void qzk_plan_block(qzk_huff_lds *S, uint32_t stored_len, bool can_store)
     qzk_send_tree(S, S->len_d, max_d);
 }
 
-/* ------------------------------------------------------------------ workgroup helpers */
+/* ------------------------------------------------------------------ wave helpers */
 QZ_DEV uint32_t qzk_wave_incl_scan(uint32_t v, int lane)
 {
     for (int d = 1; d < 64; d <<= 1) {
@@ -266,20 +266,6 @@ QZ_DEV uint32_t qzk_wave_incl_scan(uint32_t v, int lane)
         if (lane >= d) v += o;
     }
     return v;
-}
-
-/* exclusive prefix sum over the 256 threads; *total = sum */
-QZ_DEV uint32_t qzk_block_excl_scan(qzk_huff_lds *S, uint32_t v, uint32_t *total)
-{
-    const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t inc = qzk_wave_incl_scan(v, lane);
-    if (lane == 63) S->scan[wv] = inc;
-    qz_block_sync();
-    uint32_t off = 0, tot = 0;
-    for (int k = 0; k < QZK_HT / 64; k++) { uint32_t s = S->scan[k]; if (k < wv) off += s; tot += s; }
-    qz_block_sync();
-    *total = tot;
-    return off + inc - v;
 }
 
 /* symbol -> (bits, nbits) with the current code tables */
@@ -310,40 +296,45 @@ QZ_DEV void qzk_sym_bits(const qzk_huff_lds *S, uint32_t lc, uint32_t dist, uint
     *val = v; *nb = n;
 }
 
-typedef struct { uint8_t *out; uint32_t nbytes; uint32_t cbits; uint32_t carry; } qzk_bitout;
+typedef struct { uint8_t *out; uint32_t nbytes; uint32_t cbits; uint32_t carry; } qzk_bitout;   /* wave-uniform */
 
-/* One workgroup-wide emission step: every thread contributes (val, nb<=48 bits). */
-QZ_DEV void qzk_emit_step(qzk_huff_lds *S, qzk_bitout *bo, uint64_t val, uint32_t nb)
+/* One wave-wide emission step: every lane contributes (val, nb <= 48 bits), in lane order.  The bits are OR-ed into
+ * an LDS tile behind the pending partial byte and the whole bytes leave as (unaligned) dwords. */
+QZ_DEV void qzk_emit_wave(qzk_huff_lds *S, qzk_bitout *bo, uint64_t val, uint32_t nb, int lane)
 {
-    const int t = (int)threadIdx.x;
-    uint32_t total;
-    uint32_t off = qzk_block_excl_scan(S, nb, &total);      /* contains two block syncs */
+    const uint32_t inc = qzk_wave_incl_scan(nb, lane);
+    const uint32_t total = qz_readlane(inc, 63);
     if (total == 0) return;
-    for (int i = t; i < 420; i += QZK_HT) S->stage[i] = i == 0 ? bo->carry : 0;
-    qz_block_sync();
+    const uint32_t tb = bo->cbits + total, nw = (tb + 31) >> 5;           /* bits / words in the tile after this step */
+    for (uint32_t i = (uint32_t)lane; i < nw + 2; i += 64) S->stage[i] = i == 0 ? bo->carry : 0;
+    qz_lds_sync();
     if (nb) {
-        uint32_t pos = bo->cbits + off, w = pos >> 5, s = pos & 31;
-        uint64_t a = val << s;
-        uint32_t hi = s ? (uint32_t)(val >> (64 - s)) : 0;
+        const uint32_t pos = bo->cbits + inc - nb, w = pos >> 5, sh = pos & 31;
+        const uint64_t a = val << sh;
+        const uint32_t hi = sh ? (uint32_t)(val >> (64 - sh)) : 0;
         atomicOr(&S->stage[w], (uint32_t)a);
         if ((uint32_t)(a >> 32)) atomicOr(&S->stage[w + 1], (uint32_t)(a >> 32));
         if (hi) atomicOr(&S->stage[w + 2], hi);
     }
-    qz_block_sync();
-    uint32_t tb = bo->cbits + total, nby = tb >> 3;
-    for (uint32_t i = (uint32_t)t; i < nby; i += QZK_HT)
-        bo->out[bo->nbytes + i] = (uint8_t)(S->stage[i >> 2] >> (8 * (i & 3)));
-    uint32_t nc = tb & 7;
-    uint32_t cw = (S->stage[nby >> 2] >> (8 * (nby & 3))) & ((1u << nc) - 1);
-    qz_block_sync();
-    bo->nbytes += nby; bo->cbits = nc; bo->carry = cw;
+    qz_lds_sync();
+    const uint32_t nby = tb >> 3;
+    uint8_t *o = bo->out + bo->nbytes;
+    for (uint32_t i = 4u * (uint32_t)lane; i < nby; i += 256) {
+        const uint32_t v = S->stage[i >> 2];
+        if (i + 4 <= nby) ((qz_u32u *)(o + i))->v = v;
+        else for (uint32_t k = 0; i + k < nby; k++) o[i + k] = (uint8_t)(v >> (8 * k));
+    }
+    const uint32_t nc = tb & 7;
+    const uint32_t cw = (S->stage[nby >> 2] >> (8 * (nby & 3))) & ((1u << nc) - 1);
+    qz_lds_sync();                                                        /* the tile is rewritten by the next step */
+    bo->nbytes += nby; bo->cbits = nc; bo->carry = qz_readfirstlane(cw);
 }
 
 /* flush the partial byte (bi_windup) */
-QZ_DEV void qzk_align(qzk_bitout *bo)
+QZ_DEV void qzk_align(qzk_bitout *bo, int lane)
 {
     if (bo->cbits) {
-        if (threadIdx.x == 0) bo->out[bo->nbytes] = (uint8_t)bo->carry;
+        if (lane == 0) bo->out[bo->nbytes] = (uint8_t)bo->carry;
         bo->nbytes++; bo->cbits = 0; bo->carry = 0;
     }
 }
@@ -442,13 +433,14 @@ QZ_DEV uint32_t qzk_block_crc32(qzk_crc_lds *S, const uint8_t *src, uint32_t n)
 }
 
 /* ------------------------------------------------------------------ the kernel */
+#define QZK_HW 64                  /* threads per workgroup of K2: one wave per chunk, no workgroup barriers */
 QZ_KERNEL qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                           const uint8_t *sym_lc, const uint16_t *sym_dist, const qzk_lzmeta *meta,
                           uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk /* index or ~0u */,
                           uint32_t *out_len)
 {
     QZ_LDS qzk_huff_lds S;
-    const int t = (int)threadIdx.x;
+    const int lane = qz_lane();
     const uint32_t chunk = blockIdx.x;
     if (chunk >= nchunks) return;
     const uint64_t coff = (uint64_t)chunk * chunk_sz;
@@ -472,10 +464,10 @@ QZ_KERNEL qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
         const uint32_t be = b < nfull ? mt->bstart[b + 1 < QZK_MAXBLK ? b + 1 : QZK_MAXBLK - 1] : n;
         const uint32_t last = (is_final && b == nblocks - 1) ? 1u : 0u;
 
-        for (int i = t; i < 288; i += QZK_HT) S.fl[i] = 0;
-        if (t < 32) S.fd[t] = 0;
-        qz_block_sync();
-        for (uint32_t i = s0 + (uint32_t)t; i < s1; i += QZK_HT) {
+        for (int i = lane; i < 288; i += QZK_HW) S.fl[i] = 0;
+        if (lane < 32) S.fd[lane] = 0;
+        qz_lds_sync();
+        for (uint32_t i = s0 + (uint32_t)lane; i < s1; i += QZK_HW) {
             uint32_t lc = lcs[i], dist = dists[i];
             if (dist == 0) atomicAdd(&S.fl[lc], 1u);
             else {
@@ -487,56 +479,56 @@ QZ_KERNEL qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_s
                 atomicAdd(&S.fd[dcode], 1u);
             }
         }
-        qz_block_sync();
-        if (t == 0) {
+        qz_lds_sync();
+        if (lane == 0) {                                /* zlib's trees are built serially; other waves fill the CU meanwhile */
             S.fl[256] = 1;
             qzk_plan_block(&S, be - bs, (cs >> b) & 1);
         }
-        qz_block_sync();
+        qz_lds_sync();
         const uint32_t btype = S.btype;
 
         /* 3-bit block header */
-        qzk_emit_step(&S, &bo, t == 0 ? (uint64_t)((btype << 1) | last) : 0, t == 0 ? 3 : 0);
+        qzk_emit_wave(&S, &bo, lane == 0 ? (uint64_t)((btype << 1) | last) : 0, lane == 0 ? 3 : 0, lane);
 
         if (btype == 0) {
             const uint32_t slen = be - bs;
-            qzk_align(&bo);
-            if (t < 4) {
-                uint32_t v = t < 2 ? slen : ~slen;
-                bo.out[bo.nbytes + (uint32_t)t] = (uint8_t)(v >> (8 * (t & 1)));
+            qzk_align(&bo, lane);
+            if (lane < 4) {
+                uint32_t v = lane < 2 ? slen : ~slen;
+                bo.out[bo.nbytes + (uint32_t)lane] = (uint8_t)(v >> (8 * (lane & 1)));
             }
-            for (uint32_t i = (uint32_t)t; i < slen; i += QZK_HT) bo.out[bo.nbytes + 4 + i] = in[bs + i];
+            for (uint32_t i = (uint32_t)lane; i < slen; i += QZK_HW) bo.out[bo.nbytes + 4 + i] = in[bs + i];
             bo.nbytes += 4 + slen;
         } else {
             if (btype == 2) {
                 const uint32_t hb = S.hbits, hw = (hb + 31) >> 5;
-                for (uint32_t w0 = 0; w0 < hw; w0 += QZK_HT) {
-                    uint32_t w = w0 + (uint32_t)t, nb = 0; uint64_t v = 0;
+                for (uint32_t w0 = 0; w0 < hw; w0 += QZK_HW) {
+                    uint32_t w = w0 + (uint32_t)lane, nb = 0; uint64_t v = 0;
                     if (w < hw) { nb = (w + 1) * 32 <= hb ? 32 : hb - w * 32; v = S.hdr[w] & (nb == 32 ? 0xffffffffu : ((1u << nb) - 1)); }
-                    qzk_emit_step(&S, &bo, v, nb);
+                    qzk_emit_wave(&S, &bo, v, nb, lane);
                 }
             }
-            for (uint32_t i0 = s0; i0 < s1; i0 += QZK_HT) {
-                uint32_t i = i0 + (uint32_t)t, nb = 0; uint64_t v = 0;
+            for (uint32_t i0 = s0; i0 < s1; i0 += QZK_HW) {
+                uint32_t i = i0 + (uint32_t)lane, nb = 0; uint64_t v = 0;
                 if (i < s1) qzk_sym_bits(&S, lcs[i], dists[i], &v, &nb);
-                qzk_emit_step(&S, &bo, v, nb);
+                qzk_emit_wave(&S, &bo, v, nb, lane);
             }
             {   /* END_BLOCK */
                 uint32_t c = S.code_l[256];
-                qzk_emit_step(&S, &bo, t == 0 ? (uint64_t)(c & 0xffff) : 0, t == 0 ? c >> 16 : 0);
+                qzk_emit_wave(&S, &bo, lane == 0 ? (uint64_t)(c & 0xffff) : 0, lane == 0 ? c >> 16 : 0, lane);
             }
         }
-        qz_block_sync();
+        qz_lds_sync();
     }
-    if (is_final) qzk_align(&bo);
+    if (is_final) qzk_align(&bo, lane);
     else {
         /* Z_FULL_FLUSH: empty stored block */
-        qzk_emit_step(&S, &bo, 0, t == 0 ? 3 : 0);
-        qzk_align(&bo);
-        if (t < 4) bo.out[bo.nbytes + (uint32_t)t] = t < 2 ? 0x00 : 0xff;
+        qzk_emit_wave(&S, &bo, 0, lane == 0 ? 3 : 0, lane);
+        qzk_align(&bo, lane);
+        if (lane < 4) bo.out[bo.nbytes + (uint32_t)lane] = lane < 2 ? 0x00 : 0xff;
         bo.nbytes += 4;
     }
-    if (t == 0) out_len[chunk] = bo.nbytes;
+    if (lane == 0) out_len[chunk] = bo.nbytes;
 }
 
 #endif

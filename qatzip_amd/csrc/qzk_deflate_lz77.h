@@ -39,7 +39,7 @@
 #define QZK_MAXINS 4
 #define QZK_HSIZE 65536            /* zlib hash_bits 16 at memLevel 9 */
 #define QZK_NSLOT 512
-#define QZK_RING 8192              /* bytes of recent input kept in LDS by the prev-in-HBM variant */
+#define QZK_RING 4096              /* bytes of recent input kept in LDS by the prev-in-HBM variant */
 #define QZK_RINGW (QZK_RING / 4)
 
 #if defined(QZK_PROF) && !defined(QZ_SIM)

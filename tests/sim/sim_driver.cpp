@@ -51,7 +51,7 @@ static int deflate_variant(int variant, const uint8_t *src, uint64_t n, uint32_t
     std::vector<uint8_t> slots((size_t)nchunks * stride);
     std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
     run_k1(variant, 2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data());
-    sim::launch(nchunks, QZK_HT, 0, [&] {
+    sim::launch(nchunks, QZK_HW, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
                         last ? nchunks - 1 : ~0u, olen.data());
     });
@@ -91,7 +91,7 @@ int sim_deflate_lane(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last
     sim::launch((nchunks + 63) / 64, 64, 0, [&] {
         qzk_lz77_lane_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), head.data(), prev.data());
     });
-    sim::launch(nchunks, QZK_HT, 0, [&] {
+    sim::launch(nchunks, QZK_HW, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
                         last ? nchunks - 1 : ~0u, olen.data());
     });
