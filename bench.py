@@ -84,7 +84,9 @@ def main():
     import datagen
     import qatzip_amd
 
-    ctx = qatzip_amd.Context(local)
+    # one process per GPU: LOCAL_RANK picks the device (QATZIP_AMD_BENCH_DEVICE overrides it, for exercising the
+    # multi-rank path on a box with fewer GPUs than ranks)
+    ctx = qatzip_amd.Context(int(os.environ.get("QATZIP_AMD_BENCH_DEVICE", local)))
     total = args.mb << 20
     base_n = min(args.base_mb << 20, total)
     base = datagen.gen("silesia", base_n, 20250523 + rank)

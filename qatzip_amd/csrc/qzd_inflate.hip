@@ -30,9 +30,10 @@
 #include "qzk_inflate_lane.h"
 #include "qzk_checksum.h"
 
-/* a lane needs ~60 ms per 64 KB segment whatever the segment count, the wave kernel does ~300 segments/ms
- * (bound by the CUs' scalar units): lanes win from ~18 000 segments on (measured) */
-#define QZD_LANE_MIN_SEGS 20000u
+/* the two-phase path needs ~28 + 5 ms per 64 KB segment per lane whatever the segment count (phase A is bound by
+ * a lone wave's instruction latency), the wave kernel does ~300 segments/ms (bound by the CUs' scalar units): the
+ * two phases win from ~8 000 segments on (measured) */
+#define QZD_LANE_MIN_SEGS 8000u
 #define QZD_LANE_SEGS_PER_WAVE 32u
 
 /* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF */
