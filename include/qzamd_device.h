@@ -82,6 +82,8 @@ int qzd_last_timing(qzd_ctx *ctx, float ms[4]);
  *
  * Segment records shared with the kernels (see qatzip_amd/csrc/qzk_inflate.h):
  *   qzd_infseg { u64 in_off; u64 out_off; u32 in_len; u32 out_cap; u32 flags; u32 pad; }
+ *     pad: optional hint, the compressed length of the segment when in_len is only an upper bound (0 = no hint);
+ *     with a hint the two-phase path decodes a segment with several lanes (speculative sub-segment decoding)
  *   qzd_infres { i32 status; u32 in_used; u32 out_len; u32 nblocks; }
  * status: 0 = ended with BFINAL, 1 = ended at a flush marker, <0 = error
  * (-1 data, -2 output capacity, -3 input exhausted, -4 needs earlier history).

@@ -624,7 +624,7 @@ static int decompress_sized_members(Sess *s, const unsigned char *src, uint32_t 
     uint64_t oo = 0;
     for (uint32_t i = 0; i < nm; i++) {
         segs[i].in_off = mem[i].pay; segs[i].in_len = mem[i].csz; segs[i].out_off = oo; segs[i].out_cap = mem[i].usz;
-        segs[i].flags = 0; segs[i].pad = 0;
+        segs[i].flags = 0; segs[i].pad = mem[i].csz;               /* exact compressed length: lets phase A split it */
         rg[i].off = oo; rg[i].len = mem[i].usz; rg[i].pad = 0;
         oo += mem[i].usz;
     }

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include "qzk_inflate.h"
 #include "qzk_inflate_lane.h"
+#include "qzk_inflate_spec.h"
 #include "qzk_checksum.h"
 
 /* the two-phase path needs ~28 + 5 ms per 64 KB segment per lane whatever the segment count (phase A is bound by
@@ -35,6 +36,11 @@
  * two phases win from ~8 000 segments on (measured) */
 #define QZD_LANE_MIN_SEGS 8000u
 #define QZD_LANE_SEGS_PER_WAVE 32u
+/* sub-decoders per segment of phase A.  1 = the serial phase A.  The speculative one (2, 4, 8; QATZIP_AMD_INFLATE_K)
+ * decodes compressible segments K times faster, but blocks of near-equal code lengths (incompressible data that still
+ * got Huffman-coded) never let a misaligned decoder fall into step, so those segments come back to the serial kernel
+ * and set the pace: on the bench data 13 % of the segments do, and the serial phase A alone is faster */
+#define QZD_SPEC_LANES 1u
 
 /* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF */
 __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list, uint32_t cap, uint32_t *count)
@@ -48,76 +54,139 @@ __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list
     }
 }
 
+/* Two-phase inflate of nsegs segments (qzk_inflate_lane.h / qzk_inflate_spec.h).  K == 1: one lane decodes a whole
+ * segment; K > 1: K lanes per segment decode speculatively, and whatever that kernel hands back (QZK_INF_ESPEC: stored
+ * or several blocks, bad data, ...) goes through the K == 1 launch afterwards.  h_res receives every result. */
+static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qzk_infseg *hs, uint32_t nsegs,
+                     qzk_infres *h_res, uint32_t K, hipStream_t st)
+{
+    const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
+    int rc = qzd_aux_reserve(c, sb + rb + 64);
+    if (rc) return rc;
+    qzk_infseg *d_segs = (qzk_infseg *)c->d_aux;
+    qzk_infres *d_res = (qzk_infres *)(c->d_aux + ((sb + 15) & ~(size_t)15));
+    std::vector<qzk_tokseg> tsv((size_t)nsegs * K);
+    uint64_t lit_total = 0, seq_total = 0;
+    for (uint32_t i = 0; i < nsegs; i++) {
+        const bool writes = !(hs[i].flags & QZK_INF_COUNT_ONLY);
+        const uint64_t lc = !writes ? 0 : K == 1 ? QZK_TOK_LITCAP(hs[i].out_cap) : QZK_SPEC_LITCAP(hs[i].out_cap, K);
+        const uint64_t sc = !writes ? 0 : K == 1 ? QZK_TOK_SEQCAP(hs[i].out_cap) : QZK_SPEC_SEQCAP(hs[i].out_cap, K);
+        for (uint32_t j = 0; j < K; j++) {
+            tsv[(size_t)i * K + j].lit_off = lit_total; tsv[(size_t)i * K + j].seq_off = seq_total;
+            lit_total += lc; seq_total += sc;
+        }
+    }
+    const size_t tabb = ((size_t)nsegs * sizeof(qzk_inf_tab) + 255) & ~(size_t)255;
+    const size_t tsb = ((size_t)nsegs * K * sizeof(qzk_tokseg) + 255) & ~(size_t)255;
+    const size_t chb = ((size_t)nsegs * sizeof(qzk_chain) + 255) & ~(size_t)255;
+    const size_t rcb = K == 1 ? 0 : (((size_t)nsegs * K * QZK_SPEC_NREC * sizeof(qzk_rec) + 255) & ~(size_t)255);
+    const size_t litb = (lit_total + 511) & ~(uint64_t)255, seqb = seq_total * sizeof(qzk_seq);
+    const size_t need = tabb + tsb + chb + rcb + litb + seqb + 256;
+    if (need > c->big_cap) {
+        hipDeviceSynchronize();
+        if (c->d_big) hipFree(c->d_big);
+        c->d_big = NULL; c->big_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_big, need));
+        c->big_cap = need;
+    }
+    uint8_t *pb = c->d_big;
+    qzk_inf_tab *tb_d = (qzk_inf_tab *)pb; pb += tabb;
+    qzk_tokseg *ts_d = (qzk_tokseg *)pb; pb += tsb;
+    qzk_chain *ch_d = (qzk_chain *)pb; pb += chb;
+    qzk_rec *rec_d = (qzk_rec *)pb; pb += rcb;
+    uint8_t *lit_d = pb; pb += litb;
+    qzk_seq *seq_d = (qzk_seq *)pb;
+    HIPCHK(c, hipMemcpyAsync(d_segs, hs, sb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(ts_d, tsv.data(), tsv.size() * sizeof(qzk_tokseg), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev[1][1], st));
+    if (K == 1) {
+        /* segments per single-wave workgroup: each lane keeps 1.25 KiB of root tables in LDS, and partly filled waves
+         * give the serial decode loops more waves to hide behind (measured in DESIGN.md K3b) */
+        uint32_t lpw = QZD_LANE_SEGS_PER_WAVE;
+        const char *le = getenv("QATZIP_AMD_INFLATE_LPW");
+        if (le) { int v = atoi(le); if (v == 8 || v == 16 || v == 32 || v == 64) lpw = (uint32_t)v; }
+        const dim3 grid((nsegs + lpw - 1) / lpw), blk(lpw);
+#define QZD_TOK_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_tok_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
+                                            ts_d, lit_d, seq_d, ch_d)
+        if (lpw == 8) QZD_TOK_LAUNCH(8); else if (lpw == 16) QZD_TOK_LAUNCH(16); else if (lpw == 64) QZD_TOK_LAUNCH(64); else QZD_TOK_LAUNCH(32);
+#undef QZD_TOK_LAUNCH
+    } else {
+        const uint32_t spw = 64 / K;
+        const dim3 grid((nsegs + spw - 1) / spw), blk(64);
+#define QZD_SPEC_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_spec_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
+                                             ts_d, lit_d, seq_d, ch_d, rec_d)
+        if (K == 2) QZD_SPEC_LAUNCH(2); else if (K == 4) QZD_SPEC_LAUNCH(4); else QZD_SPEC_LAUNCH(8);
+#undef QZD_SPEC_LAUNCH
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1][0], st));
+    hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
+                       d_comp, d_out, d_segs, d_res, nsegs, ts_d, K, lit_d, seq_d, ch_d);
+    HIPCHK(c, hipEventRecord(c->ev[1][2], st));
+    HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    float t = 0;
+    if (hipEventElapsedTime(&t, c->ev[1][0], c->ev[1][2]) == hipSuccess) c->inf_ms[2] += t;     /* phase B share */
+    if (K == 1) return QZD_OK;
+    /* the segments the speculative kernel handed back */
+    std::vector<uint32_t> redo;
+    for (uint32_t i = 0; i < nsegs; i++) if (h_res[i].status == QZK_INF_ESPEC) redo.push_back(i);
+    if (getenv("QATZIP_AMD_TRACE")) {
+        uint32_t hist[64] = {0};
+        for (uint32_t i : redo) hist[h_res[i].nblocks < 64 ? h_res[i].nblocks : 63]++;
+        fprintf(stderr, "[two_phase] K=%u: %zu of %u segments handed back to the serial kernel; reasons:", K, redo.size(), nsegs);
+        for (int k = 0; k < 64; k++) if (hist[k]) fprintf(stderr, " %d:%u", k, hist[k]);
+        fprintf(stderr, "\n");
+    }
+    if (redo.empty()) return QZD_OK;
+    std::vector<qzk_infseg> rs(redo.size());
+    std::vector<qzk_infres> rr(redo.size());
+    for (size_t i = 0; i < redo.size(); i++) rs[i] = hs[redo[i]];
+    rc = two_phase(c, d_comp, d_out, rs.data(), (uint32_t)redo.size(), rr.data(), 1, st);
+    if (rc) return rc;
+    for (size_t i = 0; i < redo.size(); i++) h_res[redo[i]] = rr[i];
+    return QZD_OK;
+}
+
 extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const void *h_segs,
                                     uint32_t nsegs, void *h_res)
 {
     if (!c || !h_segs || !h_res) return QZD_ERR_PARAM;
     if (nsegs == 0) return QZD_OK;
     hipSetDevice(c->device);
-    const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
-    int rc = qzd_aux_reserve(c, sb + rb + 64);
-    if (rc) return rc;
-    qzk_infseg *d_segs = (qzk_infseg *)c->d_aux;
-    qzk_infres *d_res = (qzk_infres *)(c->d_aux + ((sb + 15) & ~(size_t)15));
     hipStream_t st = c->st[0];
-    HIPCHK(c, hipMemcpyAsync(d_segs, h_segs, sb, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipEventRecord(c->ev[0][0], st));
-    /* few segments: one wave each (a segment finishes sooner); thousands: one LANE each (the wave-per-segment
-     * kernel is bound by the CU's scalar unit, K3b spreads the serial work over the vector lanes) */
+    const qzk_infseg *hs = (const qzk_infseg *)h_segs;
+    /* few segments: one wave each; thousands: the two-phase path (the wave-per-segment kernel is bound by the CU's
+     * scalar unit, the lane kernels spread the serial work over the vector lanes) */
     const char *force = getenv("QATZIP_AMD_INFLATE");
     const bool lanes = force ? force[0] == 'l' : nsegs >= QZD_LANE_MIN_SEGS;
-    std::vector<qzk_tokseg> tsv;                /* outlives the stream sync below: its async upload reads it */
+    HIPCHK(c, hipEventRecord(c->ev[0][0], st));
     if (lanes) {
-        /* two phases (qzk_inflate_lane.h): A decodes into per-segment literal streams + sequence records, B resolves */
-        const qzk_infseg *hs = (const qzk_infseg *)h_segs;
-        tsv.resize(nsegs);
-        uint64_t lit_total = 0, seq_total = 0;
-        for (uint32_t i = 0; i < nsegs; i++) {
-            tsv[i].lit_off = lit_total; tsv[i].seq_off = seq_total;
-            if (!(hs[i].flags & QZK_INF_COUNT_ONLY)) { lit_total += QZK_TOK_LITCAP(hs[i].out_cap); seq_total += QZK_TOK_SEQCAP(hs[i].out_cap); }
-        }
-        const size_t tabb = ((size_t)nsegs * sizeof(qzk_inf_tab) + 255) & ~(size_t)255;
-        const size_t tsb = ((size_t)nsegs * sizeof(qzk_tokseg) + 255) & ~(size_t)255;
-        const size_t nsb = ((size_t)nsegs * 4 + 255) & ~(size_t)255;
-        const size_t litb = (lit_total + 255) & ~(uint64_t)255, seqb = seq_total * sizeof(qzk_seq);
-        const size_t need = tabb + tsb + nsb + litb + seqb + 256;
-        if (need > c->big_cap) {
-            hipDeviceSynchronize();
-            if (c->d_big) hipFree(c->d_big);
-            c->d_big = NULL; c->big_cap = 0;
-            HIPCHK(c, hipMalloc(&c->d_big, need));
-            c->big_cap = need;
-        }
-        uint8_t *pb = c->d_big;
-        qzk_inf_tab *tb_d = (qzk_inf_tab *)pb; pb += tabb;
-        qzk_tokseg *ts_d = (qzk_tokseg *)pb; pb += tsb;
-        uint32_t *ns_d = (uint32_t *)pb; pb += nsb;
-        uint8_t *lit_d = pb; pb += litb;
-        qzk_seq *seq_d = (qzk_seq *)pb;
-        HIPCHK(c, hipMemcpyAsync(ts_d, tsv.data(), (size_t)nsegs * sizeof(qzk_tokseg), hipMemcpyHostToDevice, st));
-        /* segments per single-wave workgroup of phase A: each lane keeps 1.25 KiB of root tables in LDS, and partly
-         * filled waves give the serial decode loops more waves to hide behind (measured in DESIGN.md §K3b) */
-        uint32_t lpw = QZD_LANE_SEGS_PER_WAVE;
-        const char *le = getenv("QATZIP_AMD_INFLATE_LPW");
-        if (le) { int v = atoi(le); if (v == 8 || v == 16 || v == 32 || v == 64) lpw = (uint32_t)v; }
-        const dim3 grid((nsegs + lpw - 1) / lpw), blk(lpw);
-#define QZD_TOK_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_tok_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
-                                            ts_d, lit_d, seq_d, ns_d)
-        if (lpw == 8) QZD_TOK_LAUNCH(8); else if (lpw == 16) QZD_TOK_LAUNCH(16); else if (lpw == 64) QZD_TOK_LAUNCH(64); else QZD_TOK_LAUNCH(32);
-#undef QZD_TOK_LAUNCH
-        HIPCHK(c, hipEventRecord(c->ev[1][0], st));
-        hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
-                           d_out, d_segs, d_res, nsegs, ts_d, lit_d, seq_d, ns_d);
-    } else
-    hipLaunchKernelGGL(qzk_inflate_kernel, dim3((nsegs + QZK_INF_WAVES - 1) / QZK_INF_WAVES), dim3(64 * QZK_INF_WAVES),
-                       0, st, d_comp, d_out, d_segs, d_res, nsegs);
+        /* speculative sub-segment decoding needs a length hint (qzd_infseg.pad) and segments that write output */
+        uint32_t K = QZD_SPEC_LANES;
+        const char *ke = getenv("QATZIP_AMD_INFLATE_K");
+        if (ke) { int v = atoi(ke); if (v == 1 || v == 2 || v == 4 || v == 8) K = (uint32_t)v; }
+        for (uint32_t i = 0; i < nsegs && K > 1; i++)
+            if ((hs[i].flags & (QZK_INF_COUNT_ONLY | QZK_INF_THROUGH_FLUSH)) || hs[i].pad == 0) K = 1;
+        int rc = two_phase(c, d_comp, d_out, hs, nsegs, (qzk_infres *)h_res, K, st);
+        if (rc) return rc;
+    } else {
+        const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
+        int rc = qzd_aux_reserve(c, sb + rb + 64);
+        if (rc) return rc;
+        qzk_infseg *d_segs = (qzk_infseg *)c->d_aux;
+        qzk_infres *d_res = (qzk_infres *)(c->d_aux + ((sb + 15) & ~(size_t)15));
+        HIPCHK(c, hipMemcpyAsync(d_segs, h_segs, sb, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(qzk_inflate_kernel, dim3((nsegs + QZK_INF_WAVES - 1) / QZK_INF_WAVES), dim3(64 * QZK_INF_WAVES),
+                           0, st, d_comp, d_out, d_segs, d_res, nsegs);
+        HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
-    HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipGetLastError());
     float t = 0;
     if (hipEventElapsedTime(&t, c->ev[0][0], c->ev[0][1]) == hipSuccess) c->inf_ms[0] += t;
-    if (lanes && hipEventElapsedTime(&t, c->ev[1][0], c->ev[0][1]) == hipSuccess) c->inf_ms[2] += t;   /* phase B share */
     return QZD_OK;
 }
 
@@ -224,9 +293,11 @@ static int inflate_grouped(qzd_ctx *c, const uint8_t *d_src, uint8_t *d_dst, std
         const uint32_t NB = 8192;
         std::vector<uint32_t> cnt(NB + 1, 0);
         auto cls = [&](uint32_t k) { uint32_t v = clen(k) >> 5; return v < NB ? v : NB - 1; };
-        for (uint32_t i = 0; i < ns; i++) cnt[cls(i) + 1]++;
+        /* largest first: the segments with the most symbols are the critical path, so their waves start first */
+        auto rcls = [&](uint32_t k) { return NB - 1 - cls(k); };
+        for (uint32_t i = 0; i < ns; i++) cnt[rcls(i) + 1]++;
         for (uint32_t i = 0; i < NB; i++) cnt[i + 1] += cnt[i];
-        for (uint32_t i = 0; i < ns; i++) order[cnt[cls(i)]++] = i;
+        for (uint32_t i = 0; i < ns; i++) order[cnt[rcls(i)]++] = i;
     }
     std::vector<qzk_infseg> ps(ns);
     std::vector<qzk_infres> pr(ns);
@@ -283,7 +354,8 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
             segs[k].in_off = start[k]; segs[k].in_len = (uint32_t)(n - start[k]);
             segs[k].out_off = oo < dst_cap ? oo : dst_cap;
             segs[k].out_cap = (uint32_t)std::min<uint64_t>(seg_hint, dst_cap - segs[k].out_off);
-            segs[k].flags = 0; segs[k].pad = 0;
+            segs[k].flags = 0;
+            segs[k].pad = (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k];     /* compressed-length hint for phase A */
         }
         lap("segment records");
         rc = inflate_grouped(c, d_src, d_dst, segs, res, start, n);
@@ -314,7 +386,7 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
             const qzk_infres &r = res[k];
             if (r.status != QZK_INF_FINAL && r.status != QZK_INF_FLUSH) { ok = false; break; }
             qzk_infseg s = segs[k];
-            s.flags = 0; s.out_off = oo; s.out_cap = r.out_len; s.in_len = r.in_used;
+            s.flags = 0; s.out_off = oo; s.out_cap = r.out_len; s.in_len = r.in_used; s.pad = r.in_used;
             if (oo + r.out_len > dst_cap) return QZD_ERR_DSTCAP;
             chain.push_back(s);
             oo += r.out_len;

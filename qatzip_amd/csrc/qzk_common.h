@@ -15,12 +15,19 @@
 #include "hipsim.h"
 #define QZ_DEV static inline
 #define QZ_KERNEL static void
+#define QZ_KERNEL_MAX(n) static void
+#define QZ_KERNEL_OCC(n, w) static void
 #define QZ_LDS static
 #define QZ_CONST static const
 #else
 #include <hip/hip_runtime.h>
 #define QZ_DEV static __device__ __forceinline__
 #define QZ_KERNEL static __global__ void   /* internal linkage: kernels live in headers shared by several .hip units */
+/* a kernel that is only ever launched with <= n threads per workgroup: without the bound the compiler budgets VGPRs for
+ * 1024-thread workgroups (128 per lane) and spills the rest to scratch */
+#define QZ_KERNEL_MAX(n) static __global__ void __launch_bounds__(n)
+/* ... and that should keep at least w waves per SIMD resident (the compiler caps the VGPRs accordingly) */
+#define QZ_KERNEL_OCC(n, w) static __global__ void __launch_bounds__(n, w)
 #define QZ_LDS __shared__
 #define QZ_CONST static __device__ const
 

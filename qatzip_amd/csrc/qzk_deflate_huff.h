@@ -434,7 +434,7 @@ QZ_DEV uint32_t qzk_block_crc32(qzk_crc_lds *S, const uint8_t *src, uint32_t n)
 
 /* ------------------------------------------------------------------ the kernel */
 #define QZK_HW 64                  /* threads per workgroup of K2: one wave per chunk, no workgroup barriers */
-QZ_KERNEL qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
+QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                           const uint8_t *sym_lc, const uint16_t *sym_dist, const qzk_lzmeta *meta,
                           uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk /* index or ~0u */,
                           uint32_t *out_len)

@@ -466,7 +466,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
  * warm in L2/MALL - and uneven chunks balance themselves.  head_slots: (slot_base + blockIdx.x) * 128 KiB;
  * prev_slots (HBM variant only): blockIdx.x * 64 KiB. */
 template <bool PL>
-QZ_KERNEL qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
+QZ_KERNEL_MAX(64) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                                uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint16_t *head_slots,
                                uint16_t *prev_slots, uint32_t slot_base, uint32_t *counter)
 {

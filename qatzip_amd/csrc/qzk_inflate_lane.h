@@ -125,6 +125,14 @@ QZ_DEV void qzk_st64u(uint8_t *p, uint64_t v) { ((qz_u64u *)p)->v = v; }
 /* phase A -> phase B hand-over, per segment: literal bytes + sequence records */
 typedef struct { uint32_t litrun; uint16_t mlen; uint16_t dm1; } qzk_seq;      /* mlen 0: literals only (tail) */
 typedef struct { uint64_t lit_off; uint64_t seq_off; } qzk_tokseg;             /* bytes into lits / records into seqs */
+/* what phase B stitches together for one segment: pieces of sub-streams, in output order.  The serial phase A
+ * leaves one piece (the whole stream); the speculative one (qzk_inflate_spec.h) up to one per sub-decoder. */
+#define QZK_SPEC_MAXK 8
+#define QZK_INF_ESPEC (-6)         /* speculative phase A could not finish this segment: decode it serially */
+#define QZK_PIECE_RAW 0xffffffffu  /* qzk_chain_el.sub: not a sub-stream but seq_count stored bytes at input offset seq_first */
+typedef struct { uint32_t sub, seq_first, seq_count, lit_first, lrun_skip; } qzk_chain_el;
+#define QZK_CHAIN_MAXEL 24        /* pieces per segment (K per Huffman block of the segment) */
+typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chain;
 /* scratch a segment needs: literals <= out_cap (+ staging slack), sequences <= out_cap / 3 (+ tail) */
 #define QZK_TOK_LITCAP(out_cap) ((((uint64_t)(out_cap) + 31) & ~(uint64_t)31) + 32)
 #define QZK_TOK_SEQCAP(out_cap) ((uint64_t)(out_cap) / 3 + 2)
@@ -250,8 +258,8 @@ typedef struct {
 QZ_DEV void qzk_tok_word(qzk_tok_out *O, uint64_t w)
 {
     if (O->lq == 3) {
-        uint64_t *d = (uint64_t *)(O->lp + O->lw);
-        d[0] = O->lq0; d[1] = O->lq1; d[2] = O->lq2; d[3] = w;
+        qz_u64u *d = (qz_u64u *)(O->lp + O->lw);       /* 32-byte aligned unless a flush intervened */
+        d[0].v = O->lq0; d[1].v = O->lq1; d[2].v = O->lq2; d[3].v = w;
         O->lw += 32; O->lq = 0;
     } else {
         O->lq0 = O->lq == 0 ? w : O->lq0; O->lq1 = O->lq == 1 ? w : O->lq1; O->lq2 = O->lq == 2 ? w : O->lq2;
@@ -294,16 +302,18 @@ QZ_DEV void qzk_tok_seq(qzk_tok_out *O, uint32_t mlen, uint32_t dm1)
     }
     O->nseq++; O->lrun = 0;
 }
-QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
+/* make everything appended so far visible in memory and leave the stream ready for more (used between the rounds
+ * of the speculative phase A); after it the literal position is no longer 32-byte aligned, which only costs speed */
+QZ_DEV void qzk_tok_flush(qzk_tok_out *O)
 {
     if (O->count_only) return;
     uint64_t *d = (uint64_t *)(O->lp + O->lw);
-    if (O->lq > 0) d[0] = O->lq0;
-    if (O->lq > 1) d[1] = O->lq1;
-    if (O->lq > 2) d[2] = O->lq2;
+    if (O->lq > 0) ((qz_u64u *)d)[0].v = O->lq0;
+    if (O->lq > 1) ((qz_u64u *)d)[1].v = O->lq1;
+    if (O->lq > 2) ((qz_u64u *)d)[2].v = O->lq2;
     O->lw += 8 * O->lq;
     for (uint32_t i = 0; i < O->ln; i++) O->lp[O->lw + i] = (uint8_t)(O->lbuf >> (8 * i));
-    if (O->lrun) qzk_tok_seq(O, 0u, 0u);
+    O->lw += O->ln; O->lq = 0; O->ln = 0; O->lbuf = 0;
     const uint32_t k = O->nseq & 7;
     d = (uint64_t *)(O->sq + (O->nseq & ~7u));
     if (k > 0) d[0] = O->s0;
@@ -315,11 +325,18 @@ QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
     if (k > 6) d[6] = O->s6;
 }
 
+QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
+{
+    if (O->count_only) return;
+    if (O->lrun) qzk_tok_seq(O, 0u, 0u);
+    qzk_tok_flush(O);
+}
+
 /* one symbol from an already refilled bit buffer; structured (no early exits) so that it compiles to predicated
  * straight-line code.  MIDREFILL: the caller's reader guarantees < 48 valid bits, refill before the distance code. */
-template <bool MIDREFILL>
+template <bool MIDREFILL, bool PAIR>
 QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, const uint16_t *lroot,
-                            const uint16_t *droot, uint64_t out_off)
+                            const uint16_t *droot, uint64_t hist)
 {
     qzk_lbits *b = &S->b;
     const uint32_t e = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
@@ -329,7 +346,19 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
     if (sym < 256) {
         if (sym < 0) { S->status = b->pos >= b->end && b->bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA; S->state = QZK_LS_DONE; }
         else if (S->op >= S->out_cap) { S->status = QZK_INF_EOUT; S->state = QZK_LS_DONE; }
-        else { qzk_tok_byte(O, (uint32_t)sym); S->op++; }
+        else {
+            qzk_tok_byte(O, (uint32_t)sym); S->op++;
+            if (PAIR) {
+                /* literals come in runs: take the next one in the same trip when its code sits in the root table (at
+                 * least 41 valid bits are left after the first).  Not for the speculative decoders, whose trips must
+                 * start at every symbol boundary their neighbour may have published. */
+                const uint32_t e2 = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
+                if (e2 != 0 && (e2 >> 4) < 256 && (int)(e2 & 15) <= b->bc && S->op < S->out_cap) {
+                    QZK_DROP(b, e2 & 15);
+                    qzk_tok_byte(O, e2 >> 4); S->op++;
+                }
+            }
+        }
     } else if (sym == 256) {
         if (S->last) { S->status = QZK_INF_FINAL; S->state = QZK_LS_DONE; } else S->state = QZK_LS_HDR;
     } else {
@@ -349,7 +378,7 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
         uint32_t dist = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1)) << xb);
         if (!err && (int)xb > b->bc) err = QZK_INF_EIN;
         dist += QZK_GETBITS(b, xb); QZK_DROP(b, xb);
-        if (!err && dist > S->op && (!S->through || (uint64_t)dist > out_off + S->op)) err = QZK_INF_EHIST;
+        if (!err && (uint64_t)dist > hist + S->op) err = QZK_INF_EHIST;   /* hist: bytes before the segment a match may reach */
         if (!err && S->op + len > S->out_cap) err = QZK_INF_EOUT;
         if (err) { S->status = err; S->state = QZK_LS_DONE; }
         else { qzk_tok_seq(O, len, dist - 1); S->op += len; }
@@ -358,9 +387,9 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
 
 /* LPW = segments (active lanes) per single-wave workgroup: LPW * 1.25 KiB of LDS (16 -> eight workgroups per CU) */
 template <int LPW>
-QZ_KERNEL qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
+QZ_KERNEL_MAX(64) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                  qzk_inf_tab *tabs, const qzk_tokseg *ts, uint8_t *lits, qzk_seq *seqs,
-                                 uint32_t *nseqs)
+                                 qzk_chain *chains)
 {
     QZ_LDS uint16_t roots[LPW][QZK_LANE_ROOTSZ];
     const uint32_t sidx = blockIdx.x * LPW + threadIdx.x;
@@ -393,7 +422,7 @@ QZ_KERNEL qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *segs, qz
                 b->bb |= pw << b->bc;
                 b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
                 pw = qzk_ld64u(b->p + b->pos);
-                qzk_lane_symbol<false>(&S, &O, T, lroot, droot, sg.out_off);
+                qzk_lane_symbol<false, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0);
             }
             b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;
             const uint32_t keep = (uint32_t)b->bc; const uint64_t low = b->bb;
@@ -403,7 +432,7 @@ QZ_KERNEL qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *segs, qz
             /* last bytes of the input: the careful reader */
             for (int trip = 0; trip < 64 && S.state == QZK_LS_SYM; trip++) {
                 qzk_lrefill(b);
-                qzk_lane_symbol<true>(&S, &O, T, lroot, droot, sg.out_off);
+                qzk_lane_symbol<true, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0);
             }
         } else if (S.state == QZK_LS_HDR) qzk_lane_header(&S, T, lroot, droot);
         else if (S.state == QZK_LS_RAW) {
@@ -422,7 +451,11 @@ QZ_KERNEL qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *segs, qz
         }
     }
     qzk_tok_finish(&O);
-    if (!O.count_only) nseqs[sidx] = O.nseq;
+    if (!O.count_only) {
+        qzk_chain C; C.nel = 1; C.pad = 0;
+        C.el[0].sub = 0; C.el[0].seq_first = 0; C.el[0].seq_count = O.nseq; C.el[0].lit_first = 0; C.el[0].lrun_skip = 0;
+        chains[sidx] = C;
+    }
     qzk_infres r;
     r.status = S.status; r.out_len = S.op; r.nblocks = S.nblocks;
     r.in_used = S.b.pos - (uint32_t)(S.b.bc >> 3);
@@ -475,10 +508,13 @@ QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
     }
 }
 
-/* one wave per segment; QZK_RES_WAVES segments per workgroup */
+/* one wave per segment; QZK_RES_WAVES segments per workgroup.  ts_stride sub-streams per segment (1 after the serial
+ * phase A, K after the speculative one); the chain says which pieces of which sub-streams make up the segment.  The
+ * output-dependent checks (capacity, history) live here because a speculative sub-decoder does not know its offset. */
 #define QZK_RES_WAVES 4
-QZ_KERNEL qzk_lz_resolve_kernel(uint8_t *out, const qzk_infseg *segs, const qzk_infres *res, uint32_t nsegs,
-                                const qzk_tokseg *ts, const uint8_t *lits, const qzk_seq *seqs, const uint32_t *nseqs)
+QZ_KERNEL_OCC(64 * QZK_RES_WAVES, 6) qzk_lz_resolve_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
+                                const qzk_tokseg *ts, uint32_t ts_stride, const uint8_t *lits, const qzk_seq *seqs,
+                                const qzk_chain *chains)
 {
     const int lane = qz_lane();
     const uint32_t sidx = blockIdx.x * QZK_RES_WAVES + (threadIdx.x >> 6);
@@ -486,41 +522,62 @@ QZ_KERNEL qzk_lz_resolve_kernel(uint8_t *out, const qzk_infseg *segs, const qzk_
     const qzk_infseg sg = segs[sidx];
     if (res[sidx].status < 0 || (sg.flags & QZK_INF_COUNT_ONLY)) return;
     uint8_t *o = out + sg.out_off;
-    const uint8_t *lp = lits + ts[sidx].lit_off;
-    const qzk_seq *sq = seqs + ts[sidx].seq_off;
-    const uint32_t ns = nseqs[sidx];
-    uint32_t obase = 0, lbase = 0;                     /* output / literal bytes consumed by earlier batches */
-    for (uint32_t b0 = 0; b0 < ns; b0 += 64) {
-        const uint32_t i = b0 + (uint32_t)lane;
-        uint32_t litrun = 0, mlen = 0, dist = 1;
-        if (i < ns) { const qzk_seq q = sq[i]; litrun = q.litrun; mlen = q.mlen; dist = (uint32_t)q.dm1 + 1; }
-        const uint32_t s_tot = qzk_wave_scan_incl(litrun + mlen, lane), s_lit = qzk_wave_scan_incl(litrun, lane);
-        const uint32_t Tb = qz_readlane(s_tot, 63), Lb = qz_readlane(s_lit, 63);
-        const uint32_t my_o = obase + s_tot - (litrun + mlen);       /* where my literals land */
-        const uint32_t my_l0 = s_lit - litrun;                       /* my first literal, batch-relative */
-        /* literal k of the batch belongs to the first sequence whose inclusive literal count exceeds k */
-        for (uint32_t k0 = 0; k0 < Lb; k0 += 64) {
-            const uint32_t k = k0 + (uint32_t)lane;
-            int j = 0;
-            for (int step = 32; step; step >>= 1) if (qz_shfl(s_lit, j + step - 1) <= k) j += step;
-            const uint32_t oj = qz_shfl(my_o, j), lj = qz_shfl(my_l0, j);
-            if (k < Lb) o[oj + (k - lj)] = lp[lbase + k];
-        }
-        qz_wave_sync();                                             /* matches may read these literals */
-        const uint32_t my_m = my_o + litrun;                         /* where my match lands */
-        const uint32_t src_end = my_m - dist + (mlen < dist ? mlen : dist);
-        uint64_t pending = qz_ballot(mlen != 0);
-        while (pending) {
-            /* everything below the first unfinished match is final: it and every match reading only from there go now */
-            const int f = qz_ctz64(pending);
-            const uint32_t m_f = qz_readlane(my_m, f);
-            const bool ready = ((pending >> lane) & 1) && (lane == f || src_end <= m_f);
-            if (ready) qzk_copy_match(o + (int64_t)my_m, dist, mlen);
-            pending &= ~qz_ballot(ready);
+    const uint64_t hist = (sg.flags & QZK_INF_THROUGH_FLUSH) ? sg.out_off : 0;     /* bytes a match may reach back before o */
+    const uint32_t nel = chains[sidx].nel;
+    uint32_t obase = 0;                                 /* output bytes of earlier batches */
+    int err = 0;
+    for (uint32_t e = 0; e < nel && !err; e++) {
+        const qzk_chain_el ce = chains[sidx].el[e];
+        if (ce.sub == QZK_PIECE_RAW) {                  /* a stored block: copy it from the compressed input */
+            if ((uint64_t)obase + ce.seq_count > sg.out_cap) { err = QZK_INF_EOUT; break; }
+            const uint8_t *s = comp + sg.in_off + ce.seq_first;
+            for (uint32_t i = (uint32_t)lane; i < ce.seq_count; i += 64) o[obase + i] = s[i];
             qz_wave_sync();
+            obase += ce.seq_count;
+            continue;
         }
-        obase += Tb; lbase += Lb;
+        const qzk_tokseg tk = ts[(uint64_t)sidx * ts_stride + ce.sub];
+        const uint8_t *lp = lits + tk.lit_off + ce.lit_first;
+        const qzk_seq *sq = seqs + tk.seq_off + ce.seq_first;
+        const uint32_t ns = ce.seq_count;
+        uint32_t lbase = 0;                             /* literal bytes of this piece consumed by earlier batches */
+        for (uint32_t b0 = 0; b0 < ns && !err; b0 += 64) {
+            const uint32_t i = b0 + (uint32_t)lane;
+            uint32_t litrun = 0, mlen = 0, dist = 1;
+            if (i < ns) { const qzk_seq q = sq[i]; litrun = q.litrun; mlen = q.mlen; dist = (uint32_t)q.dm1 + 1; }
+            if (i == 0) litrun -= ce.lrun_skip;         /* literals the sub-decoder produced before it was in step */
+            const uint32_t s_tot = qzk_wave_scan_incl(litrun + mlen, lane), s_lit = qzk_wave_scan_incl(litrun, lane);
+            const uint32_t Tb = qz_readlane(s_tot, 63), Lb = qz_readlane(s_lit, 63);
+            const uint32_t my_o = obase + s_tot - (litrun + mlen);       /* where my literals land */
+            const uint32_t my_l0 = s_lit - litrun;                       /* my first literal, batch-relative */
+            const uint32_t my_m = my_o + litrun;                         /* where my match lands */
+            if ((uint64_t)obase + Tb > sg.out_cap) err = QZK_INF_EOUT;
+            else if (qz_ballot(mlen != 0 && (uint64_t)dist > (uint64_t)my_m + hist) != 0) err = QZK_INF_EHIST;
+            if (err) break;
+            /* literal k of the batch belongs to the first sequence whose inclusive literal count exceeds k */
+            for (uint32_t k0 = 0; k0 < Lb; k0 += 64) {
+                const uint32_t k = k0 + (uint32_t)lane;
+                int j = 0;
+                for (int step = 32; step; step >>= 1) if (qz_shfl(s_lit, j + step - 1) <= k) j += step;
+                const uint32_t oj = qz_shfl(my_o, j), lj = qz_shfl(my_l0, j);
+                if (k < Lb) o[oj + (k - lj)] = lp[lbase + k];
+            }
+            qz_wave_sync();                                             /* matches may read these literals */
+            const uint32_t src_end = my_m - dist + (mlen < dist ? mlen : dist);
+            uint64_t pending = qz_ballot(mlen != 0);
+            while (pending) {
+                /* everything below the first unfinished match is final: it and every match reading only from there go now */
+                const int f = qz_ctz64(pending);
+                const uint32_t m_f = qz_readlane(my_m, f);
+                const bool ready = ((pending >> lane) & 1) && (lane == f || src_end <= m_f);
+                if (ready) qzk_copy_match(o + (int64_t)my_m, dist, mlen);
+                pending &= ~qz_ballot(ready);
+                qz_wave_sync();
+            }
+            obase += Tb; lbase += Lb;
+        }
     }
+    if (err) res[sidx].status = err;                    /* wave-uniform value, every lane stores the same word */
 }
 
 #endif

@@ -11,6 +11,7 @@
 #include "../../qatzip_amd/csrc/qzk_deflate_lz77_lane.h"
 #include "../../qatzip_amd/csrc/qzk_inflate.h"
 #include "../../qatzip_amd/csrc/qzk_inflate_lane.h"
+#include "../../qatzip_amd/csrc/qzk_inflate_spec.h"
 #include "../../qatzip_amd/csrc/qzk_checksum.h"
 #include "../../qatzip_amd/csrc/qzk_lz4.h"
 #include <vector>
@@ -131,11 +132,12 @@ int sim_lz4d(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *segs, qzk_lz4r
     return 0;
 }
 
-/* K3b: phase A (one segment per lane -> literal streams + sequence records), phase B (one wave per segment) */
-int sim_inflate_lane(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
+/* K3b, serial phase A (one segment per lane -> literal streams + sequence records) + phase B (one wave per segment) */
+static void two_phase_serial(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
 {
     std::vector<qzk_inf_tab> tabs(nsegs);
     std::vector<qzk_tokseg> ts(nsegs);
+    std::vector<qzk_chain> chains(nsegs);
     uint64_t lt = 0, sqt = 0;
     for (uint32_t i = 0; i < nsegs; i++) {
         ts[i].lit_off = lt; ts[i].seq_off = sqt;
@@ -143,15 +145,72 @@ int sim_inflate_lane(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, 
     }
     std::vector<uint8_t> lits(lt + 64, 0xee);
     std::vector<qzk_seq> seqs(sqt + 8);
-    std::vector<uint32_t> nseqs(nsegs, 0xdeadbeef);
-    /* 16 segments per workgroup like the device launch; the emulator wants whole waves, the kernel bounds-checks */
+    /* 16 segments per workgroup; the emulator wants whole waves, the kernel bounds-checks */
     sim::launch((nsegs + 15) / 16, 64, 0, [&] {
-        if (threadIdx.x < 16) qzk_inflate_tok_kernel<16>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), nseqs.data());
+        if (threadIdx.x < 16) qzk_inflate_tok_kernel<16>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data());
     });
     sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
-        qzk_lz_resolve_kernel(out, segs, res, nsegs, ts.data(), lits.data(), seqs.data(), nseqs.data());
+        qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), 1u, lits.data(), seqs.data(), chains.data());
     });
+}
+
+int sim_inflate_lane(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
+{
+    two_phase_serial(comp, out, segs, res, nsegs);
     return 0;
+}
+
+} /* extern "C" */
+
+/* K3b with the speculative phase A (K lanes per segment); segments it hands back are redone serially, like the host
+ * does.  Returns how many segments were handed back. */
+template <int K>
+static int two_phase_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
+{
+    std::vector<qzk_inf_tab> tabs(nsegs);
+    std::vector<qzk_tokseg> ts((size_t)nsegs * K);
+    std::vector<qzk_chain> chains(nsegs);
+    std::vector<qzk_rec> recs((size_t)nsegs * K * QZK_SPEC_NREC);
+    uint64_t lt = 0, sqt = 0;
+    for (uint32_t i = 0; i < nsegs; i++)
+        for (int j = 0; j < K; j++) {
+            ts[(size_t)i * K + j].lit_off = lt; ts[(size_t)i * K + j].seq_off = sqt;
+            lt += QZK_SPEC_LITCAP(segs[i].out_cap, K); sqt += QZK_SPEC_SEQCAP(segs[i].out_cap, K);
+        }
+    std::vector<uint8_t> lits(lt + 64, 0xee);
+    std::vector<qzk_seq> seqs(sqt + 8);
+    const uint32_t spw = 64 / K;
+    sim::launch((nsegs + spw - 1) / spw, 64, 0, [&] {
+        qzk_inflate_spec_kernel<K>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data(), recs.data());
+    });
+    sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
+        qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), (uint32_t)K, lits.data(), seqs.data(), chains.data());
+    });
+    if (getenv("QZSIM_TRACE"))
+        for (uint32_t i = 0; i < nsegs; i++) {
+            fprintf(stderr, "seg %u status %d pieces %u:", i, res[i].status, chains[i].nel);
+            for (uint32_t e = 0; e < chains[i].nel; e++) fprintf(stderr, " [sub %u seq %u+%u]", chains[i].el[e].sub, chains[i].el[e].seq_first, chains[i].el[e].seq_count);
+            fprintf(stderr, "\n");
+        }
+    std::vector<uint32_t> redo;
+    for (uint32_t i = 0; i < nsegs; i++) if (res[i].status == QZK_INF_ESPEC) redo.push_back(i);
+    if (!redo.empty()) {
+        std::vector<qzk_infseg> rs(redo.size());
+        std::vector<qzk_infres> rr(redo.size());
+        for (size_t i = 0; i < redo.size(); i++) rs[i] = segs[redo[i]];
+        two_phase_serial(comp, out, rs.data(), rr.data(), (uint32_t)redo.size());
+        for (size_t i = 0; i < redo.size(); i++) res[redo[i]] = rr[i];
+    }
+    return (int)redo.size();
+}
+
+extern "C" {
+
+int sim_inflate_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs, int K)
+{
+    if (K == 2) return two_phase_spec<2>(comp, out, segs, res, nsegs);
+    if (K == 4) return two_phase_spec<4>(comp, out, segs, res, nsegs);
+    return two_phase_spec<8>(comp, out, segs, res, nsegs);
 }
 
 int sim_adler(const uint8_t *data, uint64_t n, uint32_t chunk_sz, uint32_t *out)

@@ -130,3 +130,41 @@ def test_adler_chunks_kernel(sim):
         sim.sim_adler(src, n, chunk, out.ctypes.data)
         for i in range(nch):
             assert out[i] == zlib.adler32(src[i * chunk:(i + 1) * chunk]), (kind, n, chunk, i)
+
+
+def test_speculative_inflate_matches_serial(sim):
+    """K3b with K lanes per segment (sub-segment speculation, qzk_inflate_spec.h): same bytes and same per-segment
+    results as the one-lane-per-segment phase A; segments it cannot take (stored / several blocks) come back through
+    the serial kernel"""
+    import refcalls as R
+    if not R.zlib_pinned():
+        pytest.skip("needs the pinned zlib to cut a stream into its per-chunk pieces")
+    seg_dt = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
+    res_dt = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
+    sim.sim_inflate_lane.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    sim.sim_inflate_spec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    taken = 0
+    for kind, n, chunk in (("silesia", 400000, 65536), ("text", 300000, 65536), ("records", 200000, 32768),
+                           ("runs", 140000, 65536), ("allA", 70000, 65536), ("rand", 140000, 65536),
+                           ("lzmix", 66000, 65536), ("mod200", 100000, 16384), ("text", 9000, 1024)):
+        src = datagen.gen_bytes(kind, n, 12)
+        pieces = R.raw_chunks(src, chunk, 1, 1)
+        comp = b"".join(pieces)
+        segs, off, oo = [], 0, 0
+        for i, pc in enumerate(pieces):
+            ln = min(chunk, n - oo)
+            # like the optimistic pass of the host: in_len runs to the end of the stream, pad carries the real length
+            segs.append((off, oo, len(comp) - off, ln, 0, len(pc))); off += len(pc); oo += ln
+        cbuf = np.frombuffer(comp + b"\0" * 64, np.uint8).copy()
+        sa = np.array(segs, dtype=seg_dt)
+        ref_out = np.zeros(n + 64, np.uint8); ref_res = np.zeros(len(segs), res_dt)
+        sim.sim_inflate_lane(cbuf.ctypes.data, ref_out.ctypes.data, sa.ctypes.data, ref_res.ctypes.data, len(segs))
+        assert bytes(ref_out[:n]) == src
+        for K in (2, 4, 8):
+            out = np.zeros(n + 64, np.uint8); res = np.zeros(len(segs), res_dt)
+            redone = sim.sim_inflate_spec(cbuf.ctypes.data, out.ctypes.data, sa.ctypes.data, res.ctypes.data, len(segs), K)
+            assert bytes(out[:n]) == src, (kind, n, chunk, K)
+            for f in ("status", "in_used", "out_len"):
+                assert (res[f] == ref_res[f]).all(), (kind, chunk, K, f, res[f], ref_res[f])
+            taken += len(segs) - redone
+    assert taken > 50            # the speculative kernel really decoded most of the ordinary segments itself
