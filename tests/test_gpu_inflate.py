@@ -119,3 +119,23 @@ def test_both_inflate_kernels_agree(ctx, monkeypatch, mode):
     comp = co.compress(src) + co.flush()
     iu, out, crc = _inflate(ctx, comp, len(src))
     assert out == src
+
+
+@pytest.mark.parametrize("k", ["2", "4", "8"])
+def test_speculative_phase_a_is_bit_exact(ctx, monkeypatch, k):
+    # opt-in sub-segment speculation (qzk_inflate_spec.h): K lanes per segment; whatever it cannot take goes through
+    # the serial kernel, so every kind of stream must still come out right
+    monkeypatch.setenv("QATZIP_AMD_INFLATE", "lane")
+    monkeypatch.setenv("QATZIP_AMD_INFLATE_K", k)
+    for kind, n, chunk in (("silesia", 6 << 20, 65536), ("text", 3 << 20, 65536), ("lzmix", 140000, 65536),
+                           ("rand", 300000, 65536), ("runs", 1 << 20, 16384), ("records", 2 << 20, 131072), ("allA", 1 << 20, 65536)):
+        src = datagen.gen_bytes(kind, n, 57)
+        rc, _, comp, _ = O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)
+        for hint in (chunk, 0):                              # optimistic pass (hints) and the two-pass chain (exact lengths)
+            iu, out, crc = _inflate(ctx, comp, n, hint)
+            assert out == src and iu == len(comp) and crc == (zlib.crc32(src) & 0xffffffff), (k, kind, hint)
+    src = datagen.gen_bytes("text", 500000, 2)               # a foreign stream: one long member, no markers
+    co = zlib.compressobj(9, zlib.DEFLATED, -15)
+    comp = co.compress(src) + co.flush()
+    iu, out, crc = _inflate(ctx, comp, len(src))
+    assert out == src

@@ -15,7 +15,7 @@ def main():
     mb = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     lpws = sys.argv[2:] or ["64", "32", "16"]
     n = mb << 20
-    base = datagen.gen("silesia", min(128 << 20, n), 20250523)
+    base = datagen.gen(os.environ.get("SWEEP_KIND", "silesia"), min(128 << 20, n), 20250523)
     ctx = qatzip_amd.Context(0)
     d_src = ctx.alloc(n)
     for off in range(0, n, len(base)):
