@@ -35,7 +35,7 @@
  * a lone wave's instruction latency), the wave kernel does ~300 segments/ms (bound by the CUs' scalar units): the
  * two phases win from ~8 000 segments on (measured) */
 #define QZD_LANE_MIN_SEGS 8000u
-#define QZD_LANE_SEGS_PER_WAVE 32u
+#define QZD_LANE_SEGS_PER_WAVE 16u
 /* sub-decoders per segment of phase A.  1 = the serial phase A.  The speculative one (2, 4, 8; QATZIP_AMD_INFLATE_K)
  * decodes compressible segments K times faster, but blocks of near-equal code lengths (incompressible data that still
  * got Huffman-coded) never let a misaligned decoder fall into step, so those segments come back to the serial kernel
@@ -108,7 +108,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         const dim3 grid((nsegs + lpw - 1) / lpw), blk(lpw);
 #define QZD_TOK_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_tok_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
                                             ts_d, lit_d, seq_d, ch_d)
-        if (lpw == 8) QZD_TOK_LAUNCH(8); else if (lpw == 16) QZD_TOK_LAUNCH(16); else if (lpw == 64) QZD_TOK_LAUNCH(64); else QZD_TOK_LAUNCH(32);
+        if (lpw == 8) QZD_TOK_LAUNCH(8); else if (lpw == 32) QZD_TOK_LAUNCH(32); else if (lpw == 64) QZD_TOK_LAUNCH(64); else QZD_TOK_LAUNCH(16);
 #undef QZD_TOK_LAUNCH
     } else {
         const uint32_t spw = 64 / K;

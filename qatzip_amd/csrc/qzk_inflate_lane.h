@@ -138,6 +138,7 @@ typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chai
 #define QZK_TOK_SEQCAP(out_cap) ((uint64_t)(out_cap) / 3 + 2)
 
 enum { QZK_LS_HDR = 0, QZK_LS_SYM, QZK_LS_RAW, QZK_LS_DONE };
+#define QZK_LIT_RUN 2              /* literals one trip of the serial phase A may take */
 
 /* slow half of a symbol decode: the root entry was empty (code longer than the root) */
 QZ_DEV int qzk_ldecode_long(qzk_lbits *b, int rootbits, const uint16_t *sorted, const uint16_t *count,
@@ -349,13 +350,17 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
         else {
             qzk_tok_byte(O, (uint32_t)sym); S->op++;
             if (PAIR) {
-                /* literals come in runs: take the next one in the same trip when its code sits in the root table (at
-                 * least 41 valid bits are left after the first).  Not for the speculative decoders, whose trips must
+                /* literals come in runs: take up to QZK_LIT_RUN in one trip while their codes sit in the 9-bit root table
+                 * (15 + 3 * 9 bits fit the 56 a trip starts with).  Not for the speculative decoders, whose trips must
                  * start at every symbol boundary their neighbour may have published. */
-                const uint32_t e2 = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
-                if (e2 != 0 && (e2 >> 4) < 256 && (int)(e2 & 15) <= b->bc && S->op < S->out_cap) {
-                    QZK_DROP(b, e2 & 15);
-                    qzk_tok_byte(O, e2 >> 4); S->op++;
+                bool run = true;
+                for (int extra = 0; extra < QZK_LIT_RUN - 1; extra++) {
+                    const uint32_t e2 = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
+                    run = run && e2 != 0 && (e2 >> 4) < 256 && (int)(e2 & 15) <= b->bc && S->op < S->out_cap;
+                    if (run) {
+                        QZK_DROP(b, e2 & 15);
+                        qzk_tok_byte(O, e2 >> 4); S->op++;
+                    }
                 }
             }
         }
