@@ -127,27 +127,17 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
     hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
     for (int i = 0; i < QZD_K1EV; i++) { hipEventCreate(&c->k1ev[i][0]); hipEventCreate(&c->k1ev[i][1]); }
     {
-        /* K1 residency (measured): a batch that fits two single-wave workgroups per CU runs the
-         * prev-in-LDS variant (lowest latency per chunk); anything larger runs QZD_K1_HBM_PER_CU workgroups per CU of
-         * the prev-in-HBM variant, which trades per-wave latency for six times the waves in flight.
-         * QATZIP_AMD_K1_WGS="<lds>,<hbm>" forces a fixed mix of the two (they share one chunk counter). */
+        /* K1 residency (measured): QZD_K1_WGS_PER_CU persistent single-wave workgroups per CU, each with
+         * its own 512 KiB candidate table.  QATZIP_AMD_K1_WGS=<n> overrides the total. */
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) return QZD_ERR_HIP;
         const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        c->k1_wgs_lds = 2 * cus; c->k1_wgs_hbm = QZD_K1_HBM_PER_CU * cus; c->k1_fixed_mix = 0;
+        c->k1_wgs = QZD_K1_WGS_PER_CU * cus;
         const char *e = getenv("QATZIP_AMD_K1_WGS");
-        unsigned a = 0, b = 0;
-        if (e && sscanf(e, "%u,%u", &a, &b) == 2 && a + b > 0 && a <= 65536 && b <= 65536) {
-            c->k1_wgs_lds = a; c->k1_wgs_hbm = b; c->k1_fixed_mix = 1;
-        }
-        c->batch_chunks = QZD_BATCH_ROUNDS * (c->k1_fixed_mix ? c->k1_wgs_lds + c->k1_wgs_hbm : c->k1_wgs_hbm);
-        if (hipStreamCreateWithFlags(&c->st_k1b, hipStreamNonBlocking) != hipSuccess) return QZD_ERR_HIP;
-        for (int i = 0; i < QZD_NBUF; i++) {
-            hipEventCreateWithFlags(&c->k1go[i], hipEventDisableTiming);
-            hipEventCreateWithFlags(&c->k1bdone[i], hipEventDisableTiming);
-        }
-        if (hipMalloc(&c->k1_head, (size_t)(c->k1_wgs_lds + c->k1_wgs_hbm) * QZK_HSIZE * 2) != hipSuccess ||
-            hipMalloc(&c->k1_prev, (size_t)(c->k1_wgs_hbm ? c->k1_wgs_hbm : 1) * QZK_WSIZE * 2) != hipSuccess ||
+        unsigned a = 0;
+        if (e && sscanf(e, "%u", &a) == 1 && a > 0 && a <= 65536) c->k1_wgs = a;
+        c->batch_chunks = QZD_BATCH_ROUNDS * c->k1_wgs;
+        if (hipMalloc(&c->k1_tables, (size_t)c->k1_wgs * QZK_HSIZE * 8) != hipSuccess ||
             hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) return QZD_ERR_HIP;
     }
     if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) return QZD_ERR_HIP;
@@ -165,13 +155,11 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     for (int i = 0; i < QZD_NBUF; i++) {
         hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
         hipStreamDestroy(c->st[i]); hipEventDestroy(c->done[i]); hipEventDestroy(c->k1done[i]);
-        hipEventDestroy(c->k1go[i]); hipEventDestroy(c->k1bdone[i]);
         for (int k = 0; k < 4; k++) hipEventDestroy(c->ev[i][k]);
     }
     hipEventDestroy(c->ev_begin); hipEventDestroy(c->ev_end);
     for (int i = 0; i < QZD_K1EV; i++) { hipEventDestroy(c->k1ev[i][0]); hipEventDestroy(c->k1ev[i][1]); }
-    hipStreamDestroy(c->st_k1b);
-    hipFree(c->k1_head); hipFree(c->k1_prev); hipFree(c->k1_counter);
+    hipFree(c->k1_tables); hipFree(c->k1_counter);
     hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
     hipHostFree(c->h_running); hipHostFree(c->h_overflow);
     if (c->d_aux) hipFree(c->d_aux);
@@ -344,32 +332,15 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
         const uint32_t final_chunk = (last && b + bn == nchunks) ? bn - 1 : ~0u;
         hipStream_t st = c->st[s];
         const bool timed = k < QZD_NBUF;     /* events of the first use of each buffer set */
-        /* K1 already fills every CU's LDS: two K1 batches side by side would only take turns, and they share the
-         * per-workgroup table slices, so K1 of batch k starts when K1 of batch k-1 is done; what overlaps with it
-         * is K2/scan/gather of batch k-1.  Both variants pull chunk numbers from counter[s]. */
+        /* the K1 workgroups of consecutive batches share the per-workgroup tables, so K1 of batch k starts when K1 of
+         * batch k-1 is done; what overlaps with it is K2/scan/gather of batch k-1 */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->k1done[so], 0));
-        uint32_t wg_lds, wg_hbm;
-        if (c->k1_fixed_mix) {
-            wg_lds = bn < c->k1_wgs_lds ? bn : c->k1_wgs_lds;
-            wg_hbm = bn - wg_lds < c->k1_wgs_hbm ? bn - wg_lds : c->k1_wgs_hbm;
-        } else if (bn <= c->k1_wgs_lds) { wg_lds = bn; wg_hbm = 0; }
-        else { wg_lds = 0; wg_hbm = bn < c->k1_wgs_hbm ? bn : c->k1_wgs_hbm; }
+        const uint32_t wgs = bn < c->k1_wgs ? bn : c->k1_wgs;
         HIPCHK(c, hipMemsetAsync(c->k1_counter + s, 0, 4, st));
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
         if (k < QZD_K1EV) HIPCHK(c, hipEventRecord(c->k1ev[k][0], st));
-        if (wg_hbm) {
-            HIPCHK(c, hipEventRecord(c->k1go[s], st));
-            HIPCHK(c, hipStreamWaitEvent(c->st_k1b, c->k1go[s], 0));
-            hipLaunchKernelGGL(qzk_lz77_pull_kernel<false>, dim3(wg_hbm), dim3(64), 0, c->st_k1b, d_src + boff, blen,
-                               chunk_sz, bn, c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_head, c->k1_prev,
-                               c->k1_wgs_lds, c->k1_counter + s);
-            HIPCHK(c, hipEventRecord(c->k1bdone[s], c->st_k1b));
-        }
-        if (wg_lds)
-            hipLaunchKernelGGL(qzk_lz77_pull_kernel<true>, dim3(wg_lds), dim3(64), 0, st, d_src + boff, blen, chunk_sz,
-                               bn, c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_head, c->k1_prev, 0u,
-                               c->k1_counter + s);
-        if (wg_hbm) HIPCHK(c, hipStreamWaitEvent(st, c->k1bdone[s], 0));
+        hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn,
+                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_tables, c->k1_counter + s);
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));

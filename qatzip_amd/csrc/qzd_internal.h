@@ -12,7 +12,7 @@
 #define QZD_BATCH_ROUNDS 3u
 #define QZD_NBUF 2
 #define QZD_K1EV 64                  /* K1 launches per call that get their own pair of timing events */
-#define QZD_K1_HBM_PER_CU 12u
+#define QZD_K1_WGS_PER_CU 16u
 
 struct qzd_ctx {
     int device;
@@ -21,11 +21,9 @@ struct qzd_ctx {
     /* scratch per buffer set */
     uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];
     qzk_lzmeta *meta[QZD_NBUF];
-    /* K1 (persistent pull kernels): table slices per resident workgroup, one chunk counter per buffer set */
-    hipStream_t st_k1b; hipEvent_t k1go[QZD_NBUF], k1bdone[QZD_NBUF];
-    uint16_t *k1_head, *k1_prev; uint32_t *k1_counter;
-    uint32_t k1_wgs_lds, k1_wgs_hbm;                /* workgroups of the prev-in-LDS / prev-in-HBM variant */
-    int k1_fixed_mix;                               /* QATZIP_AMD_K1_WGS given: always launch that mix */
+    /* K1 (persistent pull kernel): one 512 KiB candidate table per resident workgroup, one chunk counter per buffer set */
+    uint64_t *k1_tables; uint32_t *k1_counter;
+    uint32_t k1_wgs;
     uint32_t batch_chunks;
     /* K1 launch durations (HIP events around every K1 launch, harvested at qzd_sync): bench.py's roofline input */
     hipEvent_t k1ev[QZD_K1EV][2]; uint32_t k1ev_chunks[QZD_K1EV]; uint32_t k1ev_n;

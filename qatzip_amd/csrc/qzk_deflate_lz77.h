@@ -98,27 +98,26 @@ QZ_DEV int qzk_wave_matchlen(const uint8_t *src, uint64_t src_len, uint64_t a, u
     return maxlen;
 }
 
-/* One chunk, one wave.  PL selects where zlib's prev[] lives: true = this workgroup's LDS (64 KiB, two such
- * workgroups fit a CU), false = a per-workgroup slice of HBM/L2 (4 KiB of LDS left, so several more of these
- * fit beside the LDS ones and hide each other's latency).  head[] is always a per-workgroup 128 KiB slice. */
-template <bool PL>
+/* One chunk, one wave.  zlib's head[] + prev[] chains (level 1 never follows more than four links) are kept as ONE
+ * table: bkt[hash] = the four most recent inserted window positions with that 16-bit hash, newest first, 4 x u16
+ * (0 = NIL) - exactly the candidates longest_match() would visit, in its order.  A lookup is a single 8-byte gather
+ * instead of a gather plus up to three dependent ones; an insert shifts the entry.  512 KiB per resident workgroup,
+ * in HBM/L2; LDS holds a ring of the most recent input and the per-window slot tables (8 KiB). */
 QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t chunk,
-                           uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint16_t *head, uint16_t *prev_g)
+                           uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint64_t *bkt)
 {
-    QZ_LDS uint16_t prev_l[PL ? QZK_WSIZE : 2];  /* [pos & 32767] = distance to the previous inserted position with the same hash (0 = none) */
     QZ_LDS uint32_t slot[QZK_NSLOT];       /* per-window: min(lane<<16 | hash) over the lanes on a hash key */
     QZ_LDS uint32_t scnt[QZK_NSLOT];       /* per-window: number of lanes on the key */
-    /* prev-in-HBM variant: the last QZK_RING bytes of input (and ~100 ahead of the parse point) sit in LDS.  Every
-     * candidate compare drags a 128-byte line through L2 for 16 bytes, 86 % of them less than 8 KiB back; with a
-     * dozen waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
-    QZ_LDS uint32_t ring[PL ? 1 : QZK_RINGW];
+    /* the last QZK_RING bytes of input (and ~100 ahead of the parse point) sit in LDS.  Every candidate compare
+     * drags a 128-byte line through L2 for 16 bytes, three quarters of them less than 4 KiB back; with a dozen
+     * waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
+    QZ_LDS uint32_t ring[QZK_RINGW];
     uint32_t rhi = 0;                      /* chunk offset the ring is filled up to (multiple of 256) */
 #define QZK_RING16(dst, ca) do { const uint32_t r_ = (ca) & (QZK_RING - 1), i_ = r_ >> 2, s_ = r_ & 3; \
         const uint32_t d0_ = ring[i_ & (QZK_RINGW - 1)], d1_ = ring[(i_ + 1) & (QZK_RINGW - 1)], d2_ = ring[(i_ + 2) & (QZK_RINGW - 1)], \
                        d3_ = ring[(i_ + 3) & (QZK_RINGW - 1)], d4_ = ring[(i_ + 4) & (QZK_RINGW - 1)]; \
         (dst)[0] = qzk_alignbyte(d1_, d0_, s_); (dst)[1] = qzk_alignbyte(d2_, d1_, s_); \
         (dst)[2] = qzk_alignbyte(d3_, d2_, s_); (dst)[3] = qzk_alignbyte(d4_, d3_, s_); } while (0)
-#define QZK_PREV(i) (*(PL ? &prev_l[(i) & (PL ? QZK_WSIZE - 1 : 1)] : &prev_g[(i)]))
 
     const int lane = qz_lane();
     const uint64_t coff = (uint64_t)chunk * chunk_sz;
@@ -127,9 +126,9 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     uint16_t *odist = sym_dist + coff;
     qzk_lzmeta *mt = meta + chunk;
 
-    /* zlib's head[]: 16-bit hash -> last inserted window position (0 = NIL); one gather + one scatter per window */
+    /* every entry NIL; one gather + one scatter of the table per window */
     qz_wave_sync();
-    for (int i = lane; i < QZK_HSIZE / 4; i += 64) ((uint64_t *)head)[i] = 0;
+    for (int i = lane; i < QZK_HSIZE; i += 64) bkt[i] = 0;
     qz_wave_sync();
 
     uint32_t base = 0;                              /* chunk offset of window position 0 */
@@ -149,11 +148,14 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             if (pos - base >= (uint32_t)(QZK_WSIZE + QZK_MAXDIST)) {
                 base += QZK_WSIZE;
                 qz_wave_sync();
-                for (int i = lane; i < QZK_HSIZE / 2; i += 64) {
-                    uint32_t v = ((uint32_t *)head)[i], lo = v & 0xffff, hi = v >> 16;
-                    lo = lo >= QZK_WSIZE ? lo - QZK_WSIZE : 0;
-                    hi = hi >= QZK_WSIZE ? hi - QZK_WSIZE : 0;
-                    ((uint32_t *)head)[i] = lo | (hi << 16);
+                for (int i = lane; i < QZK_HSIZE; i += 64) {       /* zlib slide_hash(): positions below the new origin become NIL */
+                    const uint64_t v = bkt[i];
+                    uint64_t r = 0;
+                    for (int f = 0; f < 4; f++) {
+                        const uint32_t q = (uint32_t)(v >> (16 * f)) & 0xffff;
+                        r |= (uint64_t)(q >= QZK_WSIZE ? q - QZK_WSIZE : 0) << (16 * f);
+                    }
+                    bkt[i] = r;
                 }
                 qz_wave_sync();
             }
@@ -176,7 +178,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         /* all of this window's loads stay inside the buffer unless it sits at the very end of it */
         const bool guard = coff + pos + 64 + 2 * QZK_CAP > src_len;
         uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        if (!PL) {
+        {
             /* top the ring up to 96 bytes past the window start: one coalesced 256-byte load every few windows */
             if (rhi < pos + 64 + 2 * QZK_CAP) {
                 do {
@@ -190,28 +192,19 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             uint32_t w[4];
             QZK_RING16(w, pa);
             w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
-        } else if (!guard) {
-            const uint8_t *o = src + coff + pa;
-            w0 = qz_ld32(o); w1 = qz_ld32(o + 4); w2 = qz_ld32(o + 8); w3 = qz_ld32(o + 12);
-        } else if (avail > 0) {
-            w0 = qzk_ld32g(src, coff + pa, src_len);
-            w1 = qzk_ld32g(src, coff + pa + 4, src_len);
-            w2 = qzk_ld32g(src, coff + pa + 8, src_len);
-            w3 = qzk_ld32g(src, coff + pa + 12, src_len);
         }
         const uint32_t h = (((w0 & 0xf) << 12) ^ (((w0 >> 8) & 0xff) << 6) ^ ((w0 >> 16) & 0xff)) & 0xffff;
         const uint32_t bucket = h;
         const uint32_t key = h & (QZK_NSLOT - 1);
 
         QZK_T(1);
-        /* chain walk on the table state as of the window start: head (HBM/L2), then <= 3 prev links (LDS);
-         * first candidate needs dist <= MAX_DIST, chained ones cur_match > limit (zlib's asymmetry) */
-        /* the previous window's head[] stores must have landed before this gather (same wave, same CU) */
+        /* candidates as of the window start: one 8-byte gather; first candidate needs dist <= MAX_DIST, chained ones
+         * cur_match > limit (zlib's asymmetry), and the chain ends at the first one that fails */
+        /* the previous window's table stores must have landed before this gather (same wave, same CU) */
         qz_wave_sync();
-        const int q0 = canh ? (int)head[bucket] : 0;
+        const uint64_t e0 = canh ? bkt[bucket] : 0;
+        const int q0 = (int)(e0 & 0xffff), q1 = (int)((e0 >> 16) & 0xffff), q2 = (int)((e0 >> 32) & 0xffff), q3 = (int)(e0 >> 48);
         const int lo = p > QZK_MAXDIST ? (int)(p - QZK_MAXDIST) : 0;
-        /* straight-line walk (no branches): a dead link parks on the lane's own position, whose loads are
-         * harmless, so the 16-byte candidate loads can be issued as soon as each address is known */
         const int maxlen = avail < 258 ? avail : 258;
         const int nice = avail < QZK_NICE ? avail : QZK_NICE;
         int best_len = 2, best_c = 0;
@@ -221,29 +214,20 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         {
             uint32_t x[4][4];
 #define QZK_LDC(k, ck) do { const uint32_t ca_ = base + (uint32_t)(ck); uint64_t g_ = coff + ca_; \
-        if (!PL && (int64_t)ca_ >= (int64_t)rhi - QZK_RING) QZK_RING16(x[k], ca_); \
+        if ((int64_t)ca_ >= (int64_t)rhi - QZK_RING) QZK_RING16(x[k], ca_); \
         else if (!guard) { x[k][0] = qz_ld32(src + g_); x[k][1] = qz_ld32(src + g_ + 4); x[k][2] = qz_ld32(src + g_ + 8); x[k][3] = qz_ld32(src + g_ + 12); } \
         else { x[k][0] = qzk_ld32g(src, g_, src_len); x[k][1] = qzk_ld32g(src, g_ + 4, src_len); x[k][2] = qzk_ld32g(src, g_ + 8, src_len); x[k][3] = qzk_ld32g(src, g_ + 12, src_len); } } while (0)
             /* loads are predicated on the link being live: with a dozen waves per CU the kernel is bound by the
              * texture path (TA/TD ~ one lane-line per cycle), so dead lanes must not ride along */
             for (int k = 0; k < 4; k++) x[k][0] = x[k][1] = x[k][2] = x[k][3] = 0;
             const bool ok0 = canh && q0 != 0 && (int)p - q0 <= QZK_MAXDIST;
-            c0 = ok0 ? q0 : (int)p;
-            int d = 0, q;
-            if (ok0) { QZK_LDC(0, c0); d = QZK_PREV(c0 & (QZK_WSIZE - 1)); }
-            q = c0 - d;
-            const bool ok1 = ok0 && d != 0 && q > lo;
-            c1 = ok1 ? q : (int)p;
-            d = 0;
-            if (ok1) { QZK_LDC(1, c1); d = QZK_PREV(c1 & (QZK_WSIZE - 1)); }
-            q = c1 - d;
-            const bool ok2 = ok1 && d != 0 && q > lo;
-            c2 = ok2 ? q : (int)p;
-            d = 0;
-            if (ok2) { QZK_LDC(2, c2); d = QZK_PREV(c2 & (QZK_WSIZE - 1)); }
-            q = c2 - d;
-            const bool ok3 = ok2 && d != 0 && q > lo;
-            c3 = ok3 ? q : (int)p;
+            const bool ok1 = ok0 && q1 > lo;
+            const bool ok2 = ok1 && q2 > lo;
+            const bool ok3 = ok2 && q3 > lo;
+            c0 = ok0 ? q0 : (int)p; c1 = ok1 ? q1 : (int)p; c2 = ok2 ? q2 : (int)p; c3 = ok3 ? q3 : (int)p;
+            if (ok0) QZK_LDC(0, c0);
+            if (ok1) QZK_LDC(1, c1);
+            if (ok2) QZK_LDC(2, c2);
             if (ok3) QZK_LDC(3, c3);
 #undef QZK_LDC
             nc = (int)ok0 + (int)ok1 + (int)ok2 + (int)ok3;
@@ -419,14 +403,10 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         nsym += (uint32_t)qz_popc64(Pm);
 
         QZK_T(7);
-        /* clean inserted lanes: link to the table head seen at window start */
-        if (isI && !suspect) {
-            uint32_t d = (q0 != 0 && p - (uint32_t)q0 <= 32767u) ? p - (uint32_t)q0 : 0;
-            QZK_PREV(p & (QZK_WSIZE - 1)) = (uint16_t)d;
-            head[bucket] = (uint16_t)p;
-        }
-        qz_lds_sync();
-        {   /* suspect inserted lanes, in position order */
+        /* clean inserted lanes: my position goes in front of the entry seen at window start, its oldest one drops out */
+        if (isI && !suspect) bkt[bucket] = (uint64_t)p | (e0 << 16);
+        {   /* suspect inserted lanes, in position order: the entry is [me, the (up to three) most recent inserted lanes
+             * of this window with my hash, then what the table held at window start] */
             uint64_t todo = I & qz_ballot(suspect);
             QZK_C(10, qz_popc64(todo)); QZK_C(11, qz_popc64(Pm));
             while (todo) {
@@ -434,19 +414,17 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 todo &= todo - 1;
                 uint32_t b_j = qz_readlane(bucket, j);
                 uint64_t mates = qz_ballot(canh && bucket == b_j) & I & qz_below(j);
-                uint32_t d;
-                if (mates) d = (uint32_t)(j - qz_msb64(mates));
-                else {
-                    uint32_t q0j = qz_readlane((uint32_t)q0, j), pj = B + (uint32_t)j;
-                    d = (q0j != 0 && pj - q0j <= 32767u) ? pj - q0j : 0;
+                uint64_t ent = (uint64_t)(B + (uint32_t)j);
+                int nf = 1;
+                while (mates && nf < 4) {
+                    const int m = qz_msb64(mates);
+                    mates &= ~(1ull << m);
+                    ent |= (uint64_t)(B + (uint32_t)m) << (16 * nf);
+                    nf++;
                 }
-                if (lane == j) {
-                    QZK_PREV(p & (QZK_WSIZE - 1)) = (uint16_t)d;
-                    head[bucket] = (uint16_t)p;
-                }
+                if (lane == j) bkt[bucket] = nf < 4 ? ent | (e0 << (16 * nf)) : ent;
             }
         }
-        qz_lds_sync();
         pos += (uint32_t)l;
         QZK_T(12);
     }
@@ -457,21 +435,17 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 #if defined(QZK_PROF) && !defined(QZ_SIM)
     for (int k = 0; k < 16; k++) mt->prof[k] = prof[k];
 #endif
-#undef QZK_PREV
 #undef QZK_RING16
 }
 
-/* K1 launch shape: persistent single-wave workgroups pull chunk numbers from one counter shared by the two
- * variants (launched side by side on two streams), so the table slices are per resident workgroup - they stay
- * warm in L2/MALL - and uneven chunks balance themselves.  head_slots: (slot_base + blockIdx.x) * 128 KiB;
- * prev_slots (HBM variant only): blockIdx.x * 64 KiB. */
-template <bool PL>
+/* K1 launch shape: persistent single-wave workgroups pull chunk numbers from a counter, so the 512 KiB table is per
+ * resident workgroup - it stays warm in L2/MALL as far as it fits - and uneven chunks balance themselves.
+ * tables: blockIdx.x * 65536 entries. */
 QZ_KERNEL_MAX(64) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
-                               uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint16_t *head_slots,
-                               uint16_t *prev_slots, uint32_t slot_base, uint32_t *counter)
+                                       uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint64_t *tables,
+                                       uint32_t *counter)
 {
-    uint16_t *head = head_slots + (uint64_t)(slot_base + blockIdx.x) * QZK_HSIZE;
-    uint16_t *prev_g = PL ? (uint16_t *)0 : prev_slots + (uint64_t)blockIdx.x * QZK_WSIZE;
+    uint64_t *bkt = tables + (uint64_t)blockIdx.x * QZK_HSIZE;
     for (;;) {
         /* no `if (lane == 0)` anywhere on this loop's path: the compiler threads lane-0-only blocks of consecutive
          * iterations together, after which the other 63 lanes would run readfirstlane without lane 0 (seen on
@@ -479,7 +453,7 @@ QZ_KERNEL_MAX(64) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uin
         uint32_t chunk = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);
         chunk = qz_readfirstlane(chunk);
         if (chunk >= nchunks) break;
-        qzk_lz77_chunk<PL>(src, src_len, chunk_sz, chunk, sym_lc, sym_dist, meta, head, prev_g);
+        qzk_lz77_chunk(src, src_len, chunk_sz, chunk, sym_lc, sym_dist, meta, bkt);
     }
 }
 

@@ -19,24 +19,20 @@
 extern "C" {
 
 /* K1 through its persistent pull kernel: `wgs` workgroups share the chunk counter (the emulator runs them one after
- * the other, so the first one takes every chunk and its table slices are reused dirty - the interesting case).
- * variant 0: prev[] in LDS, 1: prev[] in a global slice. */
-static void run_k1(int variant, uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint32_t nchunks,
+ * the other, so the first one takes every chunk and its table is reused dirty - the interesting case). */
+static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint32_t nchunks,
                    uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta)
 {
-    std::vector<uint16_t> head((size_t)wgs * QZK_HSIZE, 0xabcd), prev((size_t)wgs * QZK_WSIZE, 0x5a5a);
+    std::vector<uint64_t> tables((size_t)wgs * QZK_HSIZE, 0xabcdabcdabcdabcdull);
     uint32_t counter = 0;
-    if (variant == 0)
-        sim::launch(wgs, 64, 0, [&] { qzk_lz77_pull_kernel<true>(src, n, chunk_sz, nchunks, lc, dist, meta, head.data(), prev.data(), 0u, &counter); });
-    else
-        sim::launch(wgs, 64, 0, [&] { qzk_lz77_pull_kernel<false>(src, n, chunk_sz, nchunks, lc, dist, meta, head.data(), prev.data(), 0u, &counter); });
+    sim::launch(wgs, 64, 0, [&] { qzk_lz77_pull_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, tables.data(), &counter); });
 }
 
 /* K1 only: symbols + meta of every chunk */
 int sim_lz77(const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta)
 {
     uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
-    run_k1(0, 2, src, n, chunk_sz, nchunks, lc, dist, meta);
+    run_k1(2, src, n, chunk_sz, nchunks, lc, dist, meta);
     return (int)nchunks;
 }
 
@@ -51,7 +47,7 @@ static int deflate_variant(int variant, const uint8_t *src, uint64_t n, uint32_t
     uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
     std::vector<uint8_t> slots((size_t)nchunks * stride);
     std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
-    run_k1(variant, 2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data());
+    (void)variant; run_k1(2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data());
     sim::launch(nchunks, QZK_HW, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
                         last ? nchunks - 1 : ~0u, olen.data());

@@ -82,10 +82,10 @@ def test_lane_per_chunk_kernel_is_bit_exact_too(ctx, monkeypatch):
         assert got == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2], (kind, n, chunk)
 
 
-@pytest.mark.parametrize("mix", ["3,0", "0,5", "2,3", "0,3072"])
+@pytest.mark.parametrize("mix", ["1", "3", "5", "3072"])
 def test_k1_residency_variants_are_bit_exact(monkeypatch, mix):
-    # K1's persistent workgroups come in two variants (prev[] in LDS / in an HBM slice) that pull chunks from one
-    # counter; force each one, and a mix, with few workgroups so every workgroup reuses its table slices many times
+    # K1's persistent workgroups pull chunks from one counter and reuse their candidate table chunk after chunk;
+    # force few workgroups so that every one of them does so many times
     import qatzip_amd
     monkeypatch.setenv("QATZIP_AMD_K1_WGS", mix)
     c = qatzip_amd.Context(0)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: sweep K1's residency mix (QATZIP_AMD_K1_WGS="<prev-in-LDS wgs>,<prev-in-HBM wgs>") and print
+"""Developer tool: sweep K1's residency (QATZIP_AMD_K1_WGS=<persistent workgroups>) and print
 the K1 launch time of a full batch plus whole-call compress throughput.  usage: k1_sweep.py [MiB] cfg cfg ..."""
 import os
 import sys
@@ -13,7 +13,7 @@ import qatzip_amd  # noqa: E402
 
 def main():
     mb = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    cfgs = sys.argv[2:] or ["512,0", "512,512"]
+    cfgs = sys.argv[2:] or ["3072"]
     total = mb << 20
     base = datagen.gen("silesia", min(128 << 20, total), 20250523)
     ref = None
