@@ -180,7 +180,7 @@ def main():
                        "chunk": CHUNK, "ratio": round(ratio, 4), "parallelism": "chunks sharded over %d rank(s), "
                        "no data-path collective" % world,
                        "compress_GBps": round(raw_total / tc / 1e9, 3), "decompress_GBps": round(raw_total / td / 1e9, 3)},
-            "roofline": {"bound": "hbm", "kernel": "qzk_lz77_pull_kernel<false>", "achieved": round(achieved, 3),
+            "roofline": {"bound": "hbm", "kernel": "qzk_lz77_pull_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
                          "launch_ms": round(launch_ms, 3), "launches": int(k1_launches),

@@ -2,14 +2,14 @@
  * qzd_device.hip — host side of the device-resident C ABI (include/qzamd_device.h)
  * and the small utility kernels (size scan, slot gather).  gfx950 only.
  *
- * A call is cut into batches of qzd_ctx::batch_chunks chunks.  Per batch, on one stream:
- *   K1 qzk_lz77_kernel  (1 wave / chunk, 132 KiB LDS => one workgroup per CU)
- *   K2 qzk_huff_kernel  (256 threads / chunk) -> per-chunk slot + length + crc32
+ * A call is cut into batches of qzd_ctx::batch_chunks chunks (three rounds over the resident K1 workgroups).
+ * Per batch, on one of two streams:
+ *   K1 qzk_lz77_pull_kernel  (persistent single-wave workgroups, 16 per CU, each with its 512 KiB candidate table)
+ *   K2 qzk_huff_kernel       (one wave per chunk) -> per-chunk slot + length;  qzk_crc_chunks_kernel -> crc32
  *   scan of the lengths (running total carried in HBM, no host round trip)
  *   gather of the slots into the contiguous destination
- * Scratch (symbols, slots) is double-buffered and batches alternate between two
- * streams, so K1 of batch b+1 (latency-bound, 1 wave per CU) overlaps K2/gather of
- * batch b (which co-reside on the same CUs: they need < 16 KiB LDS).
+ * Scratch (symbols, slots) is double-buffered and batches alternate between the streams: K1 of batch b+1 (which
+ * needs K1 of batch b to be done - they share the tables) overlaps K2/crc/scan/gather of batch b.
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>

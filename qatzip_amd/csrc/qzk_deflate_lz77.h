@@ -15,12 +15,13 @@
  *     candidate compares); a short wave-uniform loop then hops from parse point
  *     to parse point with v_readlane, and only lanes whose hash bucket was also
  *     touched earlier in the same window take a slower exact path.
- *   - zlib's exact tables: prev[] (32768 x u16 distances) lives in LDS, head[]
- *     (65536 x u16, indexed by the 16-bit hash) in HBM/L2 - one gather and one
- *     scatter per window - so a workgroup needs 72 KiB of LDS and two chunks are
- *     resident per CU; chains are walked exactly like zlib's (<= 4 candidates).
- *   - the 64 KiB input window is read straight from HBM/L2 (coalesced for the
- *     lanes' own bytes, gathers for candidates): LDS is spent on the tables.
+ *   - zlib's head[] + prev[] chains are kept as one table: per 16-bit hash the four
+ *     newest inserted window positions (level 1 never follows more than four links),
+ *     4 x u16 in HBM/L2 - one 8-byte gather and one scatter per window, no dependent
+ *     chain reads; 512 KiB per resident workgroup (16 of them per CU).
+ *   - LDS (8 KiB) holds a 4 KiB ring of the most recent input, from which the lanes'
+ *     own bytes and three quarters of the candidates are compared, and the per-window
+ *     slot tables; far candidates are gathered from HBM/L2.
  *   - zlib's window slide (strstart >= 65274 => rebase by 32768, NIL==0) is
  *     reproduced literally, so chunks up to 512 KiB and odd tail sizes match.
  */
@@ -403,17 +404,22 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         nsym += (uint32_t)qz_popc64(Pm);
 
         QZK_T(7);
-        /* clean inserted lanes: my position goes in front of the entry seen at window start, its oldest one drops out */
-        if (isI && !suspect) bkt[bucket] = (uint64_t)p | (e0 << 16);
-        {   /* suspect inserted lanes, in position order: the entry is [me, the (up to three) most recent inserted lanes
-             * of this window with my hash, then what the table held at window start] */
+        /* table commit, ONE scatter per window (the texture path is what K1 saturates: every extra store instruction
+         * counts).  A clean inserted lane puts its position in front of the entry seen at window start (the oldest one
+         * drops out).  Suspect inserted lanes, in position order: the entry is [me, the (up to three) most recent
+         * inserted lanes of this window with my hash, then what the table held at window start], and every earlier
+         * lane with that hash is superseded - only the last writer of a hash stores. */
+        uint64_t myent = (uint64_t)p | (e0 << 16);
+        bool store = isI;
+        {
             uint64_t todo = I & qz_ballot(suspect);
             QZK_C(10, qz_popc64(todo)); QZK_C(11, qz_popc64(Pm));
             while (todo) {
                 int j = qz_ctz64(todo);
                 todo &= todo - 1;
                 uint32_t b_j = qz_readlane(bucket, j);
-                uint64_t mates = qz_ballot(canh && bucket == b_j) & I & qz_below(j);
+                const uint64_t same = qz_ballot(canh && bucket == b_j) & I;
+                uint64_t mates = same & qz_below(j);
                 uint64_t ent = (uint64_t)(B + (uint32_t)j);
                 int nf = 1;
                 while (mates && nf < 4) {
@@ -422,9 +428,11 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                     ent |= (uint64_t)(B + (uint32_t)m) << (16 * nf);
                     nf++;
                 }
-                if (lane == j) bkt[bucket] = nf < 4 ? ent | (e0 << (16 * nf)) : ent;
+                if (lane == j) myent = nf < 4 ? ent | (e0 << (16 * nf)) : ent;
+                if (((same >> lane) & 1) && lane < j) store = false;
             }
         }
+        if (store) bkt[bucket] = myent;
         pos += (uint32_t)l;
         QZK_T(12);
     }

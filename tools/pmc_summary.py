@@ -37,8 +37,8 @@ def main():
         res["kernels"]["%s[grid=%d]" % k] = {
             "launches": nf.get(k, nw.get(k, 0)), "fetch_size_kib": round(f_kib, 1), "write_size_kib": round(w_kib, 1),
             "hbm_bytes_raw": int((f_kib + w_kib) * 1024), "hbm_bytes_fetch_x2": int((2 * f_kib + w_kib) * 1024)}
-    # the full-batch launches of K1 (largest grid of the prev-in-HBM pull kernel): what bench.py's roofline.traffic quotes
-    k1 = [k for k in res["kernels"] if k.startswith("qzk_lz77_pull_kernel<false>")]
+    # the full-batch launches of K1 (largest grid of the pull kernel): what bench.py's roofline.traffic quotes
+    k1 = [k for k in res["kernels"] if k.startswith("qzk_lz77_pull_kernel")]
     if k1:
         res["k1_key"] = max(k1, key=lambda k: int(k.split("grid=")[1].rstrip("]")))
         res["k1_launch_chunks"] = k1_chunks
