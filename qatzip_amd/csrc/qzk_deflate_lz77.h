@@ -129,7 +129,11 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 
     /* every entry NIL; one gather + one scatter of the table per window */
     qz_wave_sync();
-    for (int i = lane; i < QZK_HSIZE; i += 64) bkt[i] = 0;
+    {   /* 16 bytes per lane and store: the clear is a fifth of the kernel's store instructions otherwise */
+        typedef struct __attribute__((aligned(16))) { uint64_t a, b; } qz_u128;
+        const qz_u128 z = {0, 0};
+        for (int i = lane; i < QZK_HSIZE / 2; i += 64) ((qz_u128 *)bkt)[i] = z;
+    }
     qz_wave_sync();
 
     uint32_t base = 0;                              /* chunk offset of window position 0 */
@@ -299,13 +303,18 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             int nextc = cxr ? l + qz_ctz64(cxr) : 64;
             int stop = nextc < lim ? nextc : lim;
             while (l < stop) {                      /* hot loop: hop over clean parse points */
-                /* a run of literal lanes is a run of parse points: take it in one step, no readlane */
-                const uint64_t nl = NOLIT >> l;
-                int t = nl ? qz_ctz64(nl) : 64;
-                if (t > stop - l) t = stop - l;
-                if (t) { Pm |= qz_below(t) << l; l += t; continue; }
-                Pm |= 1ull << l;
-                l += (int)qz_readlane(mlen, l);
+                /* one trip = a run of literal lanes (each of them a parse point, no readlane needed) plus the match
+                 * lane that ends it.  The scalar unit is what sixteen waves per CU fight over, so this loop is kept
+                 * to a dozen scalar instructions per trip: bit 63 of the mask is a sentinel (no zero test), the
+                 * readlane is unconditional (its index is always a lane of the window), lim <= 61 keeps the
+                 * mask arithmetic clear of 64-bit shifts by 64. */
+                const uint64_t nl = (NOLIT | (1ull << 63)) >> l;
+                int e = l + qz_ctz64(nl);           /* first lane at or after l that is not a plain literal */
+                if (e > stop) e = stop;
+                const uint32_t ml = qz_readlane(mlen, e);
+                const int isM = e < stop ? 1 : 0;   /* inside [l, stop) that lane is a clean match (complex lanes end the range) */
+                Pm |= ((1ull << (e - l + isM)) - 1) << l;
+                l = e + (isM ? (int)ml : 0);
             }
             if (l >= lim || l != nextc) continue;
             /* -- exact path for lane l -- */
