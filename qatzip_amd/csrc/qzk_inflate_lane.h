@@ -517,6 +517,7 @@ QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
  * phase A, K after the speculative one); the chain says which pieces of which sub-streams make up the segment.  The
  * output-dependent checks (capacity, history) live here because a speculative sub-decoder does not know its offset. */
 #define QZK_RES_WAVES 4
+#define QZK_COOP_LEN 32            /* matches at least this long are copied by the whole wave */
 QZ_KERNEL_OCC(64 * QZK_RES_WAVES, 6) qzk_lz_resolve_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                 const qzk_tokseg *ts, uint32_t ts_stride, const uint8_t *lits, const qzk_seq *seqs,
                                 const qzk_chain *chains)
@@ -575,7 +576,23 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, 6) qzk_lz_resolve_kernel(const uint8_t *comp, 
                 const int f = qz_ctz64(pending);
                 const uint32_t m_f = qz_readlane(my_m, f);
                 const bool ready = ((pending >> lane) & 1) && (lane == f || src_end <= m_f);
-                if (ready) qzk_copy_match(o + (int64_t)my_m, dist, mlen);
+                /* short matches: their lane copies them.  Long ones (runs, repeated records) would be dozens of
+                 * one-lane load/store pairs on a texture path that is already the bottleneck: the whole wave copies
+                 * them, a byte per lane and step, reading the source period-wise when the match overlaps itself */
+                uint64_t wide = qz_ballot(ready && mlen >= QZK_COOP_LEN);
+                if (ready && mlen < QZK_COOP_LEN) qzk_copy_match(o + (int64_t)my_m, dist, mlen);
+                while (wide) {
+                    const int g = qz_ctz64(wide);
+                    wide &= wide - 1;
+                    const uint32_t M = qz_readlane(my_m, g), D = qz_readlane(dist, g), L = qz_readlane(mlen, g);
+                    const uint32_t stp = 64u % D;
+                    uint32_t r = (uint32_t)lane % D;
+                    const uint8_t *sp = o + ((int64_t)M - (int64_t)D);
+                    for (uint32_t i = (uint32_t)lane; i < L; i += 64) {
+                        o[M + i] = sp[r];
+                        r += stp; if (r >= D) r -= D;
+                    }
+                }
                 pending &= ~qz_ballot(ready);
                 qz_wave_sync();
             }
