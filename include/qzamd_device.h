@@ -54,7 +54,7 @@ void qzd_host_free_pinned(void *p);
 /*
  * Raw-deflate `n` bytes at d_src exactly as the reference's software path does
  * for one qzCompress() call (src/qatzip_sw.c:178-231): independent chunks of
- * chunk_sz bytes, zlib level `level` (1 only in round 1), every chunk closed by
+ * chunk_sz bytes, zlib level `level` (1-9; 1 is the tuned path), every chunk closed by
  * the Z_FULL_FLUSH marker except — when last != 0 — the final one, which
  * carries BFINAL.  n == 0 emits the single empty final block (last) or the
  * bare marker.  The stream is written contiguously to d_dst.

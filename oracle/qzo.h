@@ -44,7 +44,7 @@ uint32_t qzo_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 uint32_t qzo_adler32(uint32_t adler, const uint8_t *p, size_t n);
 uint32_t qzo_xxh32(const uint8_t *p, size_t n, uint32_t seed);
 
-/* raw deflate of ONE chunk with fresh state, zlib levels 1..3 (deflate_fast),
+/* raw deflate of ONE chunk with fresh state, zlib levels 1..9 (deflate_fast 1-3, deflate_slow 4-9),
  * memLevel 9, wbits 15.  final=0 ends with the Z_FULL_FLUSH marker, final=1 with
  * BFINAL.  Returns bytes written or (size_t)-1 on overflow. */
 size_t qzo_deflate_chunk(const uint8_t *src, size_t n, uint8_t *dst, size_t cap,

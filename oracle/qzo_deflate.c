@@ -2,8 +2,8 @@
  * qzo_deflate.c — restatement of zlib 1.2.11's deflate for the configuration
  * the QATzip software path fixes:  deflateInit2(level, Z_DEFLATED, +-15/31,
  * MAX_MEM_LEVEL(9), Z_DEFAULT_STRATEGY)   (src/qatzip_sw.c:147-152), levels 1-3
- * (zlib's greedy "deflate_fast" family), driven per hw_buff_sz chunk with
- * Z_FULL_FLUSH / Z_FINISH (src/qatzip_sw.c:178-231).
+ * (zlib's greedy "deflate_fast" family) and 4-9 (lazy "deflate_slow"), driven
+ * per hw_buff_sz chunk with Z_FULL_FLUSH / Z_FINISH (src/qatzip_sw.c:178-231).
  * TEST INFRASTRUCTURE (see qzo.h).
  *
  * zlib is not vendored in /root/reference; this file restates its published
@@ -63,7 +63,9 @@ typedef struct {
     uint16_t head[65536], prev[WSIZE];
     uint32_t strstart, lookahead, match_start, match_length, ins_h;
     long block_start;
-    int max_chain, nice_match, max_insert;
+    int max_chain, nice_match, max_insert;          /* max_insert doubles as max_lazy_match, as in zlib */
+    int good_match, lazy;                           /* lazy: levels 4-9 */
+    uint32_t prev_length, prev_match; int match_available;
     /* symbol buffers */
     uint16_t d_buf[LIT_BUFSIZE]; uint8_t l_buf[LIT_BUFSIZE]; uint32_t last_lit;
     /* trees */
@@ -418,9 +420,10 @@ static uint32_t longest_match(dstate_t *s, uint32_t cur_match)
 {
     unsigned chain_length = (unsigned)s->max_chain;
     const uint8_t *scan = s->window + s->strstart, *match;
-    int len, best_len = MIN_MATCH - 1, nice_match = s->nice_match;
+    int len, best_len = (int)s->prev_length, nice_match = s->nice_match;    /* prev_length stays 2 in the greedy levels */
     uint32_t limit = s->strstart > MAX_DIST ? s->strstart - MAX_DIST : 0;
 
+    if (s->prev_length >= (uint32_t)s->good_match) chain_length >>= 2;     /* a good match already: search less */
     if ((uint32_t)nice_match > s->lookahead) nice_match = (int)s->lookahead;
     do {
         match = s->window + cur_match;
@@ -477,15 +480,72 @@ static void deflate_fast_chunk(dstate_t *s, int final)
     stored_block(s, NULL, 0, 0);
 }
 
+/* levels 4-9: lazy evaluation.  A match found at p is held back one step; it is emitted only if the search at p+1
+ * (shortened when the held match is already good, skipped when it reaches max_lazy) finds nothing longer, otherwise
+ * byte p goes out as a literal and the new match is held in turn.  Every position of an emitted match is inserted. */
+#define TOO_FAR 4096
+static void deflate_slow_chunk(dstate_t *s, int final)
+{
+    uint32_t hash_head; int bflush;
+    for (;;) {
+        if (s->lookahead < MIN_LOOKAHEAD) {
+            fill_window(s);
+            if (s->lookahead == 0) break;
+        }
+        hash_head = 0;
+        if (s->lookahead >= MIN_MATCH) INSERT_STRING(s, s->strstart, hash_head);
+        s->prev_length = s->match_length; s->prev_match = s->match_start;
+        s->match_length = MIN_MATCH - 1;
+        if (hash_head != 0 && s->prev_length < (uint32_t)s->max_insert && s->strstart - hash_head <= MAX_DIST) {
+            s->match_length = longest_match(s, hash_head);
+            if (s->match_length <= 5 && s->match_length == MIN_MATCH && s->strstart - s->match_start > TOO_FAR)
+                s->match_length = MIN_MATCH - 1;                /* a far 3-byte match costs more than 3 literals */
+        }
+        if (s->prev_length >= MIN_MATCH && s->match_length <= s->prev_length) {
+            uint32_t max_ins = s->strstart + s->lookahead - MIN_MATCH;
+            bflush = tally(s, s->strstart - 1 - s->prev_match, s->prev_length - MIN_MATCH);
+            s->lookahead -= s->prev_length - 1;
+            s->prev_length -= 2;
+            do {
+                if (++s->strstart <= max_ins) INSERT_STRING(s, s->strstart, hash_head);
+            } while (--s->prev_length != 0);
+            s->match_available = 0;
+            s->match_length = MIN_MATCH - 1;
+            s->strstart++;
+            if (bflush) flush_block(s, 0);
+        } else if (s->match_available) {
+            bflush = tally(s, 0, s->window[s->strstart - 1]);
+            if (bflush) flush_block(s, 0);                      /* the block ends before the byte still held */
+            s->strstart++; s->lookahead--;
+        } else {
+            s->match_available = 1;
+            s->strstart++; s->lookahead--;
+        }
+    }
+    if (s->match_available) { tally(s, 0, s->window[s->strstart - 1]); s->match_available = 0; }
+    if (final) { flush_block(s, 1); return; }
+    if (s->last_lit) flush_block(s, 0);
+    stored_block(s, NULL, 0, 0);
+}
+
+static void deflate_chunk(dstate_t *s, int final)
+{
+    if (s->lazy) deflate_slow_chunk(s, final); else deflate_fast_chunk(s, final);
+}
+
 static dstate_t *dstate_new(int level)
 {
-    static const int cfg[4][3] = {{0,0,0}, {4, 8, 4}, {5, 16, 8}, {6, 32, 32}}; /* max_insert, nice, chain */
+    /* zlib's configuration_table: good_length, max_lazy (= max_insert for the greedy levels), nice_length, max_chain */
+    static const int cfg[10][4] = {{0, 0, 0, 0}, {4, 4, 8, 4}, {4, 5, 16, 8}, {4, 6, 32, 32}, {4, 4, 16, 16}, {8, 16, 32, 32},
+                                   {8, 16, 128, 128}, {8, 32, 128, 256}, {32, 128, 258, 1024}, {32, 258, 258, 4096}};
     dstate_t *s;
     if (!tables_ready) tables_init();
-    if (level < 1 || level > 3) return NULL;
+    if (level < 1 || level > 9) return NULL;
     s = (dstate_t *)calloc(1, sizeof(*s));
     if (!s) return NULL;
-    s->max_insert = cfg[level][0]; s->nice_match = cfg[level][1]; s->max_chain = cfg[level][2];
+    s->good_match = cfg[level][0]; s->max_insert = cfg[level][1]; s->nice_match = cfg[level][2]; s->max_chain = cfg[level][3];
+    s->lazy = level >= 4;
+    s->prev_length = MIN_MATCH - 1;
     s->l_desc = (tdesc_t){s->dyn_ltree, static_ltree, extra_lbits, 257, L_CODES, 15, 0};
     s->d_desc = (tdesc_t){s->dyn_dtree, static_dtree, extra_dbits, 0, D_CODES, 15, 0};
     s->bl_desc = (tdesc_t){s->bl_tree, NULL, extra_blbits, 0, BL_CODES, 7, 0};
@@ -499,7 +559,7 @@ size_t qzo_deflate_chunk(const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
     dstate_t *s = dstate_new(level); size_t r;
     if (!s) return (size_t)-1;
     s->in = src; s->avail_in = (uint32_t)n; s->out = dst; s->out_cap = cap;
-    deflate_fast_chunk(s, final);
+    deflate_chunk(s, final);
     r = s->overflow ? (size_t)-1 : s->out_pos;
     free(s);
     return r;
@@ -512,7 +572,7 @@ size_t qzo_deflate_symbols(const uint8_t *src, size_t n, int level, uint8_t *lc,
     tmp = (uint8_t *)malloc(n + n / 8 + 1024);
     s->in = src; s->avail_in = (uint32_t)n; s->out = tmp; s->out_cap = n + n / 8 + 1024;
     s->dump_lc = lc; s->dump_dist = dist; s->dump_cap = cap;
-    deflate_fast_chunk(s, 1);
+    deflate_chunk(s, 1);
     r = s->dump_n;
     free(tmp); free(s);
     return r;

@@ -50,7 +50,7 @@ static void usage(FILE *f)
             "  -o <name>     output name (the format suffix is appended when compressing)\n"
             "  -A <alg>      deflate | lz4                         (default deflate)\n"
             "  -O <fmt>      gzip | gzipext | deflate_4B | lz4     (default gzipext)\n"
-            "  -L <level>    compression level                     (this backend: 1)\n"
+            "  -L <level>    compression level                     (deflate: 1-9, zlib's levels; lz4: 1-2)\n"
             "  -C <bytes>    chunk size, a power of two 1K..512K   (default 65536)\n"
             "  -b <bytes>    bytes per qzCompress call = per member (default 512 MiB)\n"
             "  -q            no statistics\n"

@@ -379,7 +379,8 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
 {
     const int fmt = s->p.fmt;
     const uint32_t n = *src_len, cap = *dest_len, hw = s->p.hw_buff_sz;
-    if (s->p.comp_lvl != 1) { logmsg(LOG_ERROR, "comp_lvl %u: only level 1 runs on the GPU path\n", s->p.comp_lvl); return QZ_NOT_SUPPORTED; }
+    const unsigned lvl = s->p.comp_lvl;
+    if (lvl < 1 || lvl > 9) { logmsg(LOG_ERROR, "comp_lvl %u: zlib has levels 1-9\n", lvl); return QZ_NOT_SUPPORTED; }
     const bool opening = !s->open;
     const unsigned hl = opening ? hdr_len(fmt) : 0;
     *src_len = 0; *dest_len = 0;
@@ -412,10 +413,14 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
     const bool complete = take == nchunks;
     const uint32_t used = complete ? n : take * hw;
     if (opening) {                                                  /* header, src/qatzip_sw.c:61-75,158-171 and zlib's own gzip header */
-        if (fmt == F_GZIP) { static const unsigned char h[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 3}; memcpy(dest, h, 10); }
-        else if (fmt == F_GZIP_EXT) { static const unsigned char h[24] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0, 'Q', 'Z', 8, 0}; memcpy(dest, h, 24); }
+        const unsigned char xfl = lvl == 9 ? 2 : lvl < 2 ? 4 : 0;   /* zlib's gzip XFL: 2 = best, 4 = fastest */
+        if (fmt == F_GZIP) { static const unsigned char h[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 3}; memcpy(dest, h, 10); dest[8] = xfl; }
+        else if (fmt == F_GZIP_EXT) { static const unsigned char h[24] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0, 'Q', 'Z', 8, 0}; memcpy(dest, h, 24); dest[8] = xfl; }
         else if (fmt == F_4B) wr32(dest, 0);
-        else if (fmt == F_ZLIB) { dest[0] = 0x78; dest[1] = 0x01; }  /* CMF deflate/32K window, FLEVEL 0 (level 1), FCHECK */
+        else if (fmt == F_ZLIB) {                                   /* CMF deflate/32K window; FLG = FLEVEL by level + FCHECK */
+            static const unsigned char flg[4] = {0x01, 0x5e, 0x9c, 0xda};
+            dest[0] = 0x78; dest[1] = flg[lvl < 2 ? 0 : lvl < 6 ? 1 : lvl == 6 ? 2 : 3];
+        }
         s->open = true; s->run_sum = fmt == F_ZLIB ? 1u : 0u; s->st_in = 0; s->st_out = hl;
     }
     if (bytes && qzd_d2h(s->ctx, dest + hl, s->d_out, bytes) != QZD_OK) return QZ_FAIL;

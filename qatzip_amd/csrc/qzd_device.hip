@@ -232,12 +232,10 @@ static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
 }
 
 #include "qzk_deflate_lz77_lane.h"
-/* measured on MI355X: a lane needs ~290 ms per 64 KB chunk, so 32 768 chunks run at 4.6 GB/s
- * against 7.9 GB/s for the wave kernel; K1b only pays off beyond ~10^5 chunks in flight => opt-in for now */
-#define QZD_LZ_LANE_MIN_CHUNKS 0xffffffffu
-
-/* one batch = the whole call: K1b over every chunk, then K2, scan, gather */
-static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int last,
+/* K1b is zlib's loop with zlib's tables, one chunk per lane: the path of comp_lvl 2-9 (level 1 has its own kernel;
+ * QATZIP_AMD_DEFLATE=lane sends level 1 here too, for the parity tests).  One batch = the whole call: K1b over every
+ * chunk, then K2, scan, gather. */
+static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
                              uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks)
 {
     const uint32_t stride = slot_stride_for(chunk_sz);
@@ -277,7 +275,7 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     HIPCHK(c, hipMemsetAsync(head, 0, headb, st));
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
     hipLaunchKernelGGL(qzk_lz77_lane_kernel, dim3((nchunks + 63) / 64), dim3(64), 0, st, d_src, n, chunk_sz, nchunks,
-                       sym_lc, sym_dist, meta, head, prev);
+                       sym_lc, sym_dist, meta, head, prev, qzk_level_cfg(level));
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
     hipLaunchKernelGGL(qzk_huff_kernel, dim3(nchunks), dim3(QZK_HW), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist,
                        meta, slots, stride, last ? nchunks - 1 : ~0u, c->d_len);
@@ -299,16 +297,15 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
 {
     if (!c || !d_dst || (n && !d_src)) return QZD_ERR_PARAM;
     if (chunk_sz < 1024 || chunk_sz > 512 * 1024 || (chunk_sz & (chunk_sz - 1))) return QZD_ERR_PARAM;
-    if (level != 1) { snprintf(c->err, sizeof(c->err), "deflate level %d not implemented on the GPU path (level 1 only)", level); return QZD_ERR_UNSUPPORTED; }
+    if (level < 1 || level > 9) { snprintf(c->err, sizeof(c->err), "deflate level %d: zlib has levels 1-9", level); return QZD_ERR_UNSUPPORTED; }
     if (n > ((uint64_t)1 << 32)) return QZD_ERR_PARAM;
     hipSetDevice(c->device);
     const uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
     {
-        /* many chunks: one chunk per LANE (K1b, tables in HBM, every chunk of the call in flight at once);
-         * few chunks: one chunk per wave (K1, tables in LDS).  QATZIP_AMD_DEFLATE=lane|wave overrides. */
+        /* level 1: one chunk per wave (K1, window speculation over the four-newest table); levels 2-9: zlib's own loop
+         * and tables, one chunk per LANE (K1b).  QATZIP_AMD_DEFLATE=lane takes level 1 through K1b as well. */
         const char *force = getenv("QATZIP_AMD_DEFLATE");
-        const bool lanes = force ? force[0] == 'l' : nchunks >= QZD_LZ_LANE_MIN_CHUNKS;
-        if (lanes) return deflate_lane_path(c, d_src, n, chunk_sz, last, d_dst, dst_cap, nchunks);
+        if (level != 1 || (force && force[0] == 'l')) return deflate_lane_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks);
     }
     int rc = ensure_scratch(c, chunk_sz, nchunks);
     if (rc) return rc;

@@ -52,7 +52,21 @@ def main():
                         if n <= 4096 and kind in ("rand", "text", "runs", "lzmix"):
                             c["out_hex"] = out.hex() if n <= 1023 else None
                         cases.append(c)
-    # per-chunk symbol-stream goldens (kernel-level parity): first 64 symbols + count, via block decoding
+    # every zlib level the software path can be asked for (comp_lvl 1-9: greedy deflate_fast 1-3, lazy deflate_slow 4-9),
+    # with the level-dependent header bytes (gzip XFL, zlib FLEVEL); 131072 crosses the 64 KB window slide
+    for kind in ("text", "lzmix", "silesia", "records", "runs"):
+        for n in (0, 3, 100, 4096, 65536, 65537, 200777):
+            if kind == "lzmix" and n > 65537:
+                continue
+            src = datagen.gen_bytes(kind, n, seed + 1)
+            for level in range(2, 10):
+                for fname, hw in (("RAW", 65536), ("RAW", 131072), ("GZIP_EXT", 65536), ("GZIP", 65536), ("ZLIB", 65536)):
+                    if (hw == 131072 and n <= 65536) or (fname in ("GZIP", "ZLIB") and n not in (0, 100, 200777)):
+                        continue
+                    out = R.sw_compress(FMTS[fname], src, hw, level)
+                    cases.append({"kind": kind, "n": n, "seed": seed + 1, "fmt": fname, "hw": hw, "level": level,
+                                  "in_sha": datagen.sha(src), "crc32": zlib.crc32(src) & 0xffffffff,
+                                  "out_len": len(out), "out_sha": datagen.sha(out)})
     man = {"zlib": zlib.ZLIB_RUNTIME_VERSION, "lz4": R.lz4lib().LZ4_versionString().decode(),
            "generator": "tests/golden/gen_golden.py", "cases": cases}
     with open(os.path.join(HERE, "manifest.json"), "w") as f:

@@ -74,8 +74,8 @@ int sim_deflate_hbm(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last,
 }
 
 /* K1b (one chunk per lane) + K2 */
-int sim_deflate_lane(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len,
-                     uint32_t *crcs)
+static int deflate_lane_level(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, int level, uint8_t *out,
+                              uint64_t *out_len, uint32_t *crcs)
 {
     uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
     std::vector<uint8_t> lc(n + 64);
@@ -86,7 +86,8 @@ int sim_deflate_lane(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last
     std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
     std::vector<uint16_t> head((size_t)nchunks * QZK_HSIZE, 0), prev((size_t)nchunks * QZK_WSIZE, 0x5a5a);
     sim::launch((nchunks + 63) / 64, 64, 0, [&] {
-        qzk_lz77_lane_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), head.data(), prev.data());
+        qzk_lz77_lane_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), head.data(), prev.data(),
+                             qzk_level_cfg(level));
     });
     sim::launch(nchunks, QZK_HW, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
@@ -101,6 +102,18 @@ int sim_deflate_lane(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last
     }
     *out_len = pos;
     return (int)nchunks;
+}
+
+int sim_deflate_lane(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len, uint32_t *crcs)
+{
+    return deflate_lane_level(src, n, chunk_sz, last, 1, out, out_len, crcs);
+}
+
+/* K1b at any zlib level (2-3 greedy, 4-9 lazy) + K2 */
+int sim_deflate_level(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, int level, uint8_t *out, uint64_t *out_len,
+                      uint32_t *crcs)
+{
+    return deflate_lane_level(src, n, chunk_sz, last, level, out, out_len, crcs);
 }
 
 unsigned sim_meta_size(void) { return (unsigned)sizeof(qzk_lzmeta); }

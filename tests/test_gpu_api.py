@@ -219,10 +219,25 @@ def test_corrupt_input_is_a_data_error():
     s.close()
 
 
-def test_levels_other_than_one_fail_loudly():
-    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536, comp_lvl=6)
-    rc, used, out, _ = s.compress(b"x" * 1000, 1)
-    assert rc == A.QZ_NOT_SUPPORTED and used == 0 and out == b""
+def test_every_comp_lvl_matches_sw_path():
+    """comp_lvl 1-9 through qzCompress: the deflate body of that zlib level and the level-dependent header bytes (gzip
+    XFL 4 / 0 / 2, zlib FLEVEL) exactly as the software path writes them; levels zlib does not have fail loudly."""
+    src = datagen.gen_bytes("silesia", 300123, 41)
+    for lvl in range(1, 10):
+        for fmt in ("GZIP_EXT", "GZIP", "ZLIB"):
+            s = A.Session(hw_buff_sz=65536, comp_lvl=lvl, zlib_format=True) if fmt == "ZLIB" else A.Session(FMT[fmt], 65536, comp_lvl=lvl)
+            assert s.rc_setup == A.QZ_OK
+            rc, used, out, crc = s.compress(src, 1, crc0=0)
+            erc, eused, exp, ecrc = O.sw_compress(fmt, src, 65536, lvl, cap=len(src) * 9 // 8 + 65536)
+            assert rc == A.QZ_OK and used == len(src) and out == exp and crc == ecrc, (lvl, fmt, rc)
+            assert zlib.decompress(out, 15 if fmt == "ZLIB" else 31) == src
+            rc, cused, back = s.decompress(out, len(src) + 16)
+            assert rc == A.QZ_OK and back == src and cused == len(out)
+            s.close()
+    s = A.Session(hw_buff_sz=65536, comp_lvl=12, zlib_format=True)      # the new API admits 10-12 (QAT gen 3); zlib has no such levels
+    if s.rc_setup == A.QZ_OK:
+        rc, used, out, _ = s.compress(b"x" * 1000, 1)
+        assert rc == A.QZ_NOT_SUPPORTED and used == 0 and out == b""
     s.close()
 
 

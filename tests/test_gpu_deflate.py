@@ -19,11 +19,11 @@ def ctx():
     c.close()
 
 
-def _gpu_raw(ctx, src, chunk, last=1):
+def _gpu_raw(ctx, src, chunk, last=1, level=1):
     import qatzip_amd
     d_src = ctx.alloc(len(src)); d_src.upload(src)
     d_dst = ctx.alloc(qatzip_amd.max_deflate_len(len(src), chunk))
-    n, crcs = ctx.deflate_raw(d_src, len(src), chunk, 1, last, d_dst)
+    n, crcs = ctx.deflate_raw(d_src, len(src), chunk, level, last, d_dst)
     out = d_dst.download(n).tobytes()
     d_src.free(); d_dst.free()
     return out, crcs
@@ -80,6 +80,23 @@ def test_lane_per_chunk_kernel_is_bit_exact_too(ctx, monkeypatch):
         src = datagen.gen_bytes(kind, n, 123)
         got, crcs = _gpu_raw(ctx, src, chunk)
         assert got == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2], (kind, n, chunk)
+
+
+@pytest.mark.parametrize("level", [2, 3, 4, 5, 6, 7, 8, 9])
+def test_every_zlib_level_is_bit_exact(ctx, level):
+    """comp_lvl 2-9 (greedy 2-3, lazy 4-9): what the software path's deflateInit2(level, ...) writes, bit for bit —
+    short and empty inputs, the 65274 window slide (chunks > 64 KB), last = 0, many chunks in one call."""
+    for kind, n, chunk in (("silesia", 1 << 20, 65536), ("text", 300000, 131072), ("lzmix", 100000, 65536), ("rand", 70000, 16384),
+                           ("runs", 65400, 65536), ("records", 600000, 524288), ("allA", 200000, 65536), ("mod200", 9000, 1024),
+                           ("text", 0, 65536), ("text", 2, 65536), ("text", 3, 65536)):
+        src = datagen.gen_bytes(kind, n, 200 + level)
+        got, crcs = _gpu_raw(ctx, src, chunk, level=level)
+        assert got == O.sw_compress("RAW", src, chunk, level, cap=n * 9 // 8 + 65536)[2], (kind, n, chunk, level)
+        if n:
+            assert zlib.decompress(got, -15) == src
+    src = datagen.gen_bytes("text", 150000, level)
+    got, _ = _gpu_raw(ctx, src, 65536, last=0, level=level)
+    assert got == O.sw_compress("RAW", src, 65536, level, last=0, cap=200000)[2] and got.endswith(b"\x00\x00\xff\xff")
 
 
 @pytest.mark.parametrize("mix", ["1", "3", "5", "3072"])

@@ -118,5 +118,13 @@ def test_live_fuzz_against_system_zlib():
             if kind == "lzmix":
                 n = min(n, 40000)
             src = datagen.gen_bytes(kind, n, 100 + seed)
-            for lvl in (1, 2, 3):
-                assert O.sw_compress("RAW", src, 65536, lvl)[2] == R.sw_compress(R.FMT_RAW, src, 65536, lvl)
+            for lvl in range(1, 10):                      # 1-3 deflate_fast, 4-9 deflate_slow
+                assert O.sw_compress("RAW", src, 65536, lvl)[2] == R.sw_compress(R.FMT_RAW, src, 65536, lvl), (kind, n, lvl)
+    # chunk sizes either side of the 64 KB window (the slide at strstart >= 65274), last = 0, level-dependent header bytes
+    for kind, n, hw in (("silesia", 300000, 131072), ("records", 600000, 524288), ("text", 70000, 16384), ("runs", 140000, 131072)):
+        src = datagen.gen_bytes(kind, n, 5)
+        for lvl in range(2, 10):
+            assert O.sw_compress("RAW", src, hw, lvl, last=0)[2] == R.sw_compress(R.FMT_RAW, src, hw, lvl, last=0), (kind, hw, lvl)
+            for fmt, rf in (("GZIP", R.FMT_GZIP), ("GZIP_EXT", R.FMT_GZIP_EXT), ("ZLIB", R.FMT_ZLIB)):
+                assert O.sw_compress(fmt, src, hw, lvl)[2] == R.sw_compress(rf, src, hw, lvl), (kind, hw, lvl, fmt)
+            assert R.sw_compress(R.FMT_GZIP, src, hw, lvl) == R.gzip_stream_check(src, hw, lvl)

@@ -119,6 +119,23 @@ def test_lane_kernels_match_oracle(sim):
             assert [int(r["in_used"]) for r in res] == [len(pc) for pc in pieces]
 
 
+@pytest.mark.parametrize("level", [2, 3, 4, 5, 6, 7, 8, 9])
+def test_every_zlib_level_matches_oracle(sim, level):
+    """The general parse kernel (zlib's own loop per lane) at the greedy levels 2-3 and the lazy levels 4-9: the bytes
+    the software path writes at that comp_lvl (oracle pinned to libz 1.2.11 at every level, tests/test_oracle.py)."""
+    sim.sim_deflate_level.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    cases = [("text", 70000, 16384), ("silesia", 66000, 65536), ("runs", 140000, 131072), ("rand", 9000, 1024),
+             ("lzmix", 30000, 65536), ("records", 200000, 524288), ("allA", 70000, 65536), ("mod200", 40000, 65536), ("text", 0, 65536), ("text", 2, 1024)]
+    for kind, n, chunk in cases:
+        src = datagen.gen_bytes(kind, n, 20 + level)
+        nch = max(1, (n + chunk - 1) // chunk)
+        cap = n * 9 // 8 + 4096 * (nch + 1)
+        for last in (1, 0):
+            out = C.create_string_buffer(cap); ol = C.c_uint64(0); crcs = np.zeros(nch, np.uint32)
+            sim.sim_deflate_level(src, n, chunk, last, level, out, C.byref(ol), crcs.ctypes.data)
+            assert out.raw[:ol.value] == O.sw_compress("RAW", src, chunk, level, last=last, cap=cap)[2], (kind, n, chunk, level, last)
+
+
 def test_adler_chunks_kernel(sim):
     """the DEFLATE_ZLIB trailer checksum: per-chunk Adler-32 on the emulator against zlib.adler32"""
     sim.sim_adler.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p]
