@@ -65,6 +65,22 @@ void qzd_host_free_pinned(void *p);
 int qzd_deflate_raw(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
                     uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_chunk_crc);
 
+/*
+ * Many small requests in ONE launch — what the reference's asynchronous API is for (qzCompress2's ring + consumer
+ * thread, src/qatzip.c:3103-4110, keeps many requests in flight on the accelerator).  d_src holds nslots slots of
+ * chunk_sz bytes; a request occupies consecutive slots starting on a slot boundary; h_cdesc[k] = number of bytes in
+ * slot k (<= chunk_sz), with bit 31 set on the slot that ends its request: that slot's stream carries BFINAL, the
+ * others end in the flush marker, exactly as separate qzd_deflate_raw(last = 1) calls would write them.  All slot
+ * streams are written back to back to d_dst; h_slot_len[k] / h_slot_crc[k] give each slot's share and CRC-32.
+ */
+int qzd_deflate_slots(qzd_ctx *ctx, const uint8_t *d_src, uint32_t nslots, uint32_t chunk_sz, int level,
+                      const uint32_t *h_cdesc, uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len,
+                      uint32_t *h_slot_len, uint32_t *h_slot_crc);
+
+/* How the qzCompress2 submission queue has been doing: launches that carried more than one request, and the requests
+ * they carried (process-wide, since load).  Exported by the same library; not part of qatzip.h. */
+void qzamd_async_stats(uint64_t *launches, uint64_t *requests);
+
 /* asynchronous flavour used by bench.py: enqueue only; qzd_sync() + qzd_result() finish it */
 int qzd_deflate_raw_async(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
                           uint8_t *d_dst, uint64_t dst_cap);

@@ -373,6 +373,19 @@ static unsigned ftr_len(int fmt) { return (fmt == F_GZIP || fmt == F_GZIP_EXT) ?
 extern "C" uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);   /* qzd_device.hip */
 static void wr32be(unsigned char *p, uint32_t v) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; }
 
+/* member header with the size fields still zero (src/qatzip_sw.c:61-75,158-171 and zlib's own gzip / zlib headers) */
+static void write_header(unsigned char *dest, int fmt, unsigned lvl)
+{
+    const unsigned char xfl = lvl == 9 ? 2 : lvl < 2 ? 4 : 0;       /* zlib's gzip XFL: 2 = best, 4 = fastest */
+    if (fmt == F_GZIP) { static const unsigned char h[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 3}; memcpy(dest, h, 10); dest[8] = xfl; }
+    else if (fmt == F_GZIP_EXT) { static const unsigned char h[24] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0, 'Q', 'Z', 8, 0}; memcpy(dest, h, 24); dest[8] = xfl; }
+    else if (fmt == F_4B) wr32(dest, 0);
+    else if (fmt == F_ZLIB) {                                       /* CMF deflate/32K window; FLG = FLEVEL by level + FCHECK */
+        static const unsigned char flg[4] = {0x01, 0x5e, 0x9c, 0xda};
+        dest[0] = 0x78; dest[1] = flg[lvl < 2 ? 0 : lvl < 6 ? 1 : lvl == 6 ? 2 : 3];
+    }
+}
+
 /* ------------------------------------------------------------------ compress */
 static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
                             unsigned char *dest, unsigned int *dest_len, unsigned int last, unsigned long *crc)
@@ -413,14 +426,7 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
     const bool complete = take == nchunks;
     const uint32_t used = complete ? n : take * hw;
     if (opening) {                                                  /* header, src/qatzip_sw.c:61-75,158-171 and zlib's own gzip header */
-        const unsigned char xfl = lvl == 9 ? 2 : lvl < 2 ? 4 : 0;   /* zlib's gzip XFL: 2 = best, 4 = fastest */
-        if (fmt == F_GZIP) { static const unsigned char h[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 3}; memcpy(dest, h, 10); dest[8] = xfl; }
-        else if (fmt == F_GZIP_EXT) { static const unsigned char h[24] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0, 'Q', 'Z', 8, 0}; memcpy(dest, h, 24); dest[8] = xfl; }
-        else if (fmt == F_4B) wr32(dest, 0);
-        else if (fmt == F_ZLIB) {                                   /* CMF deflate/32K window; FLG = FLEVEL by level + FCHECK */
-            static const unsigned char flg[4] = {0x01, 0x5e, 0x9c, 0xda};
-            dest[0] = 0x78; dest[1] = flg[lvl < 2 ? 0 : lvl < 6 ? 1 : lvl == 6 ? 2 : 3];
-        }
+        write_header(dest, fmt, lvl);
         s->open = true; s->run_sum = fmt == F_ZLIB ? 1u : 0u; s->st_in = 0; s->st_out = hl;
     }
     if (bytes && qzd_d2h(s->ctx, dest + hl, s->d_out, bytes) != QZD_OK) return QZ_FAIL;
@@ -867,7 +873,7 @@ static pthread_mutex_t g_aq_lock = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_aq_more = PTHREAD_COND_INITIALIZER, g_aq_idle = PTHREAD_COND_INITIALIZER;
 static std::vector<AsyncReq> g_aq;          /* pending, oldest first */
 static size_t g_aq_head = 0;
-static QzSession_T *g_aq_running = NULL;    /* session of the request being executed */
+static std::vector<QzSession_T *> g_aq_running;   /* sessions of the requests being executed (one launch can carry many) */
 static bool g_aq_thread = false;
 
 static int run_sync2(QzSession_T *sess, const unsigned char *src, unsigned char *dest, QzResult_T *r, bool compress)
@@ -879,8 +885,103 @@ static int run_sync2(QzSession_T *sess, const unsigned char *src, unsigned char 
     return rc;
 }
 
+/* ---- the submission queue coalesces.  A 64 KB request alone keeps one wave of the GPU busy for milliseconds; what
+ * the asynchronous API is for is many requests in flight, and whatever is waiting when the consumer comes round goes
+ * to the device as ONE launch (qzd_deflate_slots): every request keeps its own member, header, trailer and CRC, and its
+ * bytes are what a call of its own would have produced. */
+#define AQ_BATCH_MAX_REQ   (4u << 20)      /* larger requests fill the device by themselves */
+#define AQ_BATCH_MAX_SLOTS 16384u
+static size_t g_aq_batches, g_aq_batched_reqs;       /* observability (qzamd_async_stats) */
+
+static Sess *batchable(const AsyncReq &q)
+{
+    Sess *s = NULL;
+    if (!q.compress || !q.sess || !q.res || ensure_ready(q.sess, &s) < 0 || !s) return NULL;
+    const int f = s->p.fmt;
+    if (!(f == F_GZIP || f == F_GZIP_EXT || f == F_RAW || f == F_4B) || s->open) return NULL;
+    if (s->p.comp_lvl < 1 || s->p.comp_lvl > 9 || q.res->src_len > AQ_BATCH_MAX_REQ) return NULL;
+    return s;
+}
+
+/* run[0..n) are batchable with equal (fmt, level, hw_buff_sz).  Returns false if the batch could not be run as a
+ * whole (nothing is reported then; the caller falls back to one call per request). */
+static bool compress_batch(const std::vector<AsyncReq> &run, const std::vector<Sess *> &ss)
+{
+    Sess *s0 = ss[0];
+    const int fmt = s0->p.fmt; const uint32_t hw = s0->p.hw_buff_sz; const unsigned lvl = s0->p.comp_lvl;
+    std::vector<uint32_t> cdesc, first(run.size());
+    for (size_t i = 0; i < run.size(); i++) {
+        const uint32_t n = run[i].res->src_len, nch = n ? (n + hw - 1) / hw : 1;
+        first[i] = (uint32_t)cdesc.size();
+        for (uint32_t k = 0; k < nch; k++) cdesc.push_back(std::min<uint32_t>(hw, n - k * hw) | (k + 1 == nch ? 0x80000000u : 0));
+    }
+    const uint32_t nslots = (uint32_t)cdesc.size();
+    const uint64_t in_bytes = (uint64_t)nslots * hw;
+    const uint64_t worst = in_bytes + (uint64_t)nslots * (5ull * (hw / 32767 + 2) + 16) + 64;
+    if (reserve(s0, in_bytes, worst) != QZ_OK) return false;
+    std::vector<unsigned char> stage(in_bytes);                  /* slot-aligned copy of every request's input */
+    for (size_t i = 0; i < run.size(); i++)
+        if (run[i].res->src_len) memcpy(stage.data() + (size_t)first[i] * hw, run[i].src, run[i].res->src_len);
+    if (qzd_h2d(s0->ctx, s0->d_in, stage.data(), in_bytes) != QZD_OK) return false;
+    std::vector<uint32_t> lens(nslots), crcs(nslots);
+    uint64_t produced = 0;
+    if (qzd_deflate_slots(s0->ctx, s0->d_in, nslots, hw, (int)lvl, cdesc.data(), s0->d_out, s0->out_cap, &produced,
+                          lens.data(), crcs.data()) != QZD_OK) {
+        logmsg(LOG_ERROR, "coalesced GPU deflate failed: %s\n", qzd_last_error(s0->ctx));
+        return false;
+    }
+    stage.resize(produced);
+    if (produced && qzd_d2h(s0->ctx, stage.data(), s0->d_out, produced) != QZD_OK) return false;
+
+    const unsigned hl = hdr_len(fmt), fl = ftr_len(fmt);
+    uint64_t pos = 0;
+    for (size_t i = 0; i < run.size(); i++) {
+        QzResult_T *r = run[i].res; unsigned char *dest = run[i].dest;
+        const uint32_t n = r->src_len, nch = n ? (n + hw - 1) / hw : 1, k0 = first[i];
+        uint64_t body = 0;
+        for (uint32_t k = 0; k < nch; k++) body += lens[k0 + k];
+        const uint64_t bpos = pos; pos += body;
+        if (hl + body + fl > r->dest_len) {                     /* too small for the whole member: the one-call path knows the partial-progress rules */
+            run_sync2(run[i].sess, run[i].src, dest, r, true);
+            continue;
+        }
+        unsigned long *crc = (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
+        write_header(dest, fmt, lvl);
+        memcpy(dest + hl, stage.data() + bpos, body);
+        uint32_t sum = 0, done = 0;
+        for (uint32_t k = 0; k < nch; k++) {                    /* same folds as compress_deflate */
+            const uint32_t cl = cdesc[k0 + k] & 0x7fffffffu;
+            if (fmt == F_GZIP || fmt == F_GZIP_EXT) sum = qzd_crc32_combine(sum, crcs[k0 + k], cl);
+            done += cl;
+            if (crc) {
+                if (fmt == F_RAW) *crc = qzd_crc32_combine((uint32_t)*crc, crcs[k0 + k], cl);
+                else {
+                    const uint32_t adler = fmt == F_4B ? 1u : sum;
+                    if (*crc == 0) *crc = adler; else *crc = qzd_crc32_combine((uint32_t)*crc, adler, done);
+                }
+            }
+        }
+        uint32_t total = hl + (uint32_t)body;
+        if (fmt == F_GZIP || fmt == F_GZIP_EXT) { wr32(dest + total, sum); wr32(dest + total + 4, n); total += 8; }
+        if (fmt == F_GZIP_EXT) { wr32(dest + 16, n); wr32(dest + 20, (uint32_t)body); }
+        if (fmt == F_4B) wr32(dest, (uint32_t)body);
+        r->dest_len = total; r->ext_rc = 0; r->status = QZ_OK;  /* src_len: all of it */
+        run[i].sess->total_in += n; run[i].sess->total_out += total; run[i].sess->thd_sess_stat = QZ_OK;
+    }
+    return true;
+}
+
+extern "C" void qzamd_async_stats(uint64_t *launches, uint64_t *requests)
+{
+    pthread_mutex_lock(&g_aq_lock);
+    if (launches) *launches = g_aq_batches;
+    if (requests) *requests = g_aq_batched_reqs;
+    pthread_mutex_unlock(&g_aq_lock);
+}
+
 static void *async_consumer(void *)
 {
+    std::vector<AsyncReq> run; std::vector<Sess *> ss;
     for (;;) {
         pthread_mutex_lock(&g_aq_lock);
         while (g_aq_head == g_aq.size()) {
@@ -888,13 +989,41 @@ static void *async_consumer(void *)
             pthread_cond_broadcast(&g_aq_idle);
             pthread_cond_wait(&g_aq_more, &g_aq_lock);
         }
-        AsyncReq q = g_aq[g_aq_head++];
-        g_aq_running = q.sess;
+        /* everything that is waiting and can share a launch with the oldest request - in order, so requests still
+         * retire in submission order */
+        run.clear(); ss.clear();
+        run.push_back(g_aq[g_aq_head++]);
+        g_aq_running.assign(1, run[0].sess);
         pthread_mutex_unlock(&g_aq_lock);
-        run_sync2(q.sess, q.src, q.dest, q.res, q.compress);
-        q.cb(q.res);
+        Sess *s0 = batchable(run[0]);
+        if (s0) {
+            ss.push_back(s0);
+            uint64_t slots = run[0].res->src_len / s0->p.hw_buff_sz + 1;
+            pthread_mutex_lock(&g_aq_lock);
+            while (g_aq_head < g_aq.size() && slots < AQ_BATCH_MAX_SLOTS) {
+                AsyncReq q = g_aq[g_aq_head];
+                pthread_mutex_unlock(&g_aq_lock);                /* ensure_ready may take the global lock */
+                Sess *s = batchable(q);
+                const bool ok = s && s->p.fmt == s0->p.fmt && s->p.comp_lvl == s0->p.comp_lvl && s->p.hw_buff_sz == s0->p.hw_buff_sz;
+                pthread_mutex_lock(&g_aq_lock);
+                if (!ok) break;
+                run.push_back(q); ss.push_back(s); g_aq_head++;
+                g_aq_running.push_back(q.sess);
+                slots += q.res->src_len / s0->p.hw_buff_sz + 1;
+            }
+            pthread_mutex_unlock(&g_aq_lock);
+        }
+        bool done = false;
+        if (run.size() > 1) {
+            done = compress_batch(run, ss);
+            if (done) { pthread_mutex_lock(&g_aq_lock); g_aq_batches++; g_aq_batched_reqs += run.size(); pthread_mutex_unlock(&g_aq_lock); }
+        }
+        for (size_t i = 0; i < run.size(); i++) {
+            if (!done) run_sync2(run[i].sess, run[i].src, run[i].dest, run[i].res, run[i].compress);
+            run[i].cb(run[i].res);
+        }
         pthread_mutex_lock(&g_aq_lock);
-        g_aq_running = NULL;
+        g_aq_running.clear();
         pthread_cond_broadcast(&g_aq_idle);
         pthread_mutex_unlock(&g_aq_lock);
     }
@@ -906,7 +1035,8 @@ static void async_drain(QzSession_T *sess)
 {
     pthread_mutex_lock(&g_aq_lock);
     for (;;) {
-        bool busy = g_aq_running && (!sess || g_aq_running == sess);
+        bool busy = false;
+        for (size_t i = 0; i < g_aq_running.size() && !busy; i++) busy = !sess || g_aq_running[i] == sess;
         for (size_t i = g_aq_head; i < g_aq.size() && !busy; i++) busy = !sess || g_aq[i].sess == sess;
         if (!busy) break;
         pthread_cond_wait(&g_aq_idle, &g_aq_lock);

@@ -166,6 +166,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     if (c->h_aux) hipHostFree(c->h_aux);
     if (c->d_big) hipFree(c->d_big);
     if (c->d_lane) hipFree(c->d_lane);
+    if (c->d_cdesc) hipFree(c->d_cdesc);
     delete c;
 }
 
@@ -236,7 +237,7 @@ static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
  * QATZIP_AMD_DEFLATE=lane sends level 1 here too, for the parity tests).  One batch = the whole call: K1b over every
  * chunk, then K2, scan, gather. */
 static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
-                             uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks)
+                             uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks, const uint32_t *cdesc)
 {
     const uint32_t stride = slot_stride_for(chunk_sz);
     const size_t symb = ((size_t)nchunks * chunk_sz + 511) & ~(size_t)255;
@@ -247,6 +248,7 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     if (need > c->lane_cap) {
         hipDeviceSynchronize();
         if (c->d_lane) hipFree(c->d_lane);
+    if (c->d_cdesc) hipFree(c->d_cdesc);
         c->d_lane = NULL; c->lane_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_lane, need));
         c->lane_cap = need;
@@ -275,11 +277,11 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     HIPCHK(c, hipMemsetAsync(head, 0, headb, st));
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
     hipLaunchKernelGGL(qzk_lz77_lane_kernel, dim3((nchunks + 63) / 64), dim3(64), 0, st, d_src, n, chunk_sz, nchunks,
-                       sym_lc, sym_dist, meta, head, prev, qzk_level_cfg(level));
+                       sym_lc, sym_dist, meta, head, prev, qzk_level_cfg(level), cdesc);
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
     hipLaunchKernelGGL(qzk_huff_kernel, dim3(nchunks), dim3(QZK_HW), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist,
-                       meta, slots, stride, last ? nchunks - 1 : ~0u, c->d_len);
-    hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(nchunks), dim3(QZK_HT), 0, st, d_src, n, chunk_sz, nchunks, c->d_crc);
+                       meta, slots, stride, last ? nchunks - 1 : ~0u, c->d_len, cdesc);
+    hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(nchunks), dim3(QZK_HT), 0, st, d_src, n, chunk_sz, nchunks, c->d_crc, cdesc);
     HIPCHK(c, hipEventRecord(c->ev[0][2], st));
     hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len, nchunks, c->d_offs, c->d_running);
     hipLaunchKernelGGL(qzk_gather_kernel, dim3(nchunks), dim3(256), 0, st, slots, stride, c->d_len, c->d_offs, nchunks,
@@ -292,8 +294,9 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     return QZD_OK;
 }
 
-extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
-                                     int last, uint8_t *d_dst, uint64_t dst_cap)
+/* cdesc (device memory, or NULL): per-chunk length / closes-its-stream flag of a coalesced launch (qzk_chunk_len) */
+static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
+                           int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc)
 {
     if (!c || !d_dst || (n && !d_src)) return QZD_ERR_PARAM;
     if (chunk_sz < 1024 || chunk_sz > 512 * 1024 || (chunk_sz & (chunk_sz - 1))) return QZD_ERR_PARAM;
@@ -305,7 +308,7 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
         /* level 1: one chunk per wave (K1, window speculation over the four-newest table); levels 2-9: zlib's own loop
          * and tables, one chunk per LANE (K1b).  QATZIP_AMD_DEFLATE=lane takes level 1 through K1b as well. */
         const char *force = getenv("QATZIP_AMD_DEFLATE");
-        if (level != 1 || (force && force[0] == 'l')) return deflate_lane_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks);
+        if (level != 1 || (force && force[0] == 'l')) return deflate_lane_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
     }
     int rc = ensure_scratch(c, chunk_sz, nchunks);
     if (rc) return rc;
@@ -337,14 +340,15 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
         if (k < QZD_K1EV) HIPCHK(c, hipEventRecord(c->k1ev[k][0], st));
         hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn,
-                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_tables, c->k1_counter + s);
+                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_tables, c->k1_counter + s, cdesc ? cdesc + b : NULL);
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
         hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HW), 0, st, d_src + boff, blen, chunk_sz, bn,
                            c->sym_lc[s], c->sym_dist[s], c->meta[s], c->slots[s], stride, final_chunk,
-                           c->d_len + b);
-        hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn, c->d_crc + b);
+                           c->d_len + b, cdesc ? cdesc + b : NULL);
+        hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn, c->d_crc + b,
+                           cdesc ? cdesc + b : NULL);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][2], st));
         /* the running total serialises scan/gather of consecutive batches across the two streams */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->done[so], 0));
@@ -362,6 +366,40 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
     HIPCHK(c, hipEventRecord(c->ev_end, c->st[0]));
     HIPCHK(c, hipGetLastError());
     return QZD_OK;
+}
+
+extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
+                                     int last, uint8_t *d_dst, uint64_t dst_cap)
+{
+    return deflate_enqueue(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, NULL);
+}
+
+/* Many small requests in one launch (the submission queue of qzCompress2, qz_api.cpp): d_src holds nslots slots of
+ * chunk_sz bytes; a request occupies consecutive slots from a slot boundary; h_cdesc[k] = bytes in slot k, bit 31 set
+ * on the slot that ends its request (it gets BFINAL, the others the flush marker).  The streams of all slots are
+ * written back to back to d_dst; h_slot_len / h_slot_crc give every slot's share and CRC-32. */
+extern "C" int qzd_deflate_slots(qzd_ctx *c, const uint8_t *d_src, uint32_t nslots, uint32_t chunk_sz, int level,
+                                 const uint32_t *h_cdesc, uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len,
+                                 uint32_t *h_slot_len, uint32_t *h_slot_crc)
+{
+    if (!c || !h_cdesc || !nslots) return QZD_ERR_PARAM;
+    hipSetDevice(c->device);
+    for (uint32_t k = 0; k < nslots; k++) if ((h_cdesc[k] & 0x7fffffffu) > chunk_sz) return QZD_ERR_PARAM;
+    if (nslots > c->cdesc_cap) {
+        hipDeviceSynchronize();
+        if (c->d_cdesc) hipFree(c->d_cdesc);
+        c->d_cdesc = NULL; c->cdesc_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_cdesc, (size_t)nslots * 4));
+        c->cdesc_cap = nslots;
+    }
+    HIPCHK(c, hipMemcpy(c->d_cdesc, h_cdesc, (size_t)nslots * 4, hipMemcpyHostToDevice));
+    int rc = deflate_enqueue(c, d_src, (uint64_t)nslots * chunk_sz, chunk_sz, level, 0, d_dst, dst_cap, c->d_cdesc);
+    if (rc) return rc;
+    rc = qzd_sync(c);
+    if (rc) return rc;
+    rc = qzd_result(c, h_out_len, h_slot_crc, nslots);
+    if (rc) return rc;
+    return h_slot_len ? qzd_chunk_lens(c, h_slot_len, nslots) : QZD_OK;
 }
 
 extern "C" int qzd_sync(qzd_ctx *c)

@@ -40,6 +40,7 @@ struct qzd_ctx {
     /* generic small scratch for the decompress side: device + pinned host mirror */
     uint8_t *d_aux, *h_aux; size_t aux_cap;
     uint8_t *d_big; size_t big_cap;                 /* device-only scratch (per-segment decode tables of K3b) */
+    uint32_t *d_cdesc; uint32_t cdesc_cap;          /* per-slot descriptors of a coalesced launch (qzd_deflate_slots) */
     uint8_t *d_lane; size_t lane_cap;               /* device-only scratch of the one-chunk-per-lane compress path (K1b) */
     float inf_ms[4];
     char err[256];

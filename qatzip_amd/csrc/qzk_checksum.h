@@ -23,13 +23,14 @@ QZ_KERNEL qzk_crc_kernel(const uint8_t *data, const qzk_range *ranges, uint32_t 
 
 /* CRC-32 of every hw_buff_sz chunk of a buffer (the per-chunk values the gzip trailers are folded from,
  * src/qatzip_sw.c:219-231 keeps them as zlib's running crc) */
-QZ_KERNEL qzk_crc_chunks_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks, uint32_t *crc_out)
+QZ_KERNEL qzk_crc_chunks_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks, uint32_t *crc_out,
+                                const uint32_t *cdesc /* per-chunk lengths of a coalesced launch, or NULL */)
 {
     QZ_LDS qzk_crc_lds S;
     const uint32_t c = blockIdx.x;
     if (c >= nchunks) return;
     const uint64_t off = (uint64_t)c * chunk_sz;
-    const uint32_t n = (uint32_t)((src_len - off) < chunk_sz ? (src_len - off) : chunk_sz);
+    const uint32_t n = cdesc ? (cdesc[c] & 0x7fffffffu) : (uint32_t)((src_len - off) < chunk_sz ? (src_len - off) : chunk_sz);
     const uint32_t v = qzk_block_crc32(&S, src + off, n);
     if (threadIdx.x == 0) crc_out[c] = v;
 }

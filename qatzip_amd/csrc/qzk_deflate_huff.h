@@ -437,7 +437,7 @@ QZ_DEV uint32_t qzk_block_crc32(qzk_crc_lds *S, const uint8_t *src, uint32_t n)
 QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                           const uint8_t *sym_lc, const uint16_t *sym_dist, const qzk_lzmeta *meta,
                           uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk /* index or ~0u */,
-                          uint32_t *out_len)
+                          uint32_t *out_len, const uint32_t *cdesc)
 {
     QZ_LDS qzk_huff_lds S;
     const int lane = qz_lane();
@@ -449,7 +449,7 @@ QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t
     const uint16_t *dists = sym_dist + coff;
     const qzk_lzmeta *mt = meta + chunk;
     const uint32_t n = mt->n, nsym = mt->nsym, nfull = mt->nfull, cs = mt->can_store;
-    const bool is_final = chunk == final_chunk;
+    const bool is_final = cdesc ? (cdesc[chunk] & QZK_CDESC_FINAL) != 0 : chunk == final_chunk;
     (void)src_len;
 
     qzk_bitout bo;

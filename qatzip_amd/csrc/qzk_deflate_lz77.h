@@ -62,6 +62,17 @@ typedef struct {
 #endif
 } qzk_lzmeta;
 
+/* A call is normally one buffer cut every chunk_sz bytes (only the last chunk is short, only the last can be final).
+ * A coalesced launch carries many small requests instead, each starting on a chunk boundary: cdesc[chunk] then gives
+ * the chunk's length (bits 0-30) and whether it closes its request's stream (bit 31).  NULL = the normal layout. */
+#define QZK_CDESC_FINAL 0x80000000u
+QZ_DEV uint32_t qzk_chunk_len(const uint32_t *cdesc, uint32_t chunk, uint64_t src_len, uint32_t chunk_sz)
+{
+    if (cdesc) return cdesc[chunk] & ~QZK_CDESC_FINAL;
+    const uint64_t coff = (uint64_t)chunk * chunk_sz;
+    return (uint32_t)((src_len - coff) < chunk_sz ? (src_len - coff) : chunk_sz);
+}
+
 QZ_DEV uint32_t qzk_ld32g(const uint8_t *src, uint64_t off, uint64_t src_len)
 {
     if (off + 4 <= src_len) return qz_ld32(src + off);
@@ -105,7 +116,7 @@ QZ_DEV int qzk_wave_matchlen(const uint8_t *src, uint64_t src_len, uint64_t a, u
  * instead of a gather plus up to three dependent ones; an insert shifts the entry.  512 KiB per resident workgroup,
  * in HBM/L2; LDS holds a ring of the most recent input and the per-window slot tables (8 KiB). */
 QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t chunk,
-                           uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint64_t *bkt)
+                           uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint64_t *bkt, const uint32_t *cdesc)
 {
     QZ_LDS uint32_t slot[QZK_NSLOT];       /* per-window: min(lane<<16 | hash) over the lanes on a hash key */
     QZ_LDS uint32_t scnt[QZK_NSLOT];       /* per-window: number of lanes on the key */
@@ -122,7 +133,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 
     const int lane = qz_lane();
     const uint64_t coff = (uint64_t)chunk * chunk_sz;
-    const uint32_t n = (uint32_t)((src_len - coff) < chunk_sz ? (src_len - coff) : chunk_sz);
+    const uint32_t n = qzk_chunk_len(cdesc, chunk, src_len, chunk_sz);
     uint8_t *olc = sym_lc + coff;
     uint16_t *odist = sym_dist + coff;
     qzk_lzmeta *mt = meta + chunk;
@@ -460,7 +471,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
  * tables: blockIdx.x * 65536 entries. */
 QZ_KERNEL_MAX(64) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                                        uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint64_t *tables,
-                                       uint32_t *counter)
+                                       uint32_t *counter, const uint32_t *cdesc)
 {
     uint64_t *bkt = tables + (uint64_t)blockIdx.x * QZK_HSIZE;
     for (;;) {
@@ -470,7 +481,7 @@ QZ_KERNEL_MAX(64) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uin
         uint32_t chunk = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);
         chunk = qz_readfirstlane(chunk);
         if (chunk >= nchunks) break;
-        qzk_lz77_chunk(src, src_len, chunk_sz, chunk, sym_lc, sym_dist, meta, bkt);
+        qzk_lz77_chunk(src, src_len, chunk_sz, chunk, sym_lc, sym_dist, meta, bkt, cdesc);
     }
 }
 

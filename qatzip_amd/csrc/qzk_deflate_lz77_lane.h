@@ -54,12 +54,13 @@ static inline qzk_lvlcfg qzk_level_cfg(int level)          /* level 1..9 */
 
 QZ_KERNEL qzk_lz77_lane_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                                uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta,
-                               uint16_t *head_all /* zeroed by the host */, uint16_t *prev_all, qzk_lvlcfg cfg)
+                               uint16_t *head_all /* zeroed by the host */, uint16_t *prev_all, qzk_lvlcfg cfg,
+                               const uint32_t *cdesc)
 {
     const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= nchunks) return;
     const uint64_t coff = (uint64_t)chunk * chunk_sz;
-    const uint32_t n = (uint32_t)((src_len - coff) < chunk_sz ? (src_len - coff) : chunk_sz);
+    const uint32_t n = qzk_chunk_len(cdesc, chunk, src_len, chunk_sz);
     uint8_t *olc = sym_lc + coff;
     uint16_t *odist = sym_dist + coff;
     qzk_lzmeta *mt = meta + chunk;

@@ -21,11 +21,11 @@ extern "C" {
 /* K1 through its persistent pull kernel: `wgs` workgroups share the chunk counter (the emulator runs them one after
  * the other, so the first one takes every chunk and its table is reused dirty - the interesting case). */
 static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint32_t nchunks,
-                   uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta)
+                   uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta, const uint32_t *cdesc = nullptr)
 {
     std::vector<uint64_t> tables((size_t)wgs * QZK_HSIZE, 0xabcdabcdabcdabcdull);
     uint32_t counter = 0;
-    sim::launch(wgs, 64, 0, [&] { qzk_lz77_pull_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, tables.data(), &counter); });
+    sim::launch(wgs, 64, 0, [&] { qzk_lz77_pull_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, tables.data(), &counter, cdesc); });
 }
 
 /* K1 only: symbols + meta of every chunk */
@@ -50,9 +50,9 @@ static int deflate_variant(int variant, const uint8_t *src, uint64_t n, uint32_t
     (void)variant; run_k1(2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data());
     sim::launch(nchunks, QZK_HW, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
-                        last ? nchunks - 1 : ~0u, olen.data());
+                        last ? nchunks - 1 : ~0u, olen.data(), nullptr);
     });
-    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data()); });
+    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data(), nullptr); });
     uint64_t pos = 0;
     for (uint32_t c = 0; c < nchunks; c++) {
         memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);
@@ -87,13 +87,13 @@ static int deflate_lane_level(const uint8_t *src, uint64_t n, uint32_t chunk_sz,
     std::vector<uint16_t> head((size_t)nchunks * QZK_HSIZE, 0), prev((size_t)nchunks * QZK_WSIZE, 0x5a5a);
     sim::launch((nchunks + 63) / 64, 64, 0, [&] {
         qzk_lz77_lane_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), head.data(), prev.data(),
-                             qzk_level_cfg(level));
+                             qzk_level_cfg(level), nullptr);
     });
     sim::launch(nchunks, QZK_HW, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
-                        last ? nchunks - 1 : ~0u, olen.data());
+                        last ? nchunks - 1 : ~0u, olen.data(), nullptr);
     });
-    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data()); });
+    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data(), nullptr); });
     uint64_t pos = 0;
     for (uint32_t c = 0; c < nchunks; c++) {
         memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);
@@ -114,6 +114,39 @@ int sim_deflate_level(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int las
                       uint32_t *crcs)
 {
     return deflate_lane_level(src, n, chunk_sz, last, level, out, out_len, crcs);
+}
+
+/* a coalesced launch: nchunks slots of chunk_sz bytes, slot k holds cdesc[k] & 0x7fffffff bytes and closes its request's
+ * stream when bit 31 is set.  Output: every slot's deflate bytes back to back, per-slot lengths and CRCs. */
+int sim_deflate_ragged(const uint8_t *src, uint32_t nchunks, uint32_t chunk_sz, const uint32_t *cdesc, int level, uint8_t *out,
+                       uint32_t *lens, uint32_t *crcs)
+{
+    const uint64_t n = (uint64_t)nchunks * chunk_sz;
+    std::vector<uint8_t> lc(n + 64);
+    std::vector<uint16_t> dist(n + 64);
+    std::vector<qzk_lzmeta> meta(nchunks);
+    uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
+    std::vector<uint8_t> slots((size_t)nchunks * stride);
+    std::vector<uint32_t> ocrc(nchunks);
+    if (level == 1) run_k1(2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), cdesc);
+    else {
+        std::vector<uint16_t> head((size_t)nchunks * QZK_HSIZE, 0), prev((size_t)nchunks * QZK_WSIZE, 0x5a5a);
+        sim::launch((nchunks + 63) / 64, 64, 0, [&] {
+            qzk_lz77_lane_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), head.data(), prev.data(),
+                                 qzk_level_cfg(level), cdesc);
+        });
+    }
+    sim::launch(nchunks, QZK_HW, 0, [&] {
+        qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride, ~0u, lens, cdesc);
+    });
+    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data(), cdesc); });
+    uint64_t pos = 0;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        memcpy(out + pos, slots.data() + (size_t)c * stride, lens[c]);
+        pos += lens[c];
+        crcs[c] = ocrc[c];
+    }
+    return (int)pos;
 }
 
 unsigned sim_meta_size(void) { return (unsigned)sizeof(qzk_lzmeta); }

@@ -161,6 +161,63 @@ def test_async_compress2_decompress2():
     s.close()                                                    # teardown waits for the queue of this session
 
 
+def test_async_queue_coalesces_small_requests():
+    """Many small qzCompress2 requests in flight (the reference's async test, test/main.c:5527-6374, keeps the ring
+    full): whatever is waiting goes to the GPU as one launch, and every request still gets exactly the member a call of
+    its own would have written - sizes 0 .. 3 chunks, two sessions sharing launches, a third with another format in
+    between, one destination too small, one request with the CRC out-field."""
+    import threading
+    import time
+    sa, sb = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536), A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    sr = A.Session(A.QZ_DEFLATE_RAW, 16384, comp_lvl=4)
+    L = sa.L
+    L.qzamd_async_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    l0, r0 = C.c_uint64(), C.c_uint64()
+    L.qzamd_async_stats(C.byref(l0), C.byref(r0))
+    kinds = ("silesia", "text", "rand", "runs", "records", "lzmix")
+    sizes = [65536, 1000, 0, 65537, 30000, 131072, 1, 200000, 65535, 4096]
+    jobs = []                                                   # (session, fmt, hw, lvl, src)
+    for i in range(240):
+        sess, fmt, hw, lvl = ((sa, "GZIP_EXT", 65536, 1), (sb, "GZIP_EXT", 65536, 1), (sr, "RAW", 16384, 4))[0 if i % 7 < 4 else 1 if i % 7 < 6 else 2]
+        n = sizes[i % len(sizes)]
+        if kinds[i % 6] == "lzmix":
+            n = min(n, 66000)
+        jobs.append((sess, fmt, hw, lvl, datagen.gen_bytes(kinds[i % 6], n, 300 + i)))
+    bufs_in = [C.create_string_buffer(j[4], max(1, len(j[4]))) for j in jobs]
+    bufs_out = [C.create_string_buffer(len(j[4]) * 9 // 8 + 4096) for j in jobs]
+    results = [A.QzResult() for _ in jobs]
+    small = 17                                                  # this one gets a destination that cannot hold its member
+    done, order = threading.Event(), []
+
+    def on_done(res):
+        order.append(res.contents.cb_tag)
+        if len(order) == len(jobs):
+            done.set()
+        return 0
+    cb = A.QzAsyncCallback(on_done)
+    t0 = time.time()
+    for i, j in enumerate(jobs):
+        results[i].cb_tag = i + 1; results[i].src_len = len(j[4]); results[i].dest_len = 64 if i == small else len(bufs_out[i])
+        assert L.qzCompress2(C.byref(j[0].s), bufs_in[i], bufs_out[i], cb, C.byref(results[i])) == A.QZ_OK
+    assert done.wait(300)
+    dt = time.time() - t0
+    assert order == list(range(1, len(jobs) + 1))                # still retired in submission order
+    for i, j in enumerate(jobs):
+        r = results[i]
+        if i == small:
+            assert r.status in (A.QZ_BUF_ERROR, A.QZ_FAIL) or r.dest_len <= 64
+            continue
+        exp = O.sw_compress(j[1], j[4], j[2], j[3], cap=len(j[4]) * 9 // 8 + 65536)[2]
+        assert r.status == A.QZ_OK and r.src_len == len(j[4]) and bufs_out[i].raw[:r.dest_len] == exp, (i, j[1], len(j[4]), r.status)
+    l1, r1 = C.c_uint64(), C.c_uint64()
+    L.qzamd_async_stats(C.byref(l1), C.byref(r1))
+    nl, nr = l1.value - l0.value, r1.value - r0.value
+    print("async: %d requests in %.3f s, %d coalesced launches carried %d of them" % (len(jobs), dt, nl, nr))
+    assert nr >= len(jobs) // 2 and nl < nr                      # most of them shared a launch
+    assert sa.s.total_in + sb.s.total_in + sr.s.total_in >= sum(len(j[4]) for k, j in enumerate(jobs) if k != small)
+    sa.close(); sb.close(); sr.close()
+
+
 def test_crc_known_answer_like_reference_test():
     # test/main.c:4283-4337: qzCompressCrc's crc == zlib crc32(src) for 64 KB and 1023 B
     s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
@@ -206,6 +263,34 @@ def test_multi_member_decompress_and_buf_error():
     s.close(); s2.close()
 
 
+def test_mixed_format_members_decode_in_one_call():
+    """test/main.c mode 5 (:892-1111): blocks compressed alternately as gzip-ext ("QZ") and plain gzip, concatenated,
+    then one decompress loop over the lot; plus the L9-software-stream case (:4339-4409) and members written by
+    another gzip implementation in between."""
+    import gzip
+    se, sg = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536), A.Session(A.QZ_DEFLATE_GZIP, 65536)
+    s9 = A.Session(A.QZ_DEFLATE_GZIP, 65536, comp_lvl=9)
+    parts, comp = [], b""
+    for i, (who, n) in enumerate((("QZ", 200000), ("GZIP", 70000), ("QZ", 65536), ("L9", 150000), ("PY", 90000), ("GZIP", 1), ("QZ", 300000))):
+        src = datagen.gen_bytes(("silesia", "text", "records")[i % 3], n, 60 + i)
+        parts.append(src)
+        if who == "PY":
+            comp += gzip.compress(src, 6)
+        else:
+            rc, used, out, _ = {"QZ": se, "GZIP": sg, "L9": s9}[who].compress(src, 1)
+            assert rc == A.QZ_OK and used == n
+            comp += out
+    want = b"".join(parts)
+    for s in (se, sg):                                   # either session kind reads the mix
+        got, pos = b"", 0
+        while pos < len(comp):                           # the caller's loop (utils/qzip.c:217-227)
+            rc, used, back = s.decompress(comp[pos:], len(want) + 16)
+            assert rc == A.QZ_OK and used > 0, (rc, pos)
+            got += back; pos += used
+        assert got == want
+    se.close(); sg.close(); s9.close()
+
+
 def test_corrupt_input_is_a_data_error():
     s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
     src = datagen.gen_bytes("text", 90000, 6)
@@ -239,6 +324,39 @@ def test_every_comp_lvl_matches_sw_path():
         rc, used, out, _ = s.compress(b"x" * 1000, 1)
         assert rc == A.QZ_NOT_SUPPORTED and used == 0 and out == b""
     s.close()
+
+
+def test_one_session_per_thread_runs_concurrently():
+    """The reference's threading contract (include/qatzip.h:122-148, test/main.c -t): the API is thread-safe with one
+    session per thread.  Four threads, each with its own session and format, compress and decompress at the same
+    time (ctypes drops the GIL inside the calls); every result is what the software path writes."""
+    import threading
+    jobs = [("GZIP_EXT", 65536, "silesia", 3_000_000), ("GZIP", 16384, "text", 1_500_000), ("RAW", 131072, "records", 2_000_000),
+            ("4B", 65536, "lzmix", 140_000)]
+    errs = []
+    O.sw_compress("RAW", b"warm the checker's static tables on this thread", 65536, 1)
+
+    def worker(fmt, hw, kind, n, seed):
+        try:
+            s = A.Session(FMT[fmt], hw)
+            assert s.rc_setup == A.QZ_OK
+            for it in range(3):
+                src = datagen.gen_bytes(kind, n - it * 1000, seed + it)
+                rc, used, out, crc = s.compress(src, 1, crc0=0)
+                assert rc == A.QZ_OK and used == len(src), (fmt, rc)
+                assert out == O.sw_compress(fmt, src, hw, 1, cap=len(src) * 9 // 8 + 65536)[2], (fmt, it)
+                rc, cused, back = s.decompress(out, len(src) + 16)
+                assert rc == A.QZ_OK and back == src and cused == len(out), (fmt, it, rc)
+            s.close()
+        except BaseException as e:      # noqa: BLE001 - reported on the main thread
+            errs.append((fmt, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(*j, 50 + i)) for i, j in enumerate(jobs)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    assert not errs, errs
 
 
 def test_stream_api_one_member_many_slices():

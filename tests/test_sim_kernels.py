@@ -136,6 +136,35 @@ def test_every_zlib_level_matches_oracle(sim, level):
             assert out.raw[:ol.value] == O.sw_compress("RAW", src, chunk, level, last=last, cap=cap)[2], (kind, n, chunk, level, last)
 
 
+@pytest.mark.parametrize("level", [1, 6])
+def test_coalesced_launch_of_small_requests(sim, level):
+    """Many small requests in one launch: every request starts on a chunk boundary, chunks carry their own length and
+    'closes the stream' flag.  Each request's bytes must be what a call of its own produces."""
+    chunk = 16384
+    reqs = [datagen.gen_bytes(k, n, 40 + i) for i, (k, n) in enumerate(
+        (("text", 16384), ("silesia", 5000), ("rand", 0), ("runs", 40000), ("text", 1), ("lzmix", 16385), ("records", 32768), ("allA", 3)))]
+    slots, cdesc = [], []
+    for r in reqs:
+        nch = max(1, (len(r) + chunk - 1) // chunk)
+        for k in range(nch):
+            piece = r[k * chunk:(k + 1) * chunk]
+            slots.append(piece + bytes([0xEE]) * (chunk - len(piece)))          # the padding is never part of the result
+            cdesc.append(len(piece) | (0x80000000 if k == nch - 1 else 0))
+    buf = b"".join(slots); nch = len(cdesc)
+    cd = np.array(cdesc, np.uint32); lens = np.zeros(nch, np.uint32); crcs = np.zeros(nch, np.uint32)
+    out = C.create_string_buffer(len(buf) * 9 // 8 + 4096 * nch)
+    sim.sim_deflate_ragged.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    total = sim.sim_deflate_ragged(buf, nch, chunk, cd.ctypes.data, level, out, lens.ctypes.data, crcs.ctypes.data)
+    pos = k = 0
+    for r in reqs:
+        n = max(1, (len(r) + chunk - 1) // chunk)
+        ln = int(lens[k:k + n].sum())
+        assert out.raw[pos:pos + ln] == O.sw_compress("RAW", r, chunk, level)[2], (len(r), level)
+        assert [int(c) for c in crcs[k:k + n]] == [zlib.crc32(r[j * chunk:(j + 1) * chunk]) & 0xffffffff for j in range(n)]
+        pos += ln; k += n
+    assert pos == total
+
+
 def test_adler_chunks_kernel(sim):
     """the DEFLATE_ZLIB trailer checksum: per-chunk Adler-32 on the emulator against zlib.adler32"""
     sim.sim_adler.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p]
