@@ -971,6 +971,63 @@ static bool compress_batch(const std::vector<AsyncReq> &run, const std::vector<S
     return true;
 }
 
+/* the other direction: a request whose source is exactly one gzip-ext member with its sizes in the header (what
+ * qzCompress writes for a last = 1 call, and what the hardware path writes per chunk) can share a launch too - one
+ * segment per request, all decoded at once */
+static Sess *batchable_d(const AsyncReq &q, uint32_t *pay, uint32_t *csz, uint32_t *usz)
+{
+    Sess *s = NULL;
+    if (q.compress || !q.sess || !q.res || ensure_ready(q.sess, &s) < 0 || !s) return NULL;
+    if (!(s->p.fmt == F_GZIP_EXT || s->p.fmt == F_GZIP) || q.res->src_len > AQ_BATCH_MAX_REQ) return NULL;
+    uint32_t es = 0, ed = 0;
+    const int hl = parse_header(F_GZIP_EXT, q.src, q.res->src_len, &es, &ed);
+    if (hl < 0 || es == 0 || ed == 0 || (uint64_t)hl + ed + 8 != q.res->src_len || es > q.res->dest_len || es > AQ_BATCH_MAX_REQ) return NULL;
+    *pay = (uint32_t)hl; *csz = ed; *usz = es;
+    return s;
+}
+
+static bool decompress_batch(const std::vector<AsyncReq> &run, const std::vector<Sess *> &ss)
+{
+    Sess *s0 = ss[0];
+    const uint32_t nm = (uint32_t)run.size();
+    std::vector<qzd_infseg> segs(nm);
+    std::vector<qzd_infres> res(nm);
+    std::vector<qzd_range> rg(nm);
+    std::vector<uint32_t> c32(nm), pay(nm);
+    uint64_t io = 0, oo = 0;
+    for (uint32_t i = 0; i < nm; i++) {
+        uint32_t csz = 0, usz = 0;
+        if (!batchable_d(run[i], &pay[i], &csz, &usz)) return false;
+        segs[i].in_off = io; segs[i].in_len = csz; segs[i].out_off = oo; segs[i].out_cap = usz; segs[i].flags = 0; segs[i].pad = csz;
+        rg[i].off = oo; rg[i].len = usz; rg[i].pad = 0;
+        io += (csz + 15u) & ~15u; oo += usz;
+    }
+    if (reserve(s0, io + 64, oo + 64) != QZ_OK) return false;
+    std::vector<unsigned char> stage(io + 64);
+    for (uint32_t i = 0; i < nm; i++) memcpy(stage.data() + segs[i].in_off, run[i].src + pay[i], segs[i].in_len);
+    if (qzd_h2d(s0->ctx, s0->d_in, stage.data(), io + 64) != QZD_OK) return false;
+    if (qzd_inflate_segments(s0->ctx, s0->d_in, s0->d_out, segs.data(), nm, res.data()) != QZD_OK) return false;
+    if (qzd_crc32_ranges(s0->ctx, s0->d_out, rg.data(), nm, c32.data()) != QZD_OK) return false;
+    stage.resize(oo);
+    if (oo && qzd_d2h(s0->ctx, stage.data(), s0->d_out, oo) != QZD_OK) return false;
+    for (uint32_t i = 0; i < nm; i++) {
+        QzResult_T *r = run[i].res;
+        const unsigned char *tr = run[i].src + pay[i] + segs[i].in_len;
+        const uint32_t usz = segs[i].out_cap;
+        if (res[i].status != 0 || res[i].out_len != usz || res[i].in_used != segs[i].in_len || rd32(tr) != c32[i] || rd32(tr + 4) != usz) {
+            run_sync2(run[i].sess, run[i].src, run[i].dest, r, false);      /* the one-call path reports what is wrong with it */
+            continue;
+        }
+        memcpy(run[i].dest, stage.data() + segs[i].out_off, usz);
+        unsigned long *crc = (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
+        if (crc) *crc = *crc == 0 ? c32[i] : qzd_crc32_combine((uint32_t)*crc, c32[i], usz);
+        r->dest_len = usz; r->ext_rc = 0; r->status = QZ_OK;        /* src_len: the whole member */
+        ss[i]->end_of_stream = 1;
+        run[i].sess->total_in += r->src_len; run[i].sess->total_out += usz; run[i].sess->thd_sess_stat = QZ_OK;
+    }
+    return true;
+}
+
 extern "C" void qzamd_async_stats(uint64_t *launches, uint64_t *requests)
 {
     pthread_mutex_lock(&g_aq_lock);
@@ -995,7 +1052,9 @@ static void *async_consumer(void *)
         run.push_back(g_aq[g_aq_head++]);
         g_aq_running.assign(1, run[0].sess);
         pthread_mutex_unlock(&g_aq_lock);
-        Sess *s0 = batchable(run[0]);
+        uint32_t a_ = 0, b_ = 0, c_ = 0;
+        const bool comp = run[0].compress;
+        Sess *s0 = comp ? batchable(run[0]) : batchable_d(run[0], &a_, &b_, &c_);
         if (s0) {
             ss.push_back(s0);
             uint64_t slots = run[0].res->src_len / s0->p.hw_buff_sz + 1;
@@ -1003,8 +1062,8 @@ static void *async_consumer(void *)
             while (g_aq_head < g_aq.size() && slots < AQ_BATCH_MAX_SLOTS) {
                 AsyncReq q = g_aq[g_aq_head];
                 pthread_mutex_unlock(&g_aq_lock);                /* ensure_ready may take the global lock */
-                Sess *s = batchable(q);
-                const bool ok = s && s->p.fmt == s0->p.fmt && s->p.comp_lvl == s0->p.comp_lvl && s->p.hw_buff_sz == s0->p.hw_buff_sz;
+                Sess *s = q.compress != comp ? NULL : comp ? batchable(q) : batchable_d(q, &a_, &b_, &c_);
+                const bool ok = s && (!comp || (s->p.fmt == s0->p.fmt && s->p.comp_lvl == s0->p.comp_lvl && s->p.hw_buff_sz == s0->p.hw_buff_sz));
                 pthread_mutex_lock(&g_aq_lock);
                 if (!ok) break;
                 run.push_back(q); ss.push_back(s); g_aq_head++;
@@ -1015,7 +1074,7 @@ static void *async_consumer(void *)
         }
         bool done = false;
         if (run.size() > 1) {
-            done = compress_batch(run, ss);
+            done = comp ? compress_batch(run, ss) : decompress_batch(run, ss);
             if (done) { pthread_mutex_lock(&g_aq_lock); g_aq_batches++; g_aq_batched_reqs += run.size(); pthread_mutex_unlock(&g_aq_lock); }
         }
         for (size_t i = 0; i < run.size(); i++) {

@@ -215,6 +215,35 @@ def test_async_queue_coalesces_small_requests():
     print("async: %d requests in %.3f s, %d coalesced launches carried %d of them" % (len(jobs), dt, nl, nr))
     assert nr >= len(jobs) // 2 and nl < nr                      # most of them shared a launch
     assert sa.s.total_in + sb.s.total_in + sr.s.total_in >= sum(len(j[4]) for k, j in enumerate(jobs) if k != small)
+    # and back: every gzip-ext member as its own qzDecompress2 request, all in flight; one of them damaged
+    back_jobs = [i for i, j in enumerate(jobs) if j[1] == "GZIP_EXT" and i != small]
+    cins = [C.create_string_buffer(bufs_out[i].raw[:results[i].dest_len], results[i].dest_len) for i in back_jobs]
+    bad = 5
+    raw = bytearray(cins[bad].raw); raw[len(raw) // 2] ^= 0x10
+    cins[bad] = C.create_string_buffer(bytes(raw), len(raw))
+    douts = [C.create_string_buffer(len(jobs[i][4]) + 32) for i in back_jobs]
+    dres = [A.QzResult() for _ in back_jobs]
+    done.clear(); order.clear()
+
+    def on_back(res):
+        order.append(res.contents.cb_tag)
+        if len(order) == len(back_jobs):
+            done.set()
+        return 0
+    cb2 = A.QzAsyncCallback(on_back)
+    for k, i in enumerate(back_jobs):
+        dres[k].cb_tag = k + 1; dres[k].src_len = len(cins[k]); dres[k].dest_len = len(douts[k])
+        assert L.qzDecompress2(C.byref(jobs[i][0].s), cins[k], douts[k], cb2, C.byref(dres[k])) == A.QZ_OK
+    assert done.wait(300) and order == list(range(1, len(back_jobs) + 1))
+    for k, i in enumerate(back_jobs):
+        if k == bad:
+            assert dres[k].status == A.QZ_DATA_ERROR
+        elif len(jobs[i][4]):
+            assert dres[k].status == A.QZ_OK and douts[k].raw[:dres[k].dest_len] == jobs[i][4] and dres[k].src_len == len(cins[k]), (k, i)
+    l2, r2 = C.c_uint64(), C.c_uint64()
+    L.qzamd_async_stats(C.byref(l2), C.byref(r2))
+    print("async back: %d requests, %d coalesced launches carried %d" % (len(back_jobs), l2.value - l1.value, r2.value - r1.value))
+    assert r2.value - r1.value >= len(back_jobs) // 2
     sa.close(); sb.close(); sr.close()
 
 
