@@ -155,14 +155,10 @@ QZ_DEV int qzk_decode_sym(qzk_bits *b, const uint16_t *root, int rootbits, const
     return -1;
 }
 
-QZ_KERNEL qzk_inflate_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
+QZ_DEV void qzk_inflate_segment(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t sidx,
+                                qzk_inf_lds *S)
 {
-    QZ_LDS qzk_inf_lds LDS[QZK_INF_WAVES];
     const int lane = qz_lane();
-    const uint32_t wv = qz_uniform((uint32_t)(threadIdx.x >> 6));
-    const uint32_t sidx = blockIdx.x * QZK_INF_WAVES + wv;
-    if (sidx >= nsegs) return;
-    qzk_inf_lds *S = &LDS[wv];
     /* segment record -> SGPRs */
     const qzk_infseg *sp = segs + sidx;
     const uint64_t in_off = (uint64_t)qz_uniform((uint32_t)sp->in_off) | (uint64_t)qz_uniform((uint32_t)(sp->in_off >> 32)) << 32;
@@ -271,7 +267,41 @@ QZ_KERNEL qzk_inflate_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg
 #define QZK_FLUSH_PENDING() do { if (pend) { if ((uint32_t)lane < plen) o[pdst + (uint32_t)lane] = pv; pend = false; } } while (0)
         while (bstat == 2) {
             qzk_refill(&b, lane);
-            int sym = qzk_decode_sym(&b, S->lroot, QZK_LROOT, S->lsorted, S->lrange, S->lindex, lmax);
+            /* Literal runs, several symbols per LDS round trip: lane l looks up the code that would start at bit l of
+             * the buffer; the real symbol boundaries are then a chain of lane hops from bit 0 (a cross-lane read each,
+             * no memory), and the lanes on the chain store their literal side by side.  The chain ends at the first
+             * symbol that is not a root-table literal; if that one is a length code or end-of-block with its bits
+             * present, its entry is already here too.  A segment of incompressible data is ~65 K literals and is what
+             * sets a call's pace: this is worth ~5 symbols a trip there. */
+            int sym = -2;
+            {
+                const uint32_t myent = S->lroot[(uint32_t)(b.bb >> lane) & ((1u << QZK_LROOT) - 1)];
+                uint64_t chain = 0; uint32_t nlit = 0; int bp = 0;
+                const int avail = b.bc < 63 ? b.bc : 63;                    /* one drop of all 64 bits would be a shift by 64 */
+                while (bp < avail) {
+                    const uint32_t ent = qz_readlane(myent, bp);
+                    const int l = (int)(ent & 15);
+                    if (ent == 0 || l > avail - bp) break;                  /* long code, or its bits are not here yet */
+                    if ((ent >> 4) >= 256) { sym = (int)(ent >> 4); bp += l; break; }     /* length code or end of block: its entry is here already */
+                    if (op + nlit >= out_cap) break;
+                    chain |= 1ull << bp; nlit++; bp += l;
+                }
+                if (nlit) {
+                    if (!count_only) {
+                        const bool mine = (chain >> lane) & 1;
+                        const uint32_t at = op + (uint32_t)qz_popc64(chain & qz_below(lane));
+                        QZK_FLUSH_PENDING();
+                        if (mine) o[at] = (uint8_t)(myent >> 4);
+                    }
+                    op += nlit;
+                }
+                if (bp) {
+                    QZK_DROP(&b, bp);
+                    if (sym == -2) continue;
+                    qzk_refill(&b, lane);               /* the length code's extra bits */
+                }
+            }
+            if (sym == -2) sym = qzk_decode_sym(&b, S->lroot, QZK_LROOT, S->lsorted, S->lrange, S->lindex, lmax);
             if (sym < 0) { bstat = b.pos >= b.end && b.bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA; break; }
             if (sym < 256) {
                 if (op >= out_cap) { bstat = QZK_INF_EOUT; break; }
@@ -330,6 +360,15 @@ QZ_KERNEL qzk_inflate_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg
         r.in_used = b.pos - (uint32_t)(b.bc >> 3);     /* whole unused bytes go back */
         res[sidx] = r;
     }
+}
+
+QZ_KERNEL qzk_inflate_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
+{
+    QZ_LDS qzk_inf_lds LDS[QZK_INF_WAVES];
+    const uint32_t wv = qz_uniform((uint32_t)(threadIdx.x >> 6));
+    const uint32_t sidx = blockIdx.x * QZK_INF_WAVES + wv;
+    if (sidx >= nsegs) return;
+    qzk_inflate_segment(comp, out, segs, res, sidx, &LDS[wv]);
 }
 
 #endif

@@ -165,6 +165,57 @@ def test_coalesced_launch_of_small_requests(sim, level):
     assert pos == total
 
 
+@pytest.mark.parametrize("variant", ["sim_inflate"])
+def test_wave_inflate_kernels(sim, variant):
+    """K3, one wave per segment (literal runs decoded by bit-offset speculation): flush-marker segments of our own streams, and whole foreign streams decoded straight through (level 9 text with 32 KiB distances, stored and
+    fixed blocks, sync-flush history), plus the count-only pass and the error codes."""
+    fn = getattr(sim, variant)
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    seg_dt = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
+    res_dt = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
+
+    def run(comp, segs, n):
+        cbuf = np.frombuffer(comp + b"\0" * 64, np.uint8).copy(); obuf = np.full(n + 64, 0xAA, np.uint8)
+        sa = np.array(segs, dtype=seg_dt); res = np.zeros(len(segs), res_dt)
+        fn(cbuf.ctypes.data, obuf.ctypes.data, sa.ctypes.data, res.ctypes.data, len(segs))
+        return bytes(obuf[:n]), res, bytes(obuf[n:n + 64])
+
+    # 1. our own chunked streams, one segment per chunk
+    for kind, n, chunk in (("text", 70000, 16384), ("silesia", 140000, 65536), ("rand", 40000, 16384), ("runs", 9000, 1024), ("allA", 70000, 65536)):
+        src = datagen.gen_bytes(kind, n, 9)
+        comp = O.sw_compress("RAW", src, chunk, 1)[2]
+        segs, off, oo = [], 0, 0
+        for k in range((n + chunk - 1) // chunk):
+            ln = min(chunk, n - oo)
+            plen = len(O.sw_compress("RAW", src[oo:oo + ln], chunk, 1, last=1 if oo + ln == n else 0)[2])
+            segs.append((off, oo, len(comp) - off, ln, 0, 0)); off += plen; oo += ln
+        got, res, tail = run(comp, segs, n)
+        assert got == src and (res["status"] >= 0).all() and tail == b"\xaa" * 64, (variant, kind)
+        cnt = [(a, b, c, d, 1, 0) for a, b, c, d, _, _ in segs]          # count only: sizes, nothing written
+        got2, res2, _ = run(comp, cnt, n)
+        assert got2 == b"\xaa" * n and [int(x) for x in res2["out_len"]] == [s_[3] for s_ in segs]
+    # 2. foreign streams straight through (flag 2): long distances, every block type, Z_SYNC_FLUSH in the middle
+    text = datagen.gen_bytes("text", 150000, 3)
+    co = zlib.compressobj(9, zlib.DEFLATED, -15)
+    a = co.compress(text[:90000]) + co.flush(zlib.Z_SYNC_FLUSH)
+    bpart = co.compress(text[90000:] + datagen.gen_bytes("rand", 70000, 4) + text[:40000]) + co.flush()
+    whole = text + datagen.gen_bytes("rand", 70000, 4) + text[:40000]
+    got, res, tail = run(a + bpart, [(0, 0, len(a + bpart), len(whole), 2, 0)], len(whole))
+    assert got == whole and res[0]["status"] == 0 and res[0]["in_used"] == len(a + bpart) and tail == b"\xaa" * 64
+    fixed = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+    fx = fixed.compress(text[:30000]) + fixed.flush()
+    got, res, _ = run(fx, [(0, 0, len(fx), 30000, 2, 0)], 30000)
+    assert got == text[:30000] and res[0]["status"] == 0
+    # 3. errors: output too small, truncated input, damaged data
+    got, res, tail = run(fx, [(0, 0, len(fx), 29000, 2, 0)], 29000)
+    assert res[0]["status"] == -2 and tail == b"\xaa" * 64
+    got, res, _ = run(fx[:len(fx) // 2], [(0, 0, len(fx) // 2, 30000, 2, 0)], 30000)
+    assert res[0]["status"] in (-3, -1)
+    bad = bytearray(a + bpart); bad[1000] ^= 0x40
+    got, res, _ = run(bytes(bad), [(0, 0, len(bad), len(whole), 2, 0)], len(whole))
+    assert res[0]["status"] < 0 or got != whole
+
+
 def test_adler_chunks_kernel(sim):
     """the DEFLATE_ZLIB trailer checksum: per-chunk Adler-32 on the emulator against zlib.adler32"""
     sim.sim_adler.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p]
