@@ -135,10 +135,14 @@ class Session:
         rc = self.L.qzCompressCrc(C.byref(self.s), src, C.byref(sl), dst, C.byref(dl), last, C.byref(crc))
         return rc, sl.value, dst.raw[:dl.value], crc.value
 
-    def decompress(self, comp: bytes, cap: int):
-        """-> (rc, consumed, out_bytes)"""
+    def decompress(self, comp: bytes, cap: int, crc0=0, want_crc=False):
+        """-> (rc, consumed, out_bytes[, crc]): qzDecompress, or qzDecompressCrc (running CRC-32 of the output) with want_crc"""
         sl, dl = C.c_uint(len(comp)), C.c_uint(cap)
         dst = C.create_string_buffer(max(cap, 1))
+        if want_crc:
+            crc = C.c_ulong(crc0)
+            rc = self.L.qzDecompressCrc(C.byref(self.s), comp, C.byref(sl), dst, C.byref(dl), C.byref(crc))
+            return rc, sl.value, dst.raw[:dl.value], crc.value
         rc = self.L.qzDecompress(C.byref(self.s), comp, C.byref(sl), dst, C.byref(dl))
         return rc, sl.value, dst.raw[:dl.value]
 

@@ -164,8 +164,8 @@ static int decompress_stream(QzSession_T *sess, FILE *in, FILE *out, unsigned lo
             *n_in += sl; *n_out += dl;
             memmove(src, src + sl, have - sl);
             have -= sl;
-            if (sl == 0 && eof) { fprintf(stderr, "%s: unexpected end of input\n", g.prog); rc = QZ_DATA_ERROR; break; }
-            if (sl == 0 && have == slab) { fprintf(stderr, "%s: a member larger than %u bytes of input is not supported\n", g.prog, slab); rc = QZ_FAIL; break; }
+            if (sl == 0 && dl == 0 && eof) { fprintf(stderr, "%s: unexpected end of input\n", g.prog); rc = QZ_DATA_ERROR; break; }
+            if (sl == 0 && dl == 0 && have == slab) { fprintf(stderr, "%s: a member larger than %u bytes of input is not supported\n", g.prog, slab); rc = QZ_FAIL; break; }
             rc = QZ_OK;
             continue;
         }

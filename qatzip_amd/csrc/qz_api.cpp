@@ -48,6 +48,9 @@ struct Sess {
     bool open; uint32_t run_sum; uint64_t st_in, st_out;
     unsigned char end_of_stream;
     std::vector<uint32_t> lens, crcs, adlers;
+    /* a member whose output did not fit the caller's destination: decoded once into d_hold, handed out over as many
+     * calls as it takes (decompress_deflate) */
+    uint8_t *d_hold; uint64_t hold_len, hold_pos;
 };
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER, g_mem_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -233,6 +236,7 @@ static int make_session(QzSession_T *sess, const Params &p)
     Sess *s = new (std::nothrow) Sess();
     if (!s) { sess->hw_session_stat = QZ_NOSW_LOW_MEM; return QZ_NOSW_LOW_MEM; }
     s->p = p; s->ctx = NULL; s->d_in = s->d_out = NULL; s->in_cap = s->out_cap = 0;
+    s->d_hold = NULL; s->hold_len = s->hold_pos = 0;
     s->open = false; s->run_sum = 0; s->st_in = s->st_out = 0; s->end_of_stream = 0;
     sess->internal = s;
     sess->hw_session_stat = g_inited ? QZ_OK : QZ_NONE;
@@ -293,6 +297,7 @@ extern "C" int qzTeardownSession(QzSession_T *sess)
         if (s->ctx) {
             if (s->d_in) qzd_dev_free(s->ctx, s->d_in);
             if (s->d_out) qzd_dev_free(s->ctx, s->d_out);
+            if (s->d_hold) qzd_dev_free(s->ctx, s->d_hold);
             qzd_destroy(s->ctx);
         }
         delete s;
@@ -661,6 +666,24 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
 {
     const int fmt = s->p.fmt;
     const uint32_t n = *src_len, cap = *dest_len;
+    if (s->d_hold) {
+        /* the rest of a member that was larger than the destination (below): the next piece; the member's last input
+         * byte was held back for exactly this, and goes with the last piece */
+        const uint32_t k = (uint32_t)std::min<uint64_t>(cap, s->hold_len - s->hold_pos);
+        if (k == 0 && s->hold_pos < s->hold_len) { *src_len = 0; *dest_len = 0; return QZ_BUF_ERROR; }
+        if (k && qzd_d2h(s->ctx, dest, s->d_hold + s->hold_pos, k) != QZD_OK) return QZ_FAIL;
+        if (crc && k) {
+            uint32_t c = 0;
+            if (qzd_crc32(s->ctx, s->d_hold + s->hold_pos, k, &c) != QZD_OK) return QZ_FAIL;
+            *crc = qzd_crc32_combine((uint32_t)*crc, c, k);
+        }
+        s->hold_pos += k;
+        const bool last_piece = s->hold_pos == s->hold_len;
+        if (last_piece) { qzd_dev_free(s->ctx, s->d_hold); s->d_hold = NULL; s->hold_len = s->hold_pos = 0; s->end_of_stream = 1; }
+        *src_len = last_piece ? 1 : 0; *dest_len = k;
+        sess->total_in += *src_len; sess->total_out += k;
+        return QZ_OK;
+    }
     int rc = reserve(s, n, cap);
     if (rc) return rc;
     if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
@@ -676,8 +699,28 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
         int hl = parse_header(fmt, src + ti, n - ti, &es, &ed);
         if (hl < 0) { ret = hl; break; }
         uint64_t iu = 0, ol = 0; uint32_t c32 = 0;
-        int r = qzd_inflate_stream(s->ctx, s->d_in + ti + hl, n - ti - hl, s->d_out + to, cap - to, s->p.hw_buff_sz, &iu, &ol,
+        uint8_t *obuf = s->d_out + to;
+        int r = qzd_inflate_stream(s->ctx, s->d_in + ti + hl, n - ti - hl, obuf, cap - to, s->p.hw_buff_sz, &iu, &ol,
                                    (fmt == F_GZIP || fmt == F_GZIP_EXT || crc) ? &c32 : NULL);
+        bool held = false;
+        if (r == QZD_ERR_DSTCAP && to == 0) {
+            /* Not even the first member fits.  The software path would hand out what fits and keep its inflate state
+             * (src/qatzip_sw.c:342-351, SURVEY 8b "decompress into 1 KB dest"); a segment-parallel decoder has no
+             * such state to keep, so the member is decoded whole into a buffer of its own - size unknown, so grown
+             * until it fits - and handed out piece by piece, this call and the following ones. */
+            uint64_t hcap = std::max<uint64_t>(std::max<uint64_t>(2ull * cap, 8ull * (n - ti - hl)), 1u << 20);
+            for (;;) {
+                hcap = std::min<uint64_t>(hcap, 0xffffffffull);
+                s->d_hold = (uint8_t *)qzd_dev_alloc(s->ctx, hcap + 4096);
+                if (!s->d_hold) { r = QZD_ERR_DSTCAP; break; }
+                r = qzd_inflate_stream(s->ctx, s->d_in + ti + hl, n - ti - hl, s->d_hold, hcap, s->p.hw_buff_sz, &iu, &ol,
+                                       (fmt == F_GZIP || fmt == F_GZIP_EXT) ? &c32 : NULL);
+                if (r == QZD_OK) { held = true; obuf = s->d_hold; break; }
+                qzd_dev_free(s->ctx, s->d_hold); s->d_hold = NULL;
+                if (r != QZD_ERR_DSTCAP || hcap >= 0xffffffffull) break;
+                hcap *= 4;
+            }
+        }
         if (r == QZD_ERR_DSTCAP) { ret = QZ_BUF_ERROR; break; }
         if (r != QZD_OK) { ret = QZ_DATA_ERROR; break; }
         uint32_t pos = ti + (uint32_t)hl + (uint32_t)iu;
@@ -687,18 +730,33 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
         } else if (fmt == F_ZLIB) {
             const uint32_t R = 256 * 1024, nr = ol ? (uint32_t)((ol + R - 1) / R) : 1;
             std::vector<uint32_t> ad(nr);
-            if (pos + 4 > n || qzd_adler32_chunks(s->ctx, s->d_out + to, ol, R, ad.data()) != QZD_OK) { ret = QZ_DATA_ERROR; break; }
+            if (pos + 4 > n || qzd_adler32_chunks(s->ctx, obuf, ol, R, ad.data()) != QZD_OK) { ret = QZ_DATA_ERROR; break; }
             uint32_t a = 1;
             for (uint32_t k = 0; k < nr; k++) a = qzd_adler32_combine(a, ad[k], std::min<uint64_t>(R, ol - (uint64_t)k * R));
             const uint32_t want = (uint32_t)src[pos] << 24 | (uint32_t)src[pos + 1] << 16 | (uint32_t)src[pos + 2] << 8 | src[pos + 3];
             if (a != want) { ret = QZ_DATA_ERROR; break; }
             pos += 4;
         }
+        if (held) {
+            /* first piece now; everything but the member's last byte counts as consumed, so the caller keeps calling */
+            const uint32_t k = (uint32_t)std::min<uint64_t>(cap, ol);
+            if (k && qzd_d2h(s->ctx, dest, s->d_hold, k) != QZD_OK) { ret = QZ_FAIL; break; }
+            if (crc && k) {
+                uint32_t c = 0;
+                if (qzd_crc32(s->ctx, s->d_hold, k, &c) != QZD_OK) { ret = QZ_FAIL; break; }
+                *crc = *crc == 0 ? c : qzd_crc32_combine((uint32_t)*crc, c, k);
+            }
+            s->hold_len = ol; s->hold_pos = k;
+            *src_len = pos - 1; *dest_len = k;
+            sess->total_in += pos - 1; sess->total_out += k;
+            return QZ_OK;
+        }
         if (crc) *crc = (to == 0 && *crc == 0) ? c32 : qzd_crc32_combine((uint32_t)*crc, c32, ol);
         ti = pos; to += (uint32_t)ol;
         s->end_of_stream = 1;
         if (s->p.stop_at_stream_end) break;
     }
+    if (ret != QZ_OK && s->d_hold) { qzd_dev_free(s->ctx, s->d_hold); s->d_hold = NULL; s->hold_len = s->hold_pos = 0; }
     /* a later member that is cut short or damaged does not undo the complete ones before it: partial consumption,
      * QZ_OK, and the next call (which starts at that member) reports the error - the member-granular version of what
      * the software path's kept inflate state does ("first half of the stream => QZ_OK, partial output") */

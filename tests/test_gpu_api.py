@@ -320,6 +320,38 @@ def test_mixed_format_members_decode_in_one_call():
     se.close(); sg.close(); s9.close()
 
 
+def test_member_larger_than_the_destination_comes_out_in_pieces():
+    """SURVEY 8b "decompress into 1 KB dest": the software path hands out what fits, returns QZ_OK and resumes on the
+    next call.  Same contract here for a destination smaller than the member: the caller's loop (advance by consumed,
+    collect produced) gets every byte, the running CRC is right, and the stream after the member decodes normally."""
+    import gzip
+    src = datagen.gen_bytes("silesia", 300_000, 71)
+    tail_src = datagen.gen_bytes("text", 50_000, 72)
+    for fmt, cap in (("GZIP_EXT", 1000), ("GZIP", 70_000), ("RAW", 4096)):
+        s = A.Session(FMT[fmt], 65536)
+        comp = s.compress(src, 1)[2] + s.compress(tail_src, 1)[2]
+        got, pos, crc, calls = b"", 0, 0, 0
+        while pos < len(comp):
+            rc, used, back, crc = s.decompress(comp[pos:], cap if len(got) < len(src) else 60_000, crc0=crc, want_crc=True)
+            assert rc == A.QZ_OK and (used or back), (fmt, rc, pos)
+            got += back; pos += used; calls += 1
+            assert calls < 1000
+        assert got == src + tail_src and pos == len(comp) and calls > 4, (fmt, calls)
+        assert crc == zlib.crc32(src + tail_src) & 0xffffffff, fmt
+        s.close()
+    # a member written by another gzip, far larger than the destination
+    big = datagen.gen_bytes("records", 2_000_000, 73)
+    comp = gzip.compress(big, 6)
+    s = A.Session(A.QZ_DEFLATE_GZIP, 65536)
+    got, pos = b"", 0
+    while pos < len(comp):
+        rc, used, back = s.decompress(comp[pos:], 65536)
+        assert rc == A.QZ_OK and (used or back)
+        got += back; pos += used
+    assert got == big
+    s.close()
+
+
 def test_corrupt_input_is_a_data_error():
     s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
     src = datagen.gen_bytes("text", 90000, 6)
