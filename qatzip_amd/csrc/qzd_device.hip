@@ -276,7 +276,13 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     HIPCHK(c, hipEventRecord(c->ev_begin, st));
     HIPCHK(c, hipMemsetAsync(head, 0, headb, st));
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
-    hipLaunchKernelGGL(qzk_lz77_lane_kernel, dim3((nchunks + 63) / 64), dim3(64), 0, st, d_src, n, chunk_sz, nchunks,
+    /* chunks per wave: a lane's loop is a chain of dependent HBM round trips and a wave steps at the pace of its
+     * slowest lane, so the fewer lanes share a wave the better - measured 1 GiB, level 6: 64 lanes 0.23 GB/s, 16: 0.33,
+     * 4: 0.53, 1: 0.69 (level 2: 2.07 -> 4.29).  One chunk per wave it is (QATZIP_AMD_LANE_LPW overrides); the idle
+     * lanes are where a parallel candidate compare would go. */
+    uint32_t lpw = 1;
+    if (const char *e = getenv("QATZIP_AMD_LANE_LPW")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v <= 64 && !(v & (v - 1))) lpw = v; }
+    hipLaunchKernelGGL(qzk_lz77_lane_kernel, dim3((nchunks + lpw - 1) / lpw), dim3(lpw), 0, st, d_src, n, chunk_sz, nchunks,
                        sym_lc, sym_dist, meta, head, prev, qzk_level_cfg(level), cdesc);
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
     hipLaunchKernelGGL(qzk_huff_kernel, dim3(nchunks), dim3(QZK_HW), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist,

@@ -10,7 +10,8 @@ src = np.tile(src, mb // 64).tobytes()
 c = qatzip_amd.Context(0)
 d_src = c.alloc(len(src)); d_src.upload(src)
 d_dst = c.alloc(qatzip_amd.max_deflate_len(len(src), 65536))
-for lvl in (1, 2, 3, 4, 6, 9):
+import os
+for lvl in [int(x) for x in os.environ.get('LEVELS', '1,2,3,4,6,9').split(',')]:
     best = 1e9
     for rep in range(2):
         t = time.time(); n, _ = c.deflate_raw(d_src, len(src), 65536, lvl, 1, d_dst); best = min(best, time.time() - t)
