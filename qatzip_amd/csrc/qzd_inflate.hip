@@ -34,7 +34,7 @@
 /* the two-phase path needs ~28 + 5 ms per 64 KB segment per lane whatever the segment count (phase A is bound by
  * a lone wave's instruction latency), the wave kernel does ~300 segments/ms (bound by the CUs' scalar units): the
  * two phases win from ~8 000 segments on (measured) */
-#define QZD_LANE_MIN_SEGS 8000u
+#define QZD_LANE_MIN_SEGS 10500u
 #define QZD_LANE_SEGS_PER_WAVE 16u
 /* sub-decoders per segment of phase A.  1 = the serial phase A.  The speculative one (2, 4, 8; QATZIP_AMD_INFLATE_K)
  * decodes compressible segments K times faster, but blocks of near-equal code lengths (incompressible data that still
