@@ -65,6 +65,12 @@ void qzd_host_free_pinned(void *p);
 int qzd_deflate_raw(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
                     uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_chunk_crc);
 
+/* qzd_deflate_raw for input that is still in host memory (what qzCompress is handed): h_src travels to d_stage (n bytes
+ * of device memory the caller provides) one batch at a time, each copy issued behind the previous batch's kernels, so
+ * PCIe time hides under the parse instead of preceding it */
+int qzd_deflate_raw_from_host(qzd_ctx *ctx, const uint8_t *h_src, uint8_t *d_stage, uint64_t n, uint32_t chunk_sz, int level,
+                              int last, uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_chunk_crc);
+
 /*
  * Many small requests in ONE launch — what the reference's asynchronous API is for (qzCompress2's ring + consumer
  * thread, src/qatzip.c:3103-4110, keeps many requests in flight on the accelerator).  d_src holds nslots slots of

@@ -407,10 +407,9 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
     const uint64_t worst = (uint64_t)n + (uint64_t)nchunks * (5ull * (hw / 32767 + 2) + 16) + 64;
     int rc = reserve(s, n, worst);
     if (rc) return rc;
-    if (n && qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
     uint64_t produced = 0;
     s->crcs.resize(nchunks); s->lens.resize(nchunks);
-    if (qzd_deflate_raw(s->ctx, s->d_in, n, hw, (int)s->p.comp_lvl, (int)last, s->d_out, s->out_cap, &produced, s->crcs.data()) != QZD_OK) {
+    if (qzd_deflate_raw_from_host(s->ctx, src, s->d_in, n, hw, (int)s->p.comp_lvl, (int)last, s->d_out, s->out_cap, &produced, s->crcs.data()) != QZD_OK) {
         logmsg(LOG_ERROR, "GPU deflate failed: %s\n", qzd_last_error(s->ctx));
         return QZ_FAIL;
     }

@@ -125,6 +125,8 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         for (int k = 0; k < 4; k++) hipEventCreate(&c->ev[i][k]);
     }
     hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
+    if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess) return QZD_ERR_HIP;
+    for (int i = 0; i < QZD_NBUF + 1; i++) hipEventCreateWithFlags(&c->cp_ev[i], hipEventDisableTiming);
     for (int i = 0; i < QZD_K1EV; i++) { hipEventCreate(&c->k1ev[i][0]); hipEventCreate(&c->k1ev[i][1]); }
     {
         /* K1 residency (measured): QZD_K1_WGS_PER_CU persistent single-wave workgroups per CU, each with
@@ -155,6 +157,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     for (int i = 0; i < QZD_NBUF; i++) {
         hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
         hipStreamDestroy(c->st[i]); hipEventDestroy(c->done[i]); hipEventDestroy(c->k1done[i]);
+        if (i == 0) { hipStreamDestroy(c->st_copy); for (int k = 0; k < QZD_NBUF + 1; k++) hipEventDestroy(c->cp_ev[k]); }
         for (int k = 0; k < 4; k++) hipEventDestroy(c->ev[i][k]);
     }
     hipEventDestroy(c->ev_begin); hipEventDestroy(c->ev_end);
@@ -302,7 +305,7 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
 
 /* cdesc (device memory, or NULL): per-chunk length / closes-its-stream flag of a coalesced launch (qzk_chunk_len) */
 static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
-                           int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc)
+                           int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc, const uint8_t *h_src = NULL)
 {
     if (!c || !d_dst || (n && !d_src)) return QZD_ERR_PARAM;
     if (chunk_sz < 1024 || chunk_sz > 512 * 1024 || (chunk_sz & (chunk_sz - 1))) return QZD_ERR_PARAM;
@@ -314,6 +317,7 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
         /* level 1: one chunk per wave (K1, window speculation over the four-newest table); levels 2-9: zlib's own loop
          * and tables, one chunk per LANE (K1b).  QATZIP_AMD_DEFLATE=lane takes level 1 through K1b as well. */
         const char *force = getenv("QATZIP_AMD_DEFLATE");
+        if ((level != 1 || (force && force[0] == 'l')) && h_src && n) HIPCHK(c, hipMemcpy((void *)d_src, h_src, n, hipMemcpyHostToDevice));
         if (level != 1 || (force && force[0] == 'l')) return deflate_lane_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
     }
     int rc = ensure_scratch(c, chunk_sz, nchunks);
@@ -330,14 +334,32 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
     HIPCHK(c, hipEventRecord(c->done[0], c->st[0]));
     HIPCHK(c, hipStreamWaitEvent(c->st[1], c->done[0], 0));
 
-    for (uint32_t b = 0, k = 0; b < nchunks; b += BATCH, k++) {
+    /* with the input still on the host the first batch is one round of the persistent workgroups instead of three:
+     * nothing can overlap its copy, so it is kept short */
+    const uint32_t FIRST = h_src && nchunks > BATCH ? std::max<uint32_t>(c->k1_wgs, 1024u) : BATCH;
+    if (FIRST != BATCH) c->nbatches = 1 + (nchunks - FIRST + BATCH - 1) / BATCH;
+    for (uint32_t b = 0, k = 0, bnext = 0; b < nchunks; b = bnext, k++) {
         const int s = (int)(k % QZD_NBUF), so = (int)((k + 1) % QZD_NBUF);
-        const uint32_t bn = nchunks - b < BATCH ? nchunks - b : BATCH;
+        const uint32_t bsz = k == 0 ? std::min(FIRST, BATCH) : BATCH;
+        const uint32_t bn = nchunks - b < bsz ? nchunks - b : bsz;
+        bnext = b + bn;
         const uint64_t boff = (uint64_t)b * chunk_sz;
         const uint64_t blen = n - boff;      /* bytes from this batch's first chunk to the end of the call */
         const uint32_t final_chunk = (last && b + bn == nchunks) ? bn - 1 : ~0u;
         hipStream_t st = c->st[s];
         const bool timed = k < QZD_NBUF;     /* events of the first use of each buffer set */
+        /* input still in host memory: batch k's bytes were sent while batch k-1 was enqueued (below); its kernels wait
+         * for them, and batch k+1's copy goes out behind this batch's launches - asynchronous from pinned memory, and
+         * from pageable memory the host blocks in it while the GPU works on batch k */
+        auto send = [&](uint32_t kk, uint32_t bb) -> hipError_t {
+            const uint64_t o = (uint64_t)bb * chunk_sz, len = std::min<uint64_t>((uint64_t)(kk == 0 ? bsz : BATCH) * chunk_sz, n - o);
+            hipError_t e = hipMemcpyAsync((void *)(d_src + o), h_src + o, len, hipMemcpyHostToDevice, c->st_copy);
+            return e != hipSuccess ? e : hipEventRecord(c->cp_ev[kk % (QZD_NBUF + 1)], c->st_copy);
+        };
+        if (h_src && n) {
+            if (k == 0) HIPCHK(c, send(0, 0));
+            HIPCHK(c, hipStreamWaitEvent(st, c->cp_ev[k % (QZD_NBUF + 1)], 0));
+        }
         /* the K1 workgroups of consecutive batches share the per-workgroup tables, so K1 of batch k starts when K1 of
          * batch k-1 is done; what overlaps with it is K2/scan/gather of batch k-1 */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->k1done[so], 0));
@@ -363,6 +385,7 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
                            c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][3], st));
         HIPCHK(c, hipEventRecord(c->done[s], st));
+        if (h_src && bnext < nchunks) HIPCHK(c, send(k + 1, bnext));
     }
     /* join: stream 0 waits for stream 1, then publishes the totals */
     HIPCHK(c, hipStreamWaitEvent(c->st[0], c->done[1], 0));
@@ -378,6 +401,20 @@ extern "C" int qzd_deflate_raw_async(qzd_ctx *c, const uint8_t *d_src, uint64_t 
                                      int last, uint8_t *d_dst, uint64_t dst_cap)
 {
     return deflate_enqueue(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, NULL);
+}
+
+/* the same call with the input still in host memory: h_src is copied to d_stage (n bytes of device memory) batch by
+ * batch, each copy behind the previous batch's launches */
+extern "C" int qzd_deflate_raw_from_host(qzd_ctx *c, const uint8_t *h_src, uint8_t *d_stage, uint64_t n, uint32_t chunk_sz,
+                                         int level, int last, uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len,
+                                         uint32_t *h_chunk_crc)
+{
+    if (!c || (n && (!h_src || !d_stage))) return QZD_ERR_PARAM;
+    int rc = deflate_enqueue(c, d_stage, n, chunk_sz, level, last, d_dst, dst_cap, NULL, h_src);
+    if (rc) return rc;
+    rc = qzd_sync(c);
+    if (rc) return rc;
+    return qzd_result(c, h_out_len, h_chunk_crc, c->last_nchunks);
 }
 
 /* Many small requests in one launch (the submission queue of qzCompress2, qz_api.cpp): d_src holds nslots slots of
@@ -414,6 +451,7 @@ extern "C" int qzd_sync(qzd_ctx *c)
     hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->st[0]));
     HIPCHK(c, hipStreamSynchronize(c->st[1]));
+    HIPCHK(c, hipStreamSynchronize(c->st_copy));
     for (uint32_t k = 0; k < c->k1ev_n; k++) {      /* harvest the K1 launch timings of the call that just finished */
         float t = 0;
         if (hipEventElapsedTime(&t, c->k1ev[k][0], c->k1ev[k][1]) == hipSuccess) {

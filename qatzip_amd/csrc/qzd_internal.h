@@ -17,6 +17,7 @@
 struct qzd_ctx {
     int device;
     hipStream_t st[QZD_NBUF];
+    hipStream_t st_copy; hipEvent_t cp_ev[QZD_NBUF + 1];   /* host input arrives batch by batch while the previous batch is parsed */
     hipEvent_t done[QZD_NBUF], k1done[QZD_NBUF];
     /* scratch per buffer set */
     uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];

@@ -60,12 +60,16 @@ static int perf(unsigned mb, unsigned block, unsigned loops)
 {
     QzSession_T sess;
     size_t total = (size_t)mb << 20, off, nblk = (total + block - 1) / block, i;
-    unsigned char *src = qzMalloc(total, 0, PINNED_MEM), *comp, *back;
+    const char *pe = getenv("BT_PINNED");       /* unset: source pinned, the rest pageable; 1: everything pinned; 0: nothing */
+    unsigned char *src = (pe && !atoi(pe)) ? NULL : qzMalloc(total, 0, PINNED_MEM), *comp, *back;
     unsigned *csz = malloc(nblk * sizeof(unsigned)), cap = qzMaxCompressedLength(block, NULL) + 64, l;
     double t0, tc = 0, td = 0;
     memset(&sess, 0, sizeof(sess));
     if (!src) src = qzMalloc(total, 0, COMMON_MEM);
-    comp = qzMalloc((size_t)cap * nblk, 0, COMMON_MEM); back = qzMalloc(total, 0, COMMON_MEM);
+    {
+        const int pin = pe && atoi(pe);
+        comp = qzMalloc((size_t)cap * nblk, 0, pin ? PINNED_MEM : COMMON_MEM); back = qzMalloc(total, 0, pin ? PINNED_MEM : COMMON_MEM);
+    }
     if (!src || !comp || !back || !csz) return 2;
     srand(1);
     for (off = 0; off < total;) {               /* genRandomData-style runs, test/main.c:293-310 */
