@@ -128,6 +128,13 @@ int qzd_inflate_segments(qzd_ctx *ctx, const uint8_t *d_comp, uint8_t *d_out, co
 int qzd_inflate_stream(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
                        uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc);
 
+/* qzd_inflate_stream for a caller that wants the output in host memory (what qzDecompress is asked for): when the
+ * stream decodes in the first, optimistic pass of a large call, the output is sent to h_dst range by range behind the
+ * kernels that produce it, and *h_sent = 1; otherwise *h_sent = 0 and the output is (only) in d_dst */
+int qzd_inflate_stream_to_host(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                               uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc,
+                               uint8_t *h_dst, int *h_sent);
+
 /* Adler-32 (zlib adler32(), what the DEFLATE_ZLIB trailer carries: deflateInit2 with windowBits 15,
  * src/qatzip_sw.c:147) of every chunk_sz chunk of HBM-resident data; fold with qzd_adler32_combine */
 int qzd_adler32_chunks(qzd_ctx *ctx, const uint8_t *d_data, uint64_t n, uint32_t chunk_sz, uint32_t *h_adler);

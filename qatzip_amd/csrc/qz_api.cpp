@@ -687,6 +687,7 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
     if (rc) return rc;
     if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
     uint32_t ti = 0, to = 0; int ret = QZ_OK;
+    bool all_sent = true; uint64_t sent_bytes = 0;                  /* output the device layer has already put into dest */
     s->end_of_stream = 0;
     if (fmt == F_GZIP_EXT && !s->p.stop_at_stream_end) {
         const int done = decompress_sized_members(s, src, n, cap, &ti, &to, crc);
@@ -699,8 +700,10 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
         if (hl < 0) { ret = hl; break; }
         uint64_t iu = 0, ol = 0; uint32_t c32 = 0;
         uint8_t *obuf = s->d_out + to;
-        int r = qzd_inflate_stream(s->ctx, s->d_in + ti + hl, n - ti - hl, obuf, cap - to, s->p.hw_buff_sz, &iu, &ol,
-                                   (fmt == F_GZIP || fmt == F_GZIP_EXT || crc) ? &c32 : NULL);
+        int sent = 0;                                               /* large members reach dest while they are still being decoded */
+        int r = qzd_inflate_stream_to_host(s->ctx, s->d_in + ti + hl, n - ti - hl, obuf, cap - to, s->p.hw_buff_sz, &iu, &ol,
+                                           (fmt == F_GZIP || fmt == F_GZIP_EXT || crc) ? &c32 : NULL, dest + to, &sent);
+        if (sent) sent_bytes += ol; else all_sent = false;
         bool held = false;
         if (r == QZD_ERR_DSTCAP && to == 0) {
             /* Not even the first member fits.  The software path would hand out what fits and keep its inflate state
@@ -761,7 +764,7 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
      * the software path's kept inflate state does ("first half of the stream => QZ_OK, partial output") */
     if (ret == QZ_DATA_ERROR && ti > 0) ret = QZ_OK;
     if (ret != QZ_OK && !(ret == QZ_BUF_ERROR && to > 0)) { *src_len = 0; *dest_len = 0; return ret; }
-    if (to && qzd_d2h(s->ctx, dest, s->d_out, to) != QZD_OK) return QZ_FAIL;
+    if (to && !(all_sent && sent_bytes == to) && qzd_d2h(s->ctx, dest, s->d_out, to) != QZD_OK) return QZ_FAIL;
     *src_len = ti; *dest_len = to;
     sess->total_in += ti; sess->total_out += to;
     return ret;

@@ -41,6 +41,7 @@
  * got Huffman-coded) never let a misaligned decoder fall into step, so those segments come back to the serial kernel
  * and set the pace: on the bench data 13 % of the segments do, and the serial phase A alone is faster */
 #define QZD_SPEC_LANES 1u
+#define QZD_SO_PARTS 4u             /* output ranges a streamed decode is resolved and sent in */
 
 /* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF */
 __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list, uint32_t cap, uint32_t *count)
@@ -81,7 +82,10 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     const size_t chb = ((size_t)nsegs * sizeof(qzk_chain) + 255) & ~(size_t)255;
     const size_t rcb = K == 1 ? 0 : (((size_t)nsegs * K * QZK_SPEC_NREC * sizeof(qzk_rec) + 255) & ~(size_t)255);
     const size_t litb = (lit_total + 511) & ~(uint64_t)255, seqb = seq_total * sizeof(qzk_seq);
-    const size_t need = tabb + tsb + chb + rcb + litb + seqb + 256;
+    /* output streaming: only the plain decode of a whole member (every segment writes, known output offsets) */
+    const bool stream_out = c->so_host && c->so_nat && K == 1 && nsegs >= QZD_LANE_MIN_SEGS;
+    const size_t ordb = stream_out ? (((size_t)nsegs * 4 + 255) & ~(size_t)255) : 0;
+    const size_t need = tabb + tsb + chb + rcb + litb + seqb + ordb + 256;
     if (need > c->big_cap) {
         hipDeviceSynchronize();
         if (c->d_big) hipFree(c->d_big);
@@ -95,7 +99,9 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     qzk_chain *ch_d = (qzk_chain *)pb; pb += chb;
     qzk_rec *rec_d = (qzk_rec *)pb; pb += rcb;
     uint8_t *lit_d = pb; pb += litb;
-    qzk_seq *seq_d = (qzk_seq *)pb;
+    qzk_seq *seq_d = (qzk_seq *)pb; pb += (seqb + 255) & ~(size_t)255;
+    uint32_t *ord_d = (uint32_t *)pb;
+    if (stream_out) HIPCHK(c, hipMemcpyAsync(ord_d, c->so_nat, (size_t)nsegs * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d_segs, hs, sb, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(ts_d, tsv.data(), tsv.size() * sizeof(qzk_tokseg), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[1][1], st));
@@ -119,9 +125,33 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
 #undef QZD_SPEC_LAUNCH
     }
     HIPCHK(c, hipEventRecord(c->ev[1][0], st));
-    hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
-                       d_comp, d_out, d_segs, d_res, nsegs, ts_d, K, lit_d, seq_d, ch_d);
-    HIPCHK(c, hipEventRecord(c->ev[1][2], st));
+    if (!stream_out) {
+        hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
+                           d_comp, d_out, d_segs, d_res, nsegs, ts_d, K, lit_d, seq_d, ch_d, (const uint32_t *)NULL, 0u);
+        HIPCHK(c, hipEventRecord(c->ev[1][2], st));
+    } else {
+        /* phase B over QZD_SO_PARTS ranges of the output, in output order; each range leaves for the host on the copy
+         * stream as soon as its launch is done, while the next range is being resolved.  (Whether the ranges are what
+         * the caller wanted is decided afterwards, from the results; a decode that turns out wrong is simply copied
+         * again as a whole.) */
+        uint64_t off[QZD_SO_PARTS + 1];
+        for (uint32_t p = 0; p < QZD_SO_PARTS; p++) {
+            const uint32_t first = (uint32_t)((uint64_t)nsegs * p / QZD_SO_PARTS), end = (uint32_t)((uint64_t)nsegs * (p + 1) / QZD_SO_PARTS);
+            off[p] = hs[c->so_nat[first]].out_off;
+            const qzk_infseg &lastseg = hs[c->so_nat[end - 1]];
+            off[p + 1] = lastseg.out_off + lastseg.out_cap;
+            hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((end - first + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
+                               d_comp, d_out, d_segs, d_res, nsegs, ts_d, K, lit_d, seq_d, ch_d, (const uint32_t *)(ord_d + first), end - first);
+            HIPCHK(c, hipEventRecord(c->so_ev[p], st));
+        }
+        HIPCHK(c, hipEventRecord(c->ev[1][2], st));
+        for (uint32_t p = 0; p < QZD_SO_PARTS; p++) {       /* a pageable destination makes these block the host: all launches are out already */
+            HIPCHK(c, hipStreamWaitEvent(c->st[1], c->so_ev[p], 0));
+            HIPCHK(c, hipMemcpyAsync(c->so_host + off[p], d_out + off[p], off[p + 1] - off[p], hipMemcpyDeviceToHost, c->st[1]));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->st[1]));
+        c->so_sent = off[QZD_SO_PARTS];
+    }
     HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
@@ -302,7 +332,10 @@ static int inflate_grouped(qzd_ctx *c, const uint8_t *d_src, uint8_t *d_dst, std
     std::vector<qzk_infseg> ps(ns);
     std::vector<qzk_infres> pr(ns);
     for (uint32_t i = 0; i < ns; i++) ps[i] = segs[order[i]];
+    std::vector<uint32_t> nat;                              /* segs[] is in output order: where each one went */
+    if (c->so_host) { nat.resize(ns); for (uint32_t i = 0; i < ns; i++) nat[order[i]] = i; c->so_nat = nat.data(); }
     int rc = qzd_inflate_segments(c, d_src, d_dst, ps.data(), ns, pr.data());
+    c->so_nat = NULL;
     if (rc) return rc;
     for (uint32_t i = 0; i < ns; i++) res[order[i]] = pr[i];
     return QZD_OK;
@@ -316,9 +349,30 @@ static int map_status(int st)
     }
 }
 
+static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                          uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc, uint8_t *h_dst, int *h_sent);
+
 extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
                                   uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc)
 {
+    return inflate_stream(c, d_src, n, d_dst, dst_cap, seg_hint, h_in_used, h_out_len, h_crc, NULL, NULL);
+}
+
+/* the same, for a caller that wants the output in host memory (qzDecompress): when the stream decodes in the first,
+ * optimistic pass, its output is sent to h_dst range by range behind the kernels and *h_sent is set; otherwise
+ * *h_sent = 0 and the caller copies d_dst out itself */
+extern "C" int qzd_inflate_stream_to_host(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                                          uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc,
+                                          uint8_t *h_dst, int *h_sent)
+{
+    if (!h_dst || !h_sent) return QZD_ERR_PARAM;
+    return inflate_stream(c, d_src, n, d_dst, dst_cap, seg_hint, h_in_used, h_out_len, h_crc, h_dst, h_sent);
+}
+
+static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                          uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc, uint8_t *h_dst, int *h_sent)
+{
+    if (h_sent) *h_sent = 0;
     if (!c || !d_src || !h_in_used || !h_out_len) return QZD_ERR_PARAM;
     if (n == 0 || n > 0xffffffffull) return QZD_ERR_PARAM;
     hipSetDevice(c->device);
@@ -358,7 +412,9 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
             segs[k].pad = (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k];     /* compressed-length hint for phase A */
         }
         lap("segment records");
+        c->so_host = h_dst; c->so_sent = 0;
         rc = inflate_grouped(c, d_src, d_dst, segs, res, start, n);
+        c->so_host = NULL;
         if (rc) return rc;
         lap("inflate (optimistic)");
         bool ok = true; uint32_t k = 0;
@@ -370,6 +426,7 @@ extern "C" int qzd_inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, 
             if (k + 1 >= ns || start[k + 1] != start[k] + r.in_used) { ok = false; break; }
         }
         done = ok;
+        if (ok && h_sent && c->so_sent >= total_out) *h_sent = 1;       /* every range that holds output went out */
     }
 
     /* --- 3. two passes over the candidates --- */

@@ -520,10 +520,14 @@ QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
 #define QZK_COOP_LEN 32            /* matches at least this long are copied by the whole wave */
 QZ_KERNEL_OCC(64 * QZK_RES_WAVES, 6) qzk_lz_resolve_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                 const qzk_tokseg *ts, uint32_t ts_stride, const uint8_t *lits, const qzk_seq *seqs,
-                                const qzk_chain *chains)
+                                const qzk_chain *chains, const uint32_t *order /* or NULL */, uint32_t count)
 {
+    /* `order`: the launch covers `count` segments picked by index (a range of the OUTPUT, so that it can leave for the
+     * host while the next range is resolved); NULL: all nsegs in array order */
     const int lane = qz_lane();
-    const uint32_t sidx = blockIdx.x * QZK_RES_WAVES + (threadIdx.x >> 6);
+    const uint32_t widx = blockIdx.x * QZK_RES_WAVES + (threadIdx.x >> 6);
+    if (widx >= (order ? count : nsegs)) return;
+    const uint32_t sidx = order ? order[widx] : widx;
     if (sidx >= nsegs) return;
     const qzk_infseg sg = segs[sidx];
     if (res[sidx].status < 0 || (sg.flags & QZK_INF_COUNT_ONLY)) return;

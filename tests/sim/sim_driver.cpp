@@ -191,9 +191,18 @@ static void two_phase_serial(const uint8_t *comp, uint8_t *out, const qzk_infseg
     sim::launch((nsegs + 15) / 16, 64, 0, [&] {
         if (threadIdx.x < 16) qzk_inflate_tok_kernel<16>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data());
     });
-    sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
-        qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), 1u, lits.data(), seqs.data(), chains.data());
-    });
+    /* phase B the way the host streams output: launches over index lists (here: the segments in reverse, two parts) */
+    std::vector<uint32_t> ord(nsegs);
+    for (uint32_t i = 0; i < nsegs; i++) ord[i] = nsegs - 1 - i;
+    const uint32_t half = nsegs / 2;
+    for (int part = 0; part < 2; part++) {
+        const uint32_t first = part ? half : 0, cnt = part ? nsegs - half : half;
+        if (!cnt) continue;
+        sim::launch((cnt + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
+            qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), 1u, lits.data(), seqs.data(), chains.data(),
+                                  ord.data() + first, cnt);
+        });
+    }
 }
 
 int sim_inflate_lane(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs)
@@ -226,7 +235,7 @@ static int two_phase_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *s
         qzk_inflate_spec_kernel<K>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data(), recs.data());
     });
     sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
-        qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), (uint32_t)K, lits.data(), seqs.data(), chains.data());
+        qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), (uint32_t)K, lits.data(), seqs.data(), chains.data(), nullptr, 0);
     });
     if (getenv("QZSIM_TRACE"))
         for (uint32_t i = 0; i < nsegs; i++) {

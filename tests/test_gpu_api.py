@@ -473,3 +473,10 @@ def test_plain_c_caller_links_and_round_trips(tmp_path):
     r = subprocess.run([exe, "perf", "64", "65536", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "Gbps" in r.stdout, r.stdout + r.stderr
     print(r.stdout)
+    # two 1 GiB calls each way: the sizes at which input and output travel in pieces beside the kernels (batched
+    # host-to-device copies under K1, output ranges sent behind phase B); the harness compares every byte
+    for pin in ("0", "1"):
+        r = subprocess.run([exe, "perf", "2048", str(1 << 30), "1"], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, BT_PINNED=pin))
+        assert r.returncode == 0 and "Gbps" in r.stdout, r.stdout + r.stderr
+        print(r.stdout)
