@@ -141,8 +141,11 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         unsigned a = 0;
         if (e && sscanf(e, "%u", &a) == 1 && a > 0 && a <= 65536) c->k1_wgs = a;
         c->batch_chunks = QZD_BATCH_ROUNDS * c->k1_wgs;
-        if (hipMalloc(&c->k1_tables, (size_t)c->k1_wgs * QZK_HSIZE * 8) != hipSuccess ||
-            hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) return QZD_ERR_HIP;
+        /* the tables (512 KiB per workgroup, 2 GiB for a full device) are allocated by the first call that needs them and
+         * only as many as its chunks can occupy: a session that decompresses, or only ever sees small calls, holds none
+         * or few */
+        c->k1_tables = NULL; c->k1_tab_wgs = 0;
+        if (hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) return QZD_ERR_HIP;
     }
     if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) return QZD_ERR_HIP;
     hipHostMalloc((void **)&c->h_running, 8, hipHostMallocDefault);
@@ -324,6 +327,17 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
     }
     int rc = ensure_scratch(c, chunk_sz, nchunks);
     if (rc) return rc;
+    {
+        const uint32_t want = nchunks < c->k1_wgs ? nchunks : c->k1_wgs;
+        if (want > c->k1_tab_wgs) {
+            hipDeviceSynchronize();
+            if (c->k1_tables) hipFree(c->k1_tables);
+            c->k1_tables = NULL; c->k1_tab_wgs = 0;
+            const uint32_t get = want > c->k1_wgs / 4 ? c->k1_wgs : want;     /* a big call: take the whole set at once */
+            HIPCHK(c, hipMalloc(&c->k1_tables, (size_t)get * QZK_HSIZE * 8));
+            c->k1_tab_wgs = get;
+        }
+    }
     const uint32_t stride = slot_stride_for(chunk_sz);
     c->last_nchunks = nchunks;
     const uint32_t BATCH = c->batch_chunks;

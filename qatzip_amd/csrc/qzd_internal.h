@@ -24,6 +24,7 @@ struct qzd_ctx {
     qzk_lzmeta *meta[QZD_NBUF];
     /* K1 (persistent pull kernel): one 512 KiB candidate table per resident workgroup, one chunk counter per buffer set */
     uint64_t *k1_tables; uint32_t *k1_counter;
+    uint32_t k1_tab_wgs;                            /* workgroups k1_tables has room for (grown on demand up to k1_wgs) */
     uint32_t k1_wgs;
     uint32_t batch_chunks;
     /* K1 launch durations (HIP events around every K1 launch, harvested at qzd_sync): bench.py's roofline input */
