@@ -10,6 +10,9 @@
  *   gather of the slots into the contiguous destination
  * Scratch (symbols, slots) is double-buffered and batches alternate between the streams: K1 of batch b+1 (which
  * needs K1 of batch b to be done - they share the tables) overlaps K2/crc/scan/gather of batch b.
+ * Variants of the same pipeline: input still on the host (copied in batch by batch on a third stream,
+ * qzd_deflate_raw_from_host), many small requests in one launch (per-slot lengths, qzd_deflate_slots), and
+ * comp_lvl 2-9 (K1b qzk_lz77_lane_kernel in place of K1, one batch).
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>

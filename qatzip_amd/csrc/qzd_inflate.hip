@@ -31,9 +31,9 @@
 #include "qzk_inflate_spec.h"
 #include "qzk_checksum.h"
 
-/* the two-phase path needs ~28 + 5 ms per 64 KB segment per lane whatever the segment count (phase A is bound by
- * a lone wave's instruction latency), the wave kernel does ~300 segments/ms (bound by the CUs' scalar units): the
- * two phases win from ~8 000 segments on (measured) */
+/* the two-phase path needs ~24 + 12 ms whatever the segment count (phase A is bound by a lone wave's instruction
+ * latency), the wave kernel ~12-17 ms per round of up to 6144 resident segments (bound by the CUs' scalar units): the
+ * two phases win from ~10 500 segments on (measured: 640 MiB 31.9 ms against 32.6) */
 #define QZD_LANE_MIN_SEGS 10500u
 #define QZD_LANE_SEGS_PER_WAVE 16u
 /* sub-decoders per segment of phase A.  1 = the serial phase A.  The speculative one (2, 4, 8; QATZIP_AMD_INFLATE_K)
