@@ -311,6 +311,9 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     return QZD_OK;
 }
 
+static int deflate_lazy_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
+                             uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks, const uint32_t *cdesc);
+
 /* cdesc (device memory, or NULL): per-chunk length / closes-its-stream flag of a coalesced launch (qzk_chunk_len) */
 static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
                            int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc, const uint8_t *h_src = NULL)
@@ -326,6 +329,9 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
          * and tables, one chunk per LANE (K1b).  QATZIP_AMD_DEFLATE=lane takes level 1 through K1b as well. */
         const char *force = getenv("QATZIP_AMD_DEFLATE");
         if ((level != 1 || (force && force[0] == 'l')) && h_src && n) HIPCHK(c, hipMemcpy((void *)d_src, h_src, n, hipMemcpyHostToDevice));
+        /* the lazy levels have their own, parallel, path; QATZIP_AMD_LAZY=0 sends them through K1b instead */
+        const char *lz = getenv("QATZIP_AMD_LAZY");
+        if (level >= 4 && !(lz && lz[0] == '0')) return deflate_lazy_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
         if (level != 1 || (force && force[0] == 'l')) return deflate_lane_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
     }
     int rc = ensure_scratch(c, chunk_sz, nchunks);
@@ -412,6 +418,80 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
     HIPCHK(c, hipMemcpyAsync(c->h_running, c->d_running, 8, hipMemcpyDeviceToHost, c->st[0]));
     HIPCHK(c, hipMemcpyAsync(c->h_overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, c->st[0]));
     HIPCHK(c, hipEventRecord(c->ev_end, c->st[0]));
+    HIPCHK(c, hipGetLastError());
+    return QZD_OK;
+}
+
+#include "qzk_deflate_lazy.h"
+#define QZD_LAZY_BATCH 16384u       /* chunks per round of the lazy path: 18 bytes of scratch per input byte */
+
+/* comp_lvl 4-9: chains (L1), one wave per chunk searching 64 positions at a time (L2), serial parse over the stored
+ * answers (L3), then K2 / CRC / scan / gather as everywhere else.  Rounds of QZD_LAZY_BATCH chunks on one stream. */
+static int deflate_lazy_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
+                             uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks, const uint32_t *cdesc)
+{
+    const uint32_t stride = slot_stride_for(chunk_sz);
+    const uint32_t B = nchunks < QZD_LAZY_BATCH ? nchunks : QZD_LAZY_BATCH;
+    const size_t span = (size_t)B * chunk_sz;
+    const size_t symb = (span + 511) & ~(size_t)255;
+    const size_t metab = ((size_t)B * sizeof(qzk_lzmeta) + 255) & ~(size_t)255;
+    const size_t slotb = ((size_t)B * stride + 255) & ~(size_t)255;
+    const size_t headb = (size_t)B * QZK_HSIZE * 4, pdb = 2 * symb, resb = 8 * symb;
+    const size_t need = symb * 3 + metab + slotb + headb + pdb + resb;
+    if (need > c->lane_cap) {
+        hipDeviceSynchronize();
+        if (c->d_lane) hipFree(c->d_lane);
+        c->d_lane = NULL; c->lane_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_lane, need));
+        c->lane_cap = need;
+    }
+    if (nchunks > c->call_cap) {
+        hipDeviceSynchronize();
+        hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs);
+        c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL; c->call_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_len, (size_t)nchunks * 4));
+        HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nchunks * 4));
+        HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nchunks * 8));
+        c->call_cap = nchunks;
+    }
+    uint8_t *pb = c->d_lane;
+    uint8_t *sym_lc = pb; pb += symb;
+    uint16_t *sym_dist = (uint16_t *)pb; pb += 2 * symb;
+    qzk_lzmeta *meta = (qzk_lzmeta *)pb; pb += metab;
+    uint8_t *slots = pb; pb += slotb;
+    uint32_t *head = (uint32_t *)pb; pb += headb;
+    uint16_t *pd = (uint16_t *)pb; pb += pdb;
+    qzk_lazyres *res = (qzk_lazyres *)pb;
+    hipStream_t st = c->st[0];
+    const qzk_lvlcfg cfg = qzk_level_cfg(level);
+    c->last_nchunks = nchunks; c->nbatches = 1;
+    HIPCHK(c, hipMemsetAsync(c->d_running, 0, 8, st));
+    HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, st));
+    HIPCHK(c, hipEventRecord(c->ev_begin, st));
+    HIPCHK(c, hipEventRecord(c->ev[0][0], st));
+    for (uint32_t b = 0; b < nchunks; b += B) {
+        const uint32_t bn = nchunks - b < B ? nchunks - b : B;
+        const uint64_t boff = (uint64_t)b * chunk_sz, blen = n - boff;
+        const uint32_t *cd = cdesc ? cdesc + b : NULL;
+        const uint32_t final_chunk = (last && b + bn == nchunks) ? bn - 1 : ~0u;
+        HIPCHK(c, hipMemsetAsync(head, 0, (size_t)bn * QZK_HSIZE * 4, st));
+        hipLaunchKernelGGL(qzk_lazy_chain_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn, cd, head, pd);
+        hipLaunchKernelGGL(qzk_lazy_search_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn, cd, pd, res, cfg);
+        hipLaunchKernelGGL(qzk_lazy_parse_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn, cd, res,
+                           sym_lc, sym_dist, meta, cfg);
+        hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HW), 0, st, d_src + boff, blen, chunk_sz, bn, sym_lc, sym_dist,
+                           meta, slots, stride, final_chunk, c->d_len + b, cd);
+        hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn, c->d_crc + b, cd);
+        hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);
+        hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, slots, stride, c->d_len + b, c->d_offs + b, bn,
+                           d_dst, dst_cap, c->d_overflow);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[0][1], st));
+    HIPCHK(c, hipEventRecord(c->ev[0][2], st));
+    HIPCHK(c, hipEventRecord(c->ev[0][3], st));
+    HIPCHK(c, hipMemcpyAsync(c->h_running, c->d_running, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev_end, st));
     HIPCHK(c, hipGetLastError());
     return QZD_OK;
 }

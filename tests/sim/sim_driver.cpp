@@ -13,6 +13,7 @@
 #include "../../qatzip_amd/csrc/qzk_inflate_lane.h"
 #include "../../qatzip_amd/csrc/qzk_inflate_spec.h"
 #include "../../qatzip_amd/csrc/qzk_checksum.h"
+#include "../../qatzip_amd/csrc/qzk_deflate_lazy.h"
 #include "../../qatzip_amd/csrc/qzk_lz4.h"
 #include <vector>
 
@@ -147,6 +148,41 @@ int sim_deflate_ragged(const uint8_t *src, uint32_t nchunks, uint32_t chunk_sz, 
         crcs[c] = ocrc[c];
     }
     return (int)pos;
+}
+
+/* comp_lvl 4-9 through the three lazy kernels (chains, parallel searches, serial parse) + K2 */
+int sim_deflate_lazy(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, int level, uint8_t *out, uint64_t *out_len,
+                     uint32_t *crcs)
+{
+    uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
+    const size_t span = (size_t)nchunks * chunk_sz;
+    std::vector<uint8_t> lc(span + 64);
+    std::vector<uint16_t> dist(span + 64), pd(span + 64, 0x7777);
+    std::vector<qzk_lazyres> res(span + 64);
+    std::vector<qzk_lzmeta> meta(nchunks);
+    uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
+    std::vector<uint8_t> slots((size_t)nchunks * stride);
+    std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
+    std::vector<uint32_t> head((size_t)nchunks * QZK_HSIZE, 0);
+    const qzk_lvlcfg cfg = qzk_level_cfg(level);
+    sim::launch(nchunks, 64, 0, [&] { qzk_lazy_chain_kernel(src, n, chunk_sz, nchunks, nullptr, head.data(), pd.data()); });
+    sim::launch(nchunks, 64, 0, [&] { qzk_lazy_search_kernel(src, n, chunk_sz, nchunks, nullptr, pd.data(), res.data(), cfg); });
+    sim::launch(nchunks, 64, 0, [&] {
+        qzk_lazy_parse_kernel(src, n, chunk_sz, nchunks, nullptr, res.data(), lc.data(), dist.data(), meta.data(), cfg);
+    });
+    sim::launch(nchunks, QZK_HW, 0, [&] {
+        qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
+                        last ? nchunks - 1 : ~0u, olen.data(), nullptr);
+    });
+    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data(), nullptr); });
+    uint64_t pos = 0;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);
+        pos += olen[c];
+        if (crcs) crcs[c] = ocrc[c];
+    }
+    *out_len = pos;
+    return (int)nchunks;
 }
 
 unsigned sim_meta_size(void) { return (unsigned)sizeof(qzk_lzmeta); }

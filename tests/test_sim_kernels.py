@@ -136,6 +136,28 @@ def test_every_zlib_level_matches_oracle(sim, level):
             assert out.raw[:ol.value] == O.sw_compress("RAW", src, chunk, level, last=last, cap=cap)[2], (kind, n, chunk, level, last)
 
 
+@pytest.mark.parametrize("level", [4, 5, 6, 7, 8, 9])
+def test_lazy_levels_by_parallel_search_match_oracle(sim, level):
+    """comp_lvl 4-9 through the three lazy kernels: chains built once, every position's search done by its own lane
+    (full and quarter chain), then the serial lazy parse over the stored answers - the same bytes as zlib's
+    deflate_slow, including the window slides of chunks above 64 KB and streams that stay open (last = 0)."""
+    sim.sim_deflate_lazy.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    # (the emulator meets at every hop of the search, so sizes are kept small; the GPU tests run the large ones)
+    cases = [("text", 20000, 16384), ("silesia", 30000, 65536), ("rand", 5000, 1024), ("lzmix", 12000, 65536),
+             ("allA", 70000, 65536), ("text", 0, 65536), ("text", 2, 1024), ("text", 3, 1024),
+             ("runs", 65536 + 300, 131072), ("records", 98304 + 7, 131072)]
+    if level in (5, 7, 8):
+        cases = cases[:2] + cases[-1:]
+    for kind, n, chunk in cases:
+        src = datagen.gen_bytes(kind, n, 30 + level)
+        nch = max(1, (n + chunk - 1) // chunk)
+        cap = n * 9 // 8 + 4096 * (nch + 1)
+        for last in (1, 0):
+            out = C.create_string_buffer(cap); ol = C.c_uint64(0); crcs = np.zeros(nch, np.uint32)
+            sim.sim_deflate_lazy(src, n, chunk, last, level, out, C.byref(ol), crcs.ctypes.data)
+            assert out.raw[:ol.value] == O.sw_compress("RAW", src, chunk, level, last=last, cap=cap)[2], (kind, n, chunk, level, last)
+
+
 @pytest.mark.parametrize("level", [1, 6])
 def test_coalesced_launch_of_small_requests(sim, level):
     """Many small requests in one launch: every request starts on a chunk boundary, chunks carry their own length and
