@@ -423,7 +423,7 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
 }
 
 #include "qzk_deflate_lazy.h"
-#define QZD_LAZY_BATCH 16384u       /* chunks per round of the lazy path: 18 bytes of scratch per input byte */
+#define QZD_LAZY_BATCH 16384u       /* chunks per round of the lazy path: 32 bytes of scratch per input byte */
 
 /* comp_lvl 4-9: chains (L1), one wave per chunk searching 64 positions at a time (L2), serial parse over the stored
  * answers (L3), then K2 / CRC / scan / gather as everywhere else.  Rounds of QZD_LAZY_BATCH chunks on one stream. */
@@ -436,7 +436,7 @@ static int deflate_lazy_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     const size_t symb = (span + 511) & ~(size_t)255;
     const size_t metab = ((size_t)B * sizeof(qzk_lzmeta) + 255) & ~(size_t)255;
     const size_t slotb = ((size_t)B * stride + 255) & ~(size_t)255;
-    const size_t headb = (size_t)B * QZK_HSIZE * 4, pdb = 2 * symb, resb = 8 * symb;
+    const size_t headb = (size_t)B * QZK_HSIZE * 4, pdb = 16 * symb, resb = 8 * symb;
     const size_t need = symb * 3 + metab + slotb + headb + pdb + resb;
     if (need > c->lane_cap) {
         hipDeviceSynchronize();
@@ -460,7 +460,7 @@ static int deflate_lazy_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     qzk_lzmeta *meta = (qzk_lzmeta *)pb; pb += metab;
     uint8_t *slots = pb; pb += slotb;
     uint32_t *head = (uint32_t *)pb; pb += headb;
-    uint16_t *pd = (uint16_t *)pb; pb += pdb;
+    qzk_lazyrec *pd = (qzk_lazyrec *)pb; pb += pdb;
     qzk_lazyres *res = (qzk_lazyres *)pb;
     hipStream_t st = c->st[0];
     const qzk_lvlcfg cfg = qzk_level_cfg(level);

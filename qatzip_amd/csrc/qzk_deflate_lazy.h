@@ -28,6 +28,23 @@
 
 typedef struct { uint32_t f, q; } qzk_lazyres;     /* len << 16 | dist for the full / quarter chain; 0 = nothing of 3 or more */
 
+/* what a hop of the search needs from a candidate, in ONE 16-byte access: the link to the next candidate (distance to
+ * the previous position with the same hash, 0 = none) and the candidate's first 14 bytes - most candidates differ
+ * from the string searched for within those, and then no second (scattered) access is needed for the compare */
+#define QZK_REC_BYTES 14
+typedef struct __attribute__((aligned(16))) { uint32_t w[4]; } qzk_lazyrec;    /* w[0] = pd | b0 << 16 | b1 << 24, then b2.. */
+QZ_DEV uint32_t qzk_rec_pd(const qzk_lazyrec &r) { return r.w[0] & 0xffff; }
+/* common prefix of the two records' byte strings, 0..14 */
+QZ_DEV int qzk_rec_common(const qzk_lazyrec &a, const qzk_lazyrec &b)
+{
+    uint32_t x = (a.w[0] ^ b.w[0]) >> 16;
+    if (x) return qz_ctz32(x) >> 3;
+    x = a.w[1] ^ b.w[1]; if (x) return 2 + (qz_ctz32(x) >> 3);
+    x = a.w[2] ^ b.w[2]; if (x) return 6 + (qz_ctz32(x) >> 3);
+    x = a.w[3] ^ b.w[3]; if (x) return 10 + (qz_ctz32(x) >> 3);
+    return QZK_REC_BYTES;
+}
+
 /* zlib's window bookkeeping as of a loop top at chunk offset p: origin of the window and how far it is filled */
 QZ_DEV void qzk_lazy_state(uint32_t p, uint32_t n, uint32_t *base_out, uint32_t *fill_out)
 {
@@ -50,7 +67,7 @@ QZ_DEV void qzk_lazy_state(uint32_t p, uint32_t n, uint32_t *base_out, uint32_t 
  * grouped hash by hash (one ballot per distinct hash of the trip).
  * head_all: 65536 words per chunk, zeroed by the host, holds position + 1.  pd_all: chunk_sz entries per chunk. */
 QZ_KERNEL_MAX(64) qzk_lazy_chain_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
-                                        const uint32_t *cdesc, uint32_t *head_all, uint16_t *pd_all)
+                                        const uint32_t *cdesc, uint32_t *head_all, qzk_lazyrec *rec_all)
 {
     const uint32_t chunk = blockIdx.x;
     if (chunk >= nchunks) return;
@@ -59,7 +76,7 @@ QZ_KERNEL_MAX(64) qzk_lazy_chain_kernel(const uint8_t *src, uint64_t src_len, ui
     const uint32_t n = qzk_chunk_len(cdesc, chunk, src_len, chunk_sz);
     const uint8_t *in = src + coff;
     uint32_t *head = head_all + (uint64_t)chunk * QZK_HSIZE;
-    uint16_t *pd = pd_all + coff;
+    qzk_lazyrec *rec = rec_all + coff;
     for (uint32_t P0 = 0; P0 + 3 <= n; P0 += 64) {
         const uint32_t p = P0 + (uint32_t)lane;
         const bool valid = p + 3 <= n;
@@ -81,7 +98,15 @@ QZ_KERNEL_MAX(64) qzk_lazy_chain_kernel(const uint8_t *src, uint64_t src_len, ui
         qz_wave_sync();                                 /* the previous trip's table stores are visible */
         uint32_t q1 = 0;                                /* predecessor's position + 1, 0 = none */
         if (valid) q1 = near >= 0 ? P0 + (uint32_t)near + 1 : head[h];
-        if (valid) pd[p] = (uint16_t)((q1 != 0 && p + 1 - q1 <= 32767u) ? p + 1 - q1 : 0);
+        if (valid) {
+            uint64_t lo = 0, hi = 0;                    /* bytes p .. p+13 (zero past the end of the chunk: lengths are clamped anyway) */
+            if (p + 16 <= n) { lo = ((const qzk_u64u *)(in + p))->v; hi = ((const qzk_u64u *)(in + p + 8))->v; }
+            else for (uint32_t k = 0; k < QZK_REC_BYTES && p + k < n; k++) { if (k < 8) lo |= (uint64_t)in[p + k] << (8 * k); else hi |= (uint64_t)in[p + k] << (8 * (k - 8)); }
+            qzk_lazyrec r;
+            r.w[0] = ((q1 != 0 && p + 1 - q1 <= 32767u) ? p + 1 - q1 : 0) | ((uint32_t)lo << 16);
+            r.w[1] = (uint32_t)(lo >> 16); r.w[2] = (uint32_t)(lo >> 48) | ((uint32_t)hi << 16); r.w[3] = (uint32_t)(hi >> 16);
+            rec[p] = r;
+        }
         qz_wave_sync();                                 /* every lane has read the table before any lane writes it */
         if (valid && !later) head[h] = p + 1;
     }
@@ -105,7 +130,7 @@ QZ_DEV int qzk_lazy_matchlen(const uint8_t *in, uint32_t a, uint32_t b, int maxl
  * over 64, not the sum of every 64 positions' longest chain.  The link to the next candidate is loaded before the
  * compare that decides whether it is needed: one memory round trip per hop instead of two. */
 QZ_KERNEL_MAX(64) qzk_lazy_search_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
-                                         const uint32_t *cdesc, const uint16_t *pd_all, qzk_lazyres *res_all, qzk_lvlcfg cfg)
+                                         const uint32_t *cdesc, const qzk_lazyrec *rec_all, qzk_lazyres *res_all, qzk_lvlcfg cfg)
 {
     const uint32_t chunk = blockIdx.x;
     if (chunk >= nchunks) return;
@@ -113,12 +138,13 @@ QZ_KERNEL_MAX(64) qzk_lazy_search_kernel(const uint8_t *src, uint64_t src_len, u
     const uint64_t coff = (uint64_t)chunk * chunk_sz;
     const uint32_t n = qzk_chunk_len(cdesc, chunk, src_len, chunk_sz);
     const uint8_t *in = src + coff;
-    const uint16_t *pd = pd_all + coff;
+    const qzk_lazyrec *rec = rec_all + coff;
     qzk_lazyres *res = res_all + coff;
     const int quarter = cfg.chain >> 2;
     uint32_t next = 0;                                  /* first position nobody has taken yet (wave-uniform) */
     bool active = false;
     uint32_t p = 0, cur = 0, lim = 0, bd = 0, rq = 0;
+    qzk_lazyrec own; own.w[0] = own.w[1] = own.w[2] = own.w[3] = 0;
     int maxlen = 0, nice = 0, best = 2, hops = 0;
     bool snapped = false;
     for (;;) {
@@ -130,7 +156,8 @@ QZ_KERNEL_MAX(64) qzk_lazy_search_kernel(const uint8_t *src, uint64_t src_len, u
                 uint32_t base, fill;
                 qzk_lazy_state(p, n, &base, &fill);
                 const uint32_t la = fill - p;
-                const uint32_t d0 = la >= 3 ? pd[p] : 0;
+                if (la >= 3) own = rec[p];
+                const uint32_t d0 = la >= 3 ? qzk_rec_pd(own) : 0;
                 if (d0 != 0 && d0 <= (uint32_t)QZK_MAXDIST && p - d0 > base) {       /* hash_head != NIL, within MAX_DIST */
                     maxlen = la < 258 ? (int)la : 258; nice = la < (uint32_t)cfg.nice ? (int)la : cfg.nice;
                     lim = p > (uint32_t)QZK_MAXDIST + base ? p - QZK_MAXDIST : base;  /* chained candidates: strictly above */
@@ -145,8 +172,12 @@ QZ_KERNEL_MAX(64) qzk_lazy_search_kernel(const uint8_t *src, uint64_t src_len, u
         }
         if (qz_ballot(active) == 0) { if (next >= n) break; continue; }
         if (active) {
-            const uint32_t d = pd[cur];                 /* in flight during the compare */
-            const int len = qzk_lazy_matchlen(in, p, cur, maxlen);
+            const qzk_lazyrec c = rec[cur];            /* link and first bytes of the candidate in one access */
+            const uint32_t d = qzk_rec_pd(c);
+            int len = qzk_rec_common(own, c);
+            if (len == QZK_REC_BYTES && maxlen > QZK_REC_BYTES)
+                len += qzk_lazy_matchlen(in, p + QZK_REC_BYTES, cur + QZK_REC_BYTES, maxlen - QZK_REC_BYTES);
+            if (len > maxlen) len = maxlen;
             hops++;
             bool stop = false;
             if (len > best) { best = len; bd = p - cur; stop = len >= nice; }

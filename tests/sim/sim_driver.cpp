@@ -157,7 +157,8 @@ int sim_deflate_lazy(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last
     uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
     const size_t span = (size_t)nchunks * chunk_sz;
     std::vector<uint8_t> lc(span + 64);
-    std::vector<uint16_t> dist(span + 64), pd(span + 64, 0x7777);
+    std::vector<uint16_t> dist(span + 64);
+    std::vector<qzk_lazyrec> pd(span + 64);
     std::vector<qzk_lazyres> res(span + 64);
     std::vector<qzk_lzmeta> meta(nchunks);
     uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
