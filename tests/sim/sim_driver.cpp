@@ -130,7 +130,17 @@ int sim_deflate_ragged(const uint8_t *src, uint32_t nchunks, uint32_t chunk_sz, 
     std::vector<uint8_t> slots((size_t)nchunks * stride);
     std::vector<uint32_t> ocrc(nchunks);
     if (level == 1) run_k1(2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), cdesc);
-    else {
+    else if (level >= 4) {                                  /* the lazy kernels, as the product path routes these levels */
+        std::vector<uint32_t> head((size_t)nchunks * QZK_HSIZE, 0);
+        std::vector<qzk_lazyrec> rec(n + 64);
+        std::vector<qzk_lazyres> res(n + 64);
+        const qzk_lvlcfg cfg = qzk_level_cfg(level);
+        sim::launch(nchunks, 64, 0, [&] { qzk_lazy_chain_kernel(src, n, chunk_sz, nchunks, cdesc, head.data(), rec.data()); });
+        sim::launch(nchunks, 64, 0, [&] { qzk_lazy_search_kernel(src, n, chunk_sz, nchunks, cdesc, rec.data(), res.data(), cfg); });
+        sim::launch(nchunks, 64, 0, [&] {
+            qzk_lazy_parse_kernel(src, n, chunk_sz, nchunks, cdesc, res.data(), lc.data(), dist.data(), meta.data(), cfg);
+        });
+    } else {
         std::vector<uint16_t> head((size_t)nchunks * QZK_HSIZE, 0), prev((size_t)nchunks * QZK_WSIZE, 0x5a5a);
         sim::launch((nchunks + 63) / 64, 64, 0, [&] {
             qzk_lz77_lane_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), head.data(), prev.data(),

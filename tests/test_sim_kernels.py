@@ -158,7 +158,7 @@ def test_lazy_levels_by_parallel_search_match_oracle(sim, level):
             assert out.raw[:ol.value] == O.sw_compress("RAW", src, chunk, level, last=last, cap=cap)[2], (kind, n, chunk, level, last)
 
 
-@pytest.mark.parametrize("level", [1, 6])
+@pytest.mark.parametrize("level", [1, 3, 6])
 def test_coalesced_launch_of_small_requests(sim, level):
     """Many small requests in one launch: every request starts on a chunk boundary, chunks carry their own length and
     'closes the stream' flag.  Each request's bytes must be what a call of its own produces."""
