@@ -102,12 +102,16 @@ class Session:
     """A QzSession_T set up the way test/main.c does it: qzGetDefaults -> tweak -> qzSetupSession."""
 
     def __init__(self, data_fmt=QZ_DEFLATE_GZIP_EXT, hw_buff_sz=65536, comp_lvl=1, lz4=False, strm_buff_sz=None,
-                 zlib_format=False):
+                 zlib_format=False, stop_at_stream_end=False):
         self.L = lib()
         self.s = QzSession()
-        if zlib_format:                        # qzSetupSessionDeflateExt(zlib_format = 1): RFC 1950 wrapper, Adler-32 trailer
+        if zlib_format or stop_at_stream_end:  # qzSetupSessionDeflateExt: zlib_format = 1 is the RFC 1950 wrapper with an Adler-32 trailer
             p = QzSessionParamsDeflateExt(); self.L.qzGetDefaultsDeflateExt(C.byref(p))
-            p.deflate_params.data_fmt = QZ_DEFLATE_RAW; p.zlib_format = 1
+            if zlib_format:
+                p.deflate_params.data_fmt = QZ_DEFLATE_RAW; p.zlib_format = 1
+            else:
+                p.deflate_params.data_fmt = data_fmt
+            p.stop_decompression_stream_end = 1 if stop_at_stream_end else 0
             p.deflate_params.common_params.hw_buff_sz = hw_buff_sz; p.deflate_params.common_params.comp_lvl = comp_lvl
             self.rc_setup = self.L.qzSetupSessionDeflateExt(C.byref(self.s), C.byref(p))
         elif lz4:
@@ -145,6 +149,12 @@ class Session:
             return rc, sl.value, dst.raw[:dl.value], crc.value
         rc = self.L.qzDecompress(C.byref(self.s), comp, C.byref(sl), dst, C.byref(dl))
         return rc, sl.value, dst.raw[:dl.value]
+
+    def end_of_stream(self):
+        """qzGetDeflateEndOfStream: 1 if the last decompress call ended on the end of a deflate stream"""
+        e = C.c_ubyte(7)
+        rc = self.L.qzGetDeflateEndOfStream(C.byref(self.s), C.byref(e))
+        return rc, e.value
 
     def close(self):
         self.L.qzTeardownSession(C.byref(self.s))

@@ -352,6 +352,39 @@ def test_member_larger_than_the_destination_comes_out_in_pieces():
     s.close()
 
 
+@pytest.mark.parametrize("fmt", ["GZIP_EXT", "GZIP", "ZLIB"])
+def test_stop_decompression_on_stream_end(fmt):
+    """test/main.c:1305-1702 (modes 27, 30, 31): 512 KB compressed as eight separate 64 KB streams; with
+    stop_decompression_stream_end set, one qzDecompress call over all of them decodes exactly the first stream and
+    qzGetDeflateEndOfStream reports 1; a cut-off stream is an error and reports 0; without the flag every stream is
+    decoded."""
+    A.lib().qzGetDeflateEndOfStream.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte)]
+    src = datagen.gen_bytes("silesia", 512 * 1024, 88)
+    mk = (lambda **kw: A.Session(hw_buff_sz=65536, zlib_format=True, **kw)) if fmt == "ZLIB" else (lambda **kw: A.Session(FMT[fmt], 65536, **kw))
+    s = mk(stop_at_stream_end=True)
+    assert s.rc_setup == A.QZ_OK
+    members = [s.compress(src[o:o + 65536], 1)[2] for o in range(0, len(src), 65536)]
+    comp = b"".join(members)
+    rc, used, back = s.decompress(comp, len(src))
+    assert rc == A.QZ_OK and back == src[:65536] and used == len(members[0]), (fmt, rc, used, len(back))
+    assert s.end_of_stream() == (A.QZ_OK, 1)
+    rc, used, back = s.decompress(comp[:1100], len(src))
+    assert rc != A.QZ_OK and back == b""
+    assert s.end_of_stream() == (A.QZ_OK, 0)
+    # the caller's loop gets the rest stream by stream
+    pos, got = 0, b""
+    while pos < len(comp):
+        rc, used, back = s.decompress(comp[pos:], len(src))
+        assert rc == A.QZ_OK and used > 0 and s.end_of_stream()[1] == 1
+        got += back; pos += used
+    assert got == src
+    s.close()
+    s2 = mk()
+    rc, used, back = s2.decompress(comp, len(src))
+    assert rc == A.QZ_OK and back == src and used == len(comp)
+    s2.close()
+
+
 def test_corrupt_input_is_a_data_error():
     s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
     src = datagen.gen_bytes("text", 90000, 6)
