@@ -892,6 +892,10 @@ extern "C" int qzCompressStream(QzSession_T *sess, QzStream_T *strm, unsigned in
     return rc;
 }
 
+/* qzDecompressStream (src/qatzip_stream.c:596-781): the caller may hand over the compressed data in slices that cut
+ * members anywhere, so unconsumed input is kept in the stream (pending_in) until the member it belongs to is complete;
+ * the slab grows when a member is larger than strm_buff_sz.  Output goes straight to the caller's buffer - a member
+ * larger than it comes out over several calls (decompress_deflate's held member), and pending_out says so. */
 extern "C" int qzDecompressStream(QzSession_T *sess, QzStream_T *strm, unsigned int last)
 {
     if (!sess || !strm || (last != 0 && last != 1) || !strm->out || (!strm->in && strm->in_sz > 0)) {
@@ -900,20 +904,40 @@ extern "C" int qzDecompressStream(QzSession_T *sess, QzStream_T *strm, unsigned 
     }
     Sess *s = NULL;
     if (ensure_ready(sess, &s) < 0) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
+    if (s->p.fmt == F_LZ4 || s->p.fmt == F_LZ4S) { strm->in_sz = 0; strm->out_sz = 0; return QZ_PARAMS; }   /* src/qatzip_stream.c:478-484 */
     if (!strm->opaque && stream_init(s, strm, false) != QZ_OK) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
     StreamBuf *b = (StreamBuf *)strm->opaque;
-    /* whole members are decoded straight from the caller's buffers: a member never has to fit the slab */
-    unsigned il = strm->in_sz, ol = strm->out_sz;
-    unsigned long c = 0;
-    (void)b;
-    int rc = qzDecompressCrc(sess, strm->in, &il, strm->out, &ol, &c);
-    if (rc == QZ_BUF_ERROR && il > 0) rc = QZ_OK;
+    const unsigned in_avail = strm->in_sz, out_room = strm->out_sz;
+    /* take all of the caller's input into the slab */
+    if ((uint64_t)strm->pending_in + in_avail > b->cap) {
+        const uint64_t want = std::max<uint64_t>((uint64_t)strm->pending_in + in_avail, 2ull * b->cap);
+        if (want > 0xfff00000ull) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
+        unsigned char *nb = (unsigned char *)qzMalloc((size_t)want, 0, COMMON_MEM);
+        if (!nb) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
+        memcpy(nb, b->in, strm->pending_in);
+        qzFree(b->in); b->in = nb; b->cap = (unsigned)want;
+    }
+    if (in_avail) memcpy(b->in + strm->pending_in, strm->in, in_avail);
+    strm->pending_in += in_avail;
+    unsigned produced = 0; int rc = QZ_OK;
+    while (strm->pending_in > 0 && produced < out_room) {
+        unsigned il = strm->pending_in, ol = out_room - produced;
+        unsigned long c = strm->crc_32;
+        rc = qzDecompressCrc(sess, b->in, &il, strm->out + produced, &ol, &c);
+        if (rc == QZ_BUF_ERROR && (il > 0 || ol > 0)) rc = QZ_OK;
+        if (rc != QZ_OK) break;
+        strm->crc_32 = (unsigned int)c;
+        produced += ol;
+        if (il) { memmove(b->in, b->in + il, strm->pending_in - il); strm->pending_in -= il; }
+        if (il == 0 && ol == 0) break;
+    }
+    strm->pending_out = s->d_hold ? (unsigned)std::min<uint64_t>(s->hold_len - s->hold_pos, 0xffffffffu) : 0;
+    if (rc == QZ_BUF_ERROR) rc = QZ_OK;                             /* no room left: the caller comes back with an empty buffer */
+    if (rc == QZ_DATA_ERROR && !last) rc = QZ_OK;                   /* an incomplete member so far: wait for the rest of it */
     if (rc != QZ_OK) { strm->in_sz = 0; strm->out_sz = 0; return rc == QZ_DATA_ERROR ? QZ_DATA_ERROR : QZ_FAIL; }
-    strm->crc_32 = (unsigned int)c;
-    strm->in_sz = il; strm->out_sz = ol;
+    strm->in_sz = in_avail; strm->out_sz = produced;
     return QZ_OK;
 }
-
 extern "C" int qzEndStream(QzSession_T *sess, QzStream_T *strm)
 {
     if (!sess || !strm) return QZ_PARAMS;

@@ -486,6 +486,59 @@ def test_stream_api_one_member_many_slices():
         sess.close()
 
 
+@pytest.mark.parametrize("out_room", [1 << 20, 50_000])
+def test_decompress_stream_fed_in_slices(out_room):
+    """qzDecompressStream the way the reference's stream tests drive it (test/main.c:2506-2847): compressed data arrives
+    in slices that cut members anywhere, output is collected from a fixed buffer - here also one smaller than the
+    members, so they come out in pieces.  Members of three producers; running CRC; damaged input; LZ4 sessions refused."""
+    import gzip
+    L = A.lib()
+    parts = [datagen.gen_bytes("silesia", 300_000, 91), datagen.gen_bytes("text", 65_536, 92), datagen.gen_bytes("runs", 1000, 93),
+             datagen.gen_bytes("records", 150_000, 94)]
+    cs = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    comp = b"".join(cs.compress(x, 1)[2] for x in parts[:3]) + gzip.compress(parts[3], 6)
+    want = b"".join(parts)
+    cs.close()
+
+    def run(data):
+        sess = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+        strm = A.QzStream()
+        obuf = C.create_string_buffer(out_room)
+        got, pos, rc, calls = b"", 0, A.QZ_OK, 0
+        while True:
+            k = min(10_000, len(data) - pos)
+            ibuf = C.create_string_buffer(data[pos:pos + k], max(k, 1))
+            strm.in_ = C.cast(ibuf, C.c_void_p); strm.in_sz = k
+            strm.out = C.cast(obuf, C.c_void_p); strm.out_sz = out_room
+            last = 1 if pos + k == len(data) else 0
+            rc = L.qzDecompressStream(C.byref(sess.s), C.byref(strm), last)
+            if rc != A.QZ_OK:
+                break
+            assert strm.in_sz == k
+            pos += k; got += obuf.raw[:strm.out_sz]; calls += 1
+            assert calls < 5000
+            if last and strm.pending_in == 0 and strm.pending_out == 0:
+                break
+        crc = strm.crc_32
+        L.qzEndStream(C.byref(sess.s), C.byref(strm))
+        sess.close()
+        return rc, got, crc
+
+    rc, got, crc = run(comp)
+    assert rc == A.QZ_OK and got == want
+    assert crc == zlib.crc32(want) & 0xffffffff
+    bad = bytearray(comp); bad[len(comp) // 3] ^= 0x55
+    rc, got, _ = run(bytes(bad))
+    assert rc != A.QZ_OK or got != want
+    lz = A.Session(hw_buff_sz=65536, lz4=True)
+    strm = A.QzStream()
+    buf = C.create_string_buffer(1000)
+    strm.in_ = C.cast(buf, C.c_void_p); strm.in_sz = 10; strm.out = C.cast(buf, C.c_void_p); strm.out_sz = 1000
+    assert L.qzDecompressStream(C.byref(lz.s), C.byref(strm), 1) == A.QZ_PARAMS
+    assert L.qzDecompressStream(C.byref(lz.s), None, 1) == A.QZ_PARAMS
+    lz.close()
+
+
 def test_pinned_memory():
     L = A.lib()
     for _ in range(100):                                  # test/main.c:2401-2441 allocates/frees in a loop
