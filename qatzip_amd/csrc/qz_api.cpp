@@ -677,7 +677,7 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
             *crc = qzd_crc32_combine((uint32_t)*crc, c, k);
         }
         s->hold_pos += k;
-        const bool last_piece = s->hold_pos == s->hold_len;
+        const bool last_piece = s->hold_pos == s->hold_len && n >= 1;     /* the held-back byte has to be there to be consumed */
         if (last_piece) { qzd_dev_free(s->ctx, s->d_hold); s->d_hold = NULL; s->hold_len = s->hold_pos = 0; s->end_of_stream = 1; }
         *src_len = last_piece ? 1 : 0; *dest_len = k;
         sess->total_in += *src_len; sess->total_out += k;
