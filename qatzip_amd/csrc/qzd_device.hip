@@ -130,7 +130,7 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
     hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
     if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess) return QZD_ERR_HIP;
     for (int i = 0; i < QZD_NBUF + 1; i++) hipEventCreateWithFlags(&c->cp_ev[i], hipEventDisableTiming);
-    for (int i = 0; i < 4; i++) hipEventCreateWithFlags(&c->so_ev[i], hipEventDisableTiming);
+    for (int i = 0; i < 8; i++) hipEventCreateWithFlags(&c->so_ev[i], hipEventDisableTiming);
     c->so_host = NULL; c->so_nat = NULL; c->so_sent = 0;
     for (int i = 0; i < QZD_K1EV; i++) { hipEventCreate(&c->k1ev[i][0]); hipEventCreate(&c->k1ev[i][1]); }
     {
@@ -165,7 +165,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     for (int i = 0; i < QZD_NBUF; i++) {
         hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
         hipStreamDestroy(c->st[i]); hipEventDestroy(c->done[i]); hipEventDestroy(c->k1done[i]);
-        if (i == 0) { for (int k = 0; k < 4; k++) hipEventDestroy(c->so_ev[k]); hipStreamDestroy(c->st_copy); for (int k = 0; k < QZD_NBUF + 1; k++) hipEventDestroy(c->cp_ev[k]); }
+        if (i == 0) { for (int k = 0; k < 8; k++) hipEventDestroy(c->so_ev[k]); hipStreamDestroy(c->st_copy); for (int k = 0; k < QZD_NBUF + 1; k++) hipEventDestroy(c->cp_ev[k]); }
         for (int k = 0; k < 4; k++) hipEventDestroy(c->ev[i][k]);
     }
     hipEventDestroy(c->ev_begin); hipEventDestroy(c->ev_end);

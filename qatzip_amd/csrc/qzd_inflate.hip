@@ -41,7 +41,7 @@
  * got Huffman-coded) never let a misaligned decoder fall into step, so those segments come back to the serial kernel
  * and set the pace: on the bench data 13 % of the segments do, and the serial phase A alone is faster */
 #define QZD_SPEC_LANES 1u
-#define QZD_SO_PARTS 4u             /* output ranges a streamed decode is resolved and sent in */
+#define QZD_SO_PARTS 8u             /* output ranges a streamed decode is resolved and sent in */
 
 /* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF */
 __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list, uint32_t cap, uint32_t *count)

@@ -43,7 +43,7 @@ struct qzd_ctx {
     uint8_t *d_aux, *h_aux; size_t aux_cap;
     /* output streaming (qzd_inflate_stream_to_host): while set, the two-phase decoder resolves the output range by range
      * and sends each range to so_host behind its launch; so_nat[i] = array index of the segment that is i-th in the output */
-    uint8_t *so_host; const uint32_t *so_nat; uint64_t so_sent; hipEvent_t so_ev[4];
+    uint8_t *so_host; const uint32_t *so_nat; uint64_t so_sent; hipEvent_t so_ev[8];
     uint8_t *d_big; size_t big_cap;                 /* device-only scratch (per-segment decode tables of K3b) */
     uint32_t *d_cdesc; uint32_t cdesc_cap;          /* per-slot descriptors of a coalesced launch (qzd_deflate_slots) */
     uint8_t *d_lane; size_t lane_cap;               /* device-only scratch of the one-chunk-per-lane compress path (K1b) */
