@@ -82,6 +82,20 @@ def test_pipe_mode_round_trip(exe):
     assert r3.returncode == 0 and len(r3.stdout) == 34 and gzip.decompress(r3.stdout) == b""
 
 
+def test_level_option(exe, tmp_path):
+    src = datagen.gen_bytes("text", 400_000, 4)
+    for lvl in (3, 6, 9):
+        f = tmp_path / ("l%d.txt" % lvl)
+        f.write_bytes(src)
+        r = run(exe, "-k", "-L", str(lvl), str(f))
+        assert r.returncode == 0, r.stderr
+        out = (tmp_path / ("l%d.txt.gz" % lvl)).read_bytes()
+        assert out == O.sw_compress("GZIP_EXT", src, 65536, lvl, cap=len(src) * 9 // 8 + 65536)[2]     # zlib's level, its XFL byte
+        assert gzip.decompress(out) == src
+    r = run(exe, "-L", "12", str(tmp_path / "l3.txt"))                 # a QAT level zlib does not have
+    assert r.returncode != 0
+
+
 def test_lz4_files(exe, tmp_path):
     src = datagen.gen_bytes("silesia", 300_000, 2)
     f = tmp_path / "x.dat"
