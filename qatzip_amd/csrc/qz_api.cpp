@@ -470,12 +470,14 @@ static int compress_lz4(QzSession_T *sess, Sess *s, const unsigned char *src, un
 {
     const uint32_t n = *src_len, cap = *dest_len;
     *src_len = 0; *dest_len = 0;
-    if (n > 65536) {
-        logmsg(LOG_ERROR, "LZ4 calls above 64 KB need liblz4's linked-block mode, which the GPU path does not produce\n");
-        return QZ_NOT_SUPPORTED;
-    }
+    /* Up to 64 KB a call is one frame with one block, byte for byte what LZ4F_compressFrame writes.  Above that the
+     * software path would link the blocks of ONE frame (each block may reach 64 KB back into the previous ones and the
+     * match table carries over), which makes the whole call one serial chain; like the hardware path
+     * (qzLZ4HeaderGen per chunk, src/qatzip_lz4.c:62-120) the call becomes a sequence of independent frames instead,
+     * one per 64 KB, each exactly the frame a call of its own would have produced.  Any LZ4 frame reader takes it. */
     if (s->p.comp_lvl >= 3) return QZ_NOT_SUPPORTED;               /* level >= 3 is LZ4-HC in liblz4 */
-    const uint64_t bound = 19 + 4 * ((n >> 16) + ((n & 65535) != 0)) + (uint64_t)n + 8;   /* LZ4F_compressFrameBound */
+    const uint64_t nfr = n ? ((uint64_t)n + 65535) >> 16 : 1;
+    const uint64_t bound = nfr * (19 + 4 + 8) + (uint64_t)n;       /* LZ4F_compressFrameBound of every piece */
     if (cap < bound) return QZ_FAIL;                               /* LZ4F_ERROR_dstMaxSize_tooSmall => QZ_FAIL */
     int rc = reserve(s, n, bound + 64);
     if (rc) return rc;

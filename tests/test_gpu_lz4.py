@@ -74,9 +74,13 @@ def test_api_lz4_session_roundtrip_and_parity():
     comp = b"".join(s.compress(p, 1, cap=70000)[2] for p in parts)
     rc, used, back = s.decompress(comp, 5 * 65536)
     assert rc == A.QZ_OK and used == len(comp) and back == b"".join(parts)
-    # above one block: linked-block frames are not produced => loud failure, lengths zeroed
-    rc, used, out, _ = s.compress(b"x" * 70000, 1, cap=80000)
-    assert rc == A.QZ_NOT_SUPPORTED and used == 0 and out == b""
+    # above one block: one independent frame per 64 KB (the hardware path's shape), each the frame a call of its own writes
+    big = datagen.gen_bytes("silesia", 300_000, 77)
+    rc, used, out, _ = s.compress(big, 1, cap=len(big) + 4096)
+    assert rc == A.QZ_OK and used == len(big)
+    assert out == b"".join(O.sw_compress("LZ4", big[i:i + 65536], 65536, 1, cap=70000)[2] for i in range(0, len(big), 65536))
+    rc, cused, back = s.decompress(out, len(big))
+    assert rc == A.QZ_OK and back == big and cused == len(out)
     # destination below LZ4F_compressFrameBound => QZ_FAIL like the software path
     rc, used, out, _ = s.compress(parts[0], 1, cap=1000)
     assert rc == A.QZ_FAIL and used == 0
