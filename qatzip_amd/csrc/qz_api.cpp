@@ -906,7 +906,7 @@ extern "C" int qzDecompressStream(QzSession_T *sess, QzStream_T *strm, unsigned 
     }
     Sess *s = NULL;
     if (ensure_ready(sess, &s) < 0) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
-    if (s->p.fmt == F_LZ4 || s->p.fmt == F_LZ4S) { strm->in_sz = 0; strm->out_sz = 0; return QZ_PARAMS; }   /* src/qatzip_stream.c:478-484 */
+    if (s->p.fmt == F_LZ4S) { strm->in_sz = 0; strm->out_sz = 0; return QZ_PARAMS; }
     if (!strm->opaque && stream_init(s, strm, false) != QZ_OK) { strm->in_sz = 0; strm->out_sz = 0; return QZ_FAIL; }
     StreamBuf *b = (StreamBuf *)strm->opaque;
     const unsigned in_avail = strm->in_sz, out_room = strm->out_sz;
@@ -935,7 +935,7 @@ extern "C" int qzDecompressStream(QzSession_T *sess, QzStream_T *strm, unsigned 
     }
     strm->pending_out = s->d_hold ? (unsigned)std::min<uint64_t>(s->hold_len - s->hold_pos, 0xffffffffu) : 0;
     if (rc == QZ_BUF_ERROR) rc = QZ_OK;                             /* no room left: the caller comes back with an empty buffer */
-    if (rc == QZ_DATA_ERROR && !last) rc = QZ_OK;                   /* an incomplete member so far: wait for the rest of it */
+    if ((rc == QZ_DATA_ERROR || (rc == QZ_FAIL && s->p.fmt == F_LZ4)) && !last) rc = QZ_OK;   /* an incomplete member / frame so far: wait for the rest of it */
     if (rc != QZ_OK) { strm->in_sz = 0; strm->out_sz = 0; return rc == QZ_DATA_ERROR ? QZ_DATA_ERROR : QZ_FAIL; }
     strm->in_sz = in_avail; strm->out_sz = produced;
     return QZ_OK;

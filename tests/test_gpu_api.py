@@ -530,11 +530,25 @@ def test_decompress_stream_fed_in_slices(out_room):
     bad = bytearray(comp); bad[len(comp) // 3] ^= 0x55
     rc, got, _ = run(bytes(bad))
     assert rc != A.QZ_OK or got != want
+    # LZ4 sessions: the compress side of the stream API refuses them (src/qatzip_stream.c:478-484), the decompress side reads frames
     lz = A.Session(hw_buff_sz=65536, lz4=True)
+    big = datagen.gen_bytes("silesia", 200_000, 95)
+    frames = lz.compress(big, 1, cap=len(big) + 4096)[2]
     strm = A.QzStream()
+    obuf = C.create_string_buffer(1 << 20)
+    got, pos = b"", 0
+    while pos < len(frames):
+        k = min(7000, len(frames) - pos)
+        ibuf = C.create_string_buffer(frames[pos:pos + k], k)
+        strm.in_ = C.cast(ibuf, C.c_void_p); strm.in_sz = k; strm.out = C.cast(obuf, C.c_void_p); strm.out_sz = len(obuf)
+        assert L.qzDecompressStream(C.byref(lz.s), C.byref(strm), 1 if pos + k == len(frames) else 0) == A.QZ_OK
+        got += obuf.raw[:strm.out_sz]; pos += k
+    assert got == big and strm.pending_in == 0
+    L.qzEndStream(C.byref(lz.s), C.byref(strm))
+    strm2 = A.QzStream()
     buf = C.create_string_buffer(1000)
-    strm.in_ = C.cast(buf, C.c_void_p); strm.in_sz = 10; strm.out = C.cast(buf, C.c_void_p); strm.out_sz = 1000
-    assert L.qzDecompressStream(C.byref(lz.s), C.byref(strm), 1) == A.QZ_PARAMS
+    strm2.in_ = C.cast(buf, C.c_void_p); strm2.in_sz = 10; strm2.out = C.cast(buf, C.c_void_p); strm2.out_sz = 1000
+    assert L.qzCompressStream(C.byref(lz.s), C.byref(strm2), 1) == A.QZ_PARAMS
     assert L.qzDecompressStream(C.byref(lz.s), None, 1) == A.QZ_PARAMS
     lz.close()
 
