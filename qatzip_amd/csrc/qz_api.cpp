@@ -628,6 +628,9 @@ static int decompress_sized_members(Sess *s, const unsigned char *src, uint32_t 
         if (hl < 0 || es == 0 || ed == 0) break;                    /* not a sized member (e.g. a software-path stream) */
         if ((uint64_t)pos + hl + ed + 8 > n) break;                 /* cut short: the caller comes back with more */
         if (out + es > cap) break;                                  /* destination full: whole members only */
+        if (es > 512u * 1024u) break;                               /* larger than any hw_buff_sz: a multi-chunk member of the software
+                                                                     * path (qzCompress fills the sizes in for those too) - the member loop
+                                                                     * below cuts it at its flush markers */
         Mem m = { pos + (uint32_t)hl, ed, es };
         mem.push_back(m);
         pos += (uint32_t)hl + ed + 8; out += es;
@@ -656,7 +659,9 @@ static int decompress_sized_members(Sess *s, const unsigned char *src, uint32_t 
         if (crc) *crc = (to == 0 && *crc == 0) ? c32[good] : qzd_crc32_combine((uint32_t)*crc, c32[good], m.usz);
         to += m.usz;
     }
-    if (good == 0) return QZ_DATA_ERROR;
+    /* a member that is not ONE deflate segment (several chunks behind one sized header, or damaged) ends the batch; when it
+     * is the first one the member loop takes over from the start and finds out which */
+    if (good == 0) return 0;
     *ti_out = mem[good - 1].pay + mem[good - 1].csz + 8;            /* end of the last good member */
     *to_out = (uint32_t)to;
     return (int)good;

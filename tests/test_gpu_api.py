@@ -278,6 +278,12 @@ def test_multi_member_decompress_and_buf_error():
     comp = b"".join(s.compress(p, 1)[2] for p in parts)
     rc, used, back = s.decompress(comp, sum(map(len, parts)) + 10)
     assert rc == A.QZ_OK and used == len(comp) and back == b"".join(parts)
+    # a multi-chunk member FIRST (qzCompress fills the size fields of the header for those too, so it looks like the
+    # hardware path's one-chunk members until it is decoded), then small ones: the batch decode steps aside
+    parts2 = [datagen.gen_bytes("silesia", n, 40 + i) for i, n in enumerate((300000, 65536, 10, 140000))]
+    comp2 = b"".join(s.compress(p, 1)[2] for p in parts2)
+    rc, used, back = s.decompress(comp2, sum(map(len, parts2)) + 16)
+    assert rc == A.QZ_OK and used == len(comp2) and back == b"".join(parts2)
     # destination that only holds the first member: progress is reported, caller loops (utils/qzip.c:217-227)
     rc, used, back = s.decompress(comp, 65536 + 500)
     assert rc in (A.QZ_OK, A.QZ_BUF_ERROR) and back == parts[0] and 0 < used < len(comp)

@@ -58,6 +58,20 @@ def test_blocks_become_members_and_input_is_removed(exe, tmp_path):
     assert f.read_bytes() == src and not (tmp_path / "t.txt.gz").exists()
 
 
+def test_gzipext_blocks_round_trip(exe, tmp_path):
+    # several gzip-ext members of many chunks each in one file (what -b produces): read back in one go
+    src = datagen.gen_bytes("silesia", 2_000_000, 12)
+    f = tmp_path / "m.bin"
+    f.write_bytes(src)
+    r = run(exe, "-O", "gzipext", "-b", "524288", str(f))
+    assert r.returncode == 0, r.stderr
+    out = (tmp_path / "m.bin.gz").read_bytes()
+    assert out == b"".join(O.sw_compress("GZIP_EXT", src[i:i + 524288], 65536, 1)[2] for i in range(0, len(src), 524288))
+    r = run(exe, "-d", str(tmp_path / "m.bin.gz"))
+    assert r.returncode == 0, r.stderr
+    assert f.read_bytes() == src
+
+
 def test_decompress_foreign_gzip(exe, tmp_path):
     src = datagen.gen_bytes("records", 1_200_000, 5)
     g = tmp_path / "foreign.gz"
