@@ -19,10 +19,13 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t0 = time.time(); n_ok = 0; bad = []
 while time.time() - t0 < budget:
     rng = random.Random(seed)
-    fmt = rng.choice(["GZIP_EXT", "GZIP_EXT", "GZIP", "RAW", "4B", "ZLIB"])
+    fmt = rng.choice(["GZIP_EXT", "GZIP_EXT", "GZIP", "RAW", "4B", "ZLIB", "LZ4"])
     hw = rng.choice([16384, 65536, 65536, 131072])
     lvl = rng.choice([1, 1, 1, 4, 2])
-    s = A.Session(hw_buff_sz=hw, comp_lvl=lvl, zlib_format=True) if fmt == "ZLIB" else A.Session(FMT[fmt], hw, comp_lvl=lvl)
+    if fmt == "LZ4":
+        lvl = 1
+    s = (A.Session(hw_buff_sz=hw, comp_lvl=lvl, zlib_format=True) if fmt == "ZLIB" else
+         A.Session(hw_buff_sz=hw, lz4=True) if fmt == "LZ4" else A.Session(FMT[fmt], hw, comp_lvl=lvl))
     ok = s.rc_setup == A.QZ_OK
     members, plain = [], []
     for m in range(rng.choice([1, 1, 2, 4]) if fmt not in ("RAW", "4B") else 1):
@@ -31,7 +34,11 @@ while time.time() - t0 < budget:
         if kind == "lzmix":
             n = min(n, 100000)
         src = datagen.gen_bytes(kind, n, 20000 + seed * 7 + m)
-        if rng.random() < 0.3 and n > hw and fmt != "4B":       # the member written by two calls: last = 0, then last = 1
+        if fmt == "LZ4":                                        # one frame per 64 KB, each what a call of its own writes
+            rc, used, out, _ = s.compress(src, 1, cap=n + 64 * (n // 65536 + 2))
+            exp = b"".join(O.sw_compress("LZ4", src[i:i + 65536], 65536, 1, cap=70000)[2] for i in range(0, max(n, 1), 65536))
+            ok &= rc == A.QZ_OK and used == n and out == exp
+        elif rng.random() < 0.3 and n > hw and fmt != "4B":     # the member written by two calls: last = 0, then last = 1
             # (not for the 4-byte header: a stream opened with last = 0 keeps a zero length there, src/qatzip_sw.c:166)
             cut = (rng.randrange(1, n) // hw) * hw or hw
             rc1, u1, o1, _ = s.compress(src[:cut], 0)
