@@ -21,6 +21,18 @@ def zlib_pinned():
     return zlib.ZLIB_RUNTIME_VERSION == "1.2.11"
 
 
+def _piece(co, chunk: bytes, fin: bool) -> bytes:
+    """deflate(chunk) + Z_FULL_FLUSH / Z_FINISH the way the reference issues it (one deflate() call into a large
+    destination, src/qatzip_sw.c:190-197)."""
+    piece = co.compress(chunk) + co.flush(zlib.Z_FINISH if fin else zlib.Z_FULL_FLUSH)
+    # CPython's flush() calls deflate() again whenever its own output buffer came back exactly full, and zlib answers a
+    # repeated Z_FULL_FLUSH with a second empty stored block (zlib.h: "avail_out greater than six to avoid repeated flush
+    # markers").  The reference never sees that; drop the artefact.
+    if not fin and len(chunk) and piece.endswith(b"\x00\x00\xff\xff\x00\x00\x00\xff\xff"):
+        piece = piece[:-5]
+    return piece
+
+
 def raw_chunks(src: bytes, hw: int, level: int = 1, last: int = 1):
     """Per-chunk raw deflate pieces of ONE continuous stream (wbits -15)."""
     co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY)
@@ -32,7 +44,8 @@ def raw_chunks(src: bytes, hw: int, level: int = 1, last: int = 1):
         chunk = src[pos:pos + send]
         pos += send
         fin = (pos == n and last == 1)
-        out.append(co.compress(chunk) + co.flush(zlib.Z_FINISH if fin else zlib.Z_FULL_FLUSH))
+        piece = _piece(co, chunk, fin)
+        out.append(piece)
         if pos == n:
             break
     return out
@@ -65,7 +78,7 @@ def sw_compress(fmt: int, src: bytes, hw: int = 65536, level: int = 1, last: int
             chunk = src[pos:pos + send]
             pos += send
             fin = (pos == len(src) and last == 1)
-            out += co.compress(chunk) + co.flush(zlib.Z_FINISH if fin else zlib.Z_FULL_FLUSH)
+            out += _piece(co, chunk, fin)
             if pos == len(src):
                 return out
     raise ValueError(fmt)
@@ -81,7 +94,7 @@ def gzip_stream_check(src: bytes, hw: int, level: int = 1) -> bytes:
         chunk = src[pos:pos + send]
         pos += send
         fin = pos == len(src)
-        out += co.compress(chunk) + co.flush(zlib.Z_FINISH if fin else zlib.Z_FULL_FLUSH)
+        out += _piece(co, chunk, fin)
         if fin:
             return out
 
