@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 #include <set>
 #include <vector>
 
@@ -982,7 +983,21 @@ static int run_sync2(QzSession_T *sess, const unsigned char *src, unsigned char 
  * bytes are what a call of its own would have produced. */
 #define AQ_BATCH_MAX_REQ   (4u << 20)      /* larger requests fill the device by themselves */
 #define AQ_BATCH_MAX_SLOTS 16384u
+#define AQ_BATCH_MAX_BYTES (1ull << 30)    /* slot-aligned input of one coalesced launch (a slot is hw_buff_sz bytes) */
 static size_t g_aq_batches, g_aq_batched_reqs;       /* observability (qzamd_async_stats) */
+
+/* pinned staging of the coalescing queue: one buffer per process, grown on demand, used only by the consumer thread */
+static unsigned char *g_stage; static uint64_t g_stage_cap;
+static unsigned char *stage_reserve(uint64_t n)
+{
+    if (n <= g_stage_cap) return g_stage;
+    if (g_stage) qzd_host_free_pinned(g_stage);
+    g_stage_cap = 0;
+    n = (n + (1u << 20)) & ~(uint64_t)((1u << 20) - 1);
+    g_stage = (unsigned char *)qzd_host_alloc_pinned((size_t)n);
+    if (g_stage) g_stage_cap = n;
+    return g_stage;
+}
 
 static Sess *batchable(const AsyncReq &q)
 {
@@ -1009,11 +1024,14 @@ static bool compress_batch(const std::vector<AsyncReq> &run, const std::vector<S
     const uint32_t nslots = (uint32_t)cdesc.size();
     const uint64_t in_bytes = (uint64_t)nslots * hw;
     const uint64_t worst = in_bytes + (uint64_t)nslots * (5ull * (hw / 32767 + 2) + 16) + 64;
-    if (reserve(s0, in_bytes, worst) != QZ_OK) return false;
-    std::vector<unsigned char> stage(in_bytes);                  /* slot-aligned copy of every request's input */
+    if (in_bytes > AQ_BATCH_MAX_BYTES + AQ_BATCH_MAX_REQ + hw || reserve(s0, in_bytes, worst) != QZ_OK) return false;
+    /* slot-aligned copy of every request's input in the queue's pinned staging buffer (allocated once, reused, never
+     * zeroed: the gaps between requests are not read - cdesc carries each slot's length), then ONE copy to the device */
+    unsigned char *stage = stage_reserve(std::max<uint64_t>(in_bytes, worst));
+    if (!stage) return false;
     for (size_t i = 0; i < run.size(); i++)
-        if (run[i].res->src_len) memcpy(stage.data() + (size_t)first[i] * hw, run[i].src, run[i].res->src_len);
-    if (qzd_h2d(s0->ctx, s0->d_in, stage.data(), in_bytes) != QZD_OK) return false;
+        if (run[i].res->src_len) memcpy(stage + (size_t)first[i] * hw, run[i].src, run[i].res->src_len);
+    if (qzd_h2d(s0->ctx, s0->d_in, stage, in_bytes) != QZD_OK) return false;
     std::vector<uint32_t> lens(nslots), crcs(nslots);
     uint64_t produced = 0;
     if (qzd_deflate_slots(s0->ctx, s0->d_in, nslots, hw, (int)lvl, cdesc.data(), s0->d_out, s0->out_cap, &produced,
@@ -1021,9 +1039,7 @@ static bool compress_batch(const std::vector<AsyncReq> &run, const std::vector<S
         logmsg(LOG_ERROR, "coalesced GPU deflate failed: %s\n", qzd_last_error(s0->ctx));
         return false;
     }
-    stage.resize(produced);
-    if (produced && qzd_d2h(s0->ctx, stage.data(), s0->d_out, produced) != QZD_OK) return false;
-
+    if (produced && qzd_d2h(s0->ctx, stage, s0->d_out, produced) != QZD_OK) return false;
     const unsigned hl = hdr_len(fmt), fl = ftr_len(fmt);
     uint64_t pos = 0;
     for (size_t i = 0; i < run.size(); i++) {
@@ -1038,7 +1054,7 @@ static bool compress_batch(const std::vector<AsyncReq> &run, const std::vector<S
         }
         unsigned long *crc = (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
         write_header(dest, fmt, lvl);
-        memcpy(dest + hl, stage.data() + bpos, body);
+        memcpy(dest + hl, stage + bpos, body);
         uint32_t sum = 0, done = 0;
         for (uint32_t k = 0; k < nch; k++) {                    /* same folds as compress_deflate */
             const uint32_t cl = cdesc[k0 + k] & 0x7fffffffu;
@@ -1094,13 +1110,13 @@ static bool decompress_batch(const std::vector<AsyncReq> &run, const std::vector
         io += (csz + 15u) & ~15u; oo += usz;
     }
     if (reserve(s0, io + 64, oo + 64) != QZ_OK) return false;
-    std::vector<unsigned char> stage(io + 64);
-    for (uint32_t i = 0; i < nm; i++) memcpy(stage.data() + segs[i].in_off, run[i].src + pay[i], segs[i].in_len);
-    if (qzd_h2d(s0->ctx, s0->d_in, stage.data(), io + 64) != QZD_OK) return false;
+    unsigned char *stage = stage_reserve(std::max<uint64_t>(io + 64, oo));
+    if (!stage) return false;
+    for (uint32_t i = 0; i < nm; i++) memcpy(stage + segs[i].in_off, run[i].src + pay[i], segs[i].in_len);
+    if (qzd_h2d(s0->ctx, s0->d_in, stage, io + 64) != QZD_OK) return false;
     if (qzd_inflate_segments(s0->ctx, s0->d_in, s0->d_out, segs.data(), nm, res.data()) != QZD_OK) return false;
     if (qzd_crc32_ranges(s0->ctx, s0->d_out, rg.data(), nm, c32.data()) != QZD_OK) return false;
-    stage.resize(oo);
-    if (oo && qzd_d2h(s0->ctx, stage.data(), s0->d_out, oo) != QZD_OK) return false;
+    if (oo && qzd_d2h(s0->ctx, stage, s0->d_out, oo) != QZD_OK) return false;
     for (uint32_t i = 0; i < nm; i++) {
         QzResult_T *r = run[i].res;
         const unsigned char *tr = run[i].src + pay[i] + segs[i].in_len;
@@ -1109,7 +1125,7 @@ static bool decompress_batch(const std::vector<AsyncReq> &run, const std::vector
             run_sync2(run[i].sess, run[i].src, run[i].dest, r, false);      /* the one-call path reports what is wrong with it */
             continue;
         }
-        memcpy(run[i].dest, stage.data() + segs[i].out_off, usz);
+        memcpy(run[i].dest, stage + segs[i].out_off, usz);
         unsigned long *crc = (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
         if (crc) *crc = *crc == 0 ? c32[i] : qzd_crc32_combine((uint32_t)*crc, c32[i], usz);
         r->dest_len = usz; r->ext_rc = 0; r->status = QZ_OK;        /* src_len: the whole member */
@@ -1150,7 +1166,7 @@ static void *async_consumer(void *)
             ss.push_back(s0);
             uint64_t slots = run[0].res->src_len / s0->p.hw_buff_sz + 1;
             pthread_mutex_lock(&g_aq_lock);
-            while (g_aq_head < g_aq.size() && slots < AQ_BATCH_MAX_SLOTS) {
+            while (g_aq_head < g_aq.size() && slots < AQ_BATCH_MAX_SLOTS && slots * s0->p.hw_buff_sz < AQ_BATCH_MAX_BYTES) {
                 AsyncReq q = g_aq[g_aq_head];
                 pthread_mutex_unlock(&g_aq_lock);                /* ensure_ready may take the global lock */
                 Sess *s = q.compress != comp ? NULL : comp ? batchable(q) : batchable_d(q, &a_, &b_, &c_);
@@ -1165,25 +1181,44 @@ static void *async_consumer(void *)
         }
         bool done = false;
         if (run.size() > 1) {
-            done = comp ? compress_batch(run, ss) : decompress_batch(run, ss);
+            try { done = comp ? compress_batch(run, ss) : decompress_batch(run, ss); }
+            catch (const std::bad_alloc &) { done = false; }        /* out of host memory for the batch: one request at a time */
             if (done) { pthread_mutex_lock(&g_aq_lock); g_aq_batches++; g_aq_batched_reqs += run.size(); pthread_mutex_unlock(&g_aq_lock); }
         }
-        for (size_t i = 0; i < run.size(); i++) {
-            if (!done) run_sync2(run[i].sess, run[i].src, run[i].dest, run[i].res, run[i].compress);
-            run[i].cb(run[i].res);
-        }
+        if (!done) for (size_t i = 0; i < run.size(); i++) run_sync2(run[i].sess, run[i].src, run[i].dest, run[i].res, run[i].compress);
+        /* every request of the batch is finished before the first callback runs, and none of their sessions counts as
+         * running any more: a callback may tear down its own session, or another one of the same batch */
         pthread_mutex_lock(&g_aq_lock);
         g_aq_running.clear();
         pthread_cond_broadcast(&g_aq_idle);
         pthread_mutex_unlock(&g_aq_lock);
+        for (size_t i = 0; i < run.size(); i++) run[i].cb(run[i].res);
     }
     return NULL;
 }
 
 /* wait until no queued or running request refers to sess (NULL: until the queue is empty) */
+static pthread_t g_aq_tid;
 static void async_drain(QzSession_T *sess)
 {
     pthread_mutex_lock(&g_aq_lock);
+    if (g_aq_thread && pthread_equal(pthread_self(), g_aq_tid)) {
+        /* called from a completion callback (the consumer thread itself): waiting would wait for this very thread.
+         * Requests of the session that are still queued are cancelled - reported QZ_FAIL through their callbacks. */
+        std::vector<AsyncReq> dropped;
+        size_t w = g_aq_head;
+        for (size_t i = g_aq_head; i < g_aq.size(); i++) {
+            if (sess && g_aq[i].sess != sess) g_aq[w++] = g_aq[i]; else dropped.push_back(g_aq[i]);
+        }
+        g_aq.resize(w);
+        pthread_mutex_unlock(&g_aq_lock);
+        for (size_t i = 0; i < dropped.size(); i++) {
+            QzResult_T *r = dropped[i].res;
+            r->status = QZ_FAIL; r->src_len = 0; r->dest_len = 0;
+            dropped[i].cb(r);
+        }
+        return;
+    }
     for (;;) {
         bool busy = false;
         for (size_t i = 0; i < g_aq_running.size() && !busy; i++) busy = !sess || g_aq_running[i] == sess;
@@ -1204,7 +1239,7 @@ static int submit2(QzSession_T *sess, const unsigned char *src, unsigned char *d
         pthread_t th;
         if (pthread_create(&th, NULL, async_consumer, NULL) != 0) { pthread_mutex_unlock(&g_aq_lock); return QZ_FAIL; }
         pthread_detach(th);
-        g_aq_thread = true;
+        g_aq_tid = th; g_aq_thread = true;
     }
     AsyncReq q = { sess, src, dest, cb, r, compress };
     g_aq.push_back(q);

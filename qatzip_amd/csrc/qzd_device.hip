@@ -94,12 +94,11 @@ static uint32_t crc_multmodp(uint32_t a, uint32_t b)
 
 uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
 {
-    static uint32_t x2n[32];
-    if (!x2n[0]) {
-        uint32_t p = 1u << 30;
-        x2n[0] = p;
-        for (int i = 1; i < 32; i++) x2n[i] = p = crc_multmodp(p, p);
-    }
+    /* x^(2^n) mod P, filled once behind the thread-safe initialisation of a function-local static (sessions on
+     * different threads make their first call concurrently) */
+    struct X2N { uint32_t v[32]; X2N() { uint32_t p = 1u << 30; v[0] = p; for (int i = 1; i < 32; i++) v[i] = p = crc_multmodp(p, p); } };
+    static const X2N tab;
+    const uint32_t *x2n = tab.v;
     uint32_t p = 1u << 31; unsigned k = 3;
     for (uint64_t n = len2; n; n >>= 1, k++) if (n & 1) p = crc_multmodp(x2n[k & 31], p);
     return crc_multmodp(p, crc1) ^ crc2;
@@ -121,14 +120,15 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
     if (!c) return QZD_ERR_HIP;
     memset(c, 0, sizeof(*c));
     c->device = device;
+#define QZD_CREATE_FAIL do { qzd_destroy(c); return QZD_ERR_HIP; } while (0)   /* no half-built context leaks */
     for (int i = 0; i < QZD_NBUF; i++) {
-        if (hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking) != hipSuccess) return QZD_ERR_HIP;
+        if (hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking) != hipSuccess) QZD_CREATE_FAIL;
         hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->k1done[i], hipEventDisableTiming);
         for (int k = 0; k < 4; k++) hipEventCreate(&c->ev[i][k]);
     }
     hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
-    if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess) return QZD_ERR_HIP;
+    if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess) QZD_CREATE_FAIL;
     for (int i = 0; i < QZD_NBUF + 1; i++) hipEventCreateWithFlags(&c->cp_ev[i], hipEventDisableTiming);
     for (int i = 0; i < 8; i++) hipEventCreateWithFlags(&c->so_ev[i], hipEventDisableTiming);
     c->so_host = NULL; c->so_nat = NULL; c->so_sent = 0;
@@ -137,7 +137,7 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         /* K1 residency (measured): QZD_K1_WGS_PER_CU persistent single-wave workgroups per CU, each with
          * its own 512 KiB candidate table.  QATZIP_AMD_K1_WGS=<n> overrides the total. */
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return QZD_ERR_HIP;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) QZD_CREATE_FAIL;
         const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
         c->k1_wgs = QZD_K1_WGS_PER_CU * cus;
         const char *e = getenv("QATZIP_AMD_K1_WGS");
@@ -148,11 +148,12 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
          * only as many as its chunks can occupy: a session that decompresses, or only ever sees small calls, holds none
          * or few */
         c->k1_tables = NULL; c->k1_tab_wgs = 0;
-        if (hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) return QZD_ERR_HIP;
+        if (hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) QZD_CREATE_FAIL;
     }
-    if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) return QZD_ERR_HIP;
+    if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) QZD_CREATE_FAIL;
     hipHostMalloc((void **)&c->h_running, 8, hipHostMallocDefault);
     hipHostMalloc((void **)&c->h_overflow, 4, hipHostMallocDefault);
+#undef QZD_CREATE_FAIL
     *out = c;
     return QZD_OK;
 }
@@ -164,12 +165,20 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     hipDeviceSynchronize();
     for (int i = 0; i < QZD_NBUF; i++) {
         hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
-        hipStreamDestroy(c->st[i]); hipEventDestroy(c->done[i]); hipEventDestroy(c->k1done[i]);
-        if (i == 0) { for (int k = 0; k < 8; k++) hipEventDestroy(c->so_ev[k]); hipStreamDestroy(c->st_copy); for (int k = 0; k < QZD_NBUF + 1; k++) hipEventDestroy(c->cp_ev[k]); }
-        for (int k = 0; k < 4; k++) hipEventDestroy(c->ev[i][k]);
+        /* handles may be missing: qzd_create comes here from its failure paths */
+        if (c->st[i]) hipStreamDestroy(c->st[i]);
+        if (c->done[i]) hipEventDestroy(c->done[i]);
+        if (c->k1done[i]) hipEventDestroy(c->k1done[i]);
+        if (i == 0) {
+            for (int k = 0; k < 8; k++) if (c->so_ev[k]) hipEventDestroy(c->so_ev[k]);
+            if (c->st_copy) hipStreamDestroy(c->st_copy);
+            for (int k = 0; k < QZD_NBUF + 1; k++) if (c->cp_ev[k]) hipEventDestroy(c->cp_ev[k]);
+        }
+        for (int k = 0; k < 4; k++) if (c->ev[i][k]) hipEventDestroy(c->ev[i][k]);
     }
-    hipEventDestroy(c->ev_begin); hipEventDestroy(c->ev_end);
-    for (int i = 0; i < QZD_K1EV; i++) { hipEventDestroy(c->k1ev[i][0]); hipEventDestroy(c->k1ev[i][1]); }
+    if (c->ev_begin) hipEventDestroy(c->ev_begin);
+    if (c->ev_end) hipEventDestroy(c->ev_end);
+    for (int i = 0; i < QZD_K1EV; i++) { if (c->k1ev[i][0]) hipEventDestroy(c->k1ev[i][0]); if (c->k1ev[i][1]) hipEventDestroy(c->k1ev[i][1]); }
     hipFree(c->k1_tables); hipFree(c->k1_counter);
     hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
     hipHostFree(c->h_running); hipHostFree(c->h_overflow);
@@ -221,9 +230,12 @@ static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
     size_t sym = (size_t)batch * chunk_sz + 256, slot = (size_t)batch * slot_stride_for(chunk_sz);
     if (sym > c->sym_cap || slot > c->slot_cap || batch > c->meta_cap) {
         hipDeviceSynchronize();
+        c->sym_cap = 0; c->slot_cap = 0; c->meta_cap = 0;      /* set again only when every allocation below succeeded */
         for (int i = 0; i < QZD_NBUF; i++) {
             hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
             c->sym_lc[i] = NULL; c->sym_dist[i] = NULL; c->slots[i] = NULL; c->meta[i] = NULL;
+        }
+        for (int i = 0; i < QZD_NBUF; i++) {
             HIPCHK(c, hipMalloc(&c->sym_lc[i], sym));
             HIPCHK(c, hipMalloc(&c->sym_dist[i], sym * 2));
             HIPCHK(c, hipMalloc(&c->slots[i], slot));
@@ -234,7 +246,7 @@ static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
     if (nchunks > c->call_cap) {
         hipDeviceSynchronize();
         hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs);
-        c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL;
+        c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL; c->call_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_len, (size_t)nchunks * 4));
         HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nchunks * 4));
         HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nchunks * 8));
@@ -259,7 +271,6 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     if (need > c->lane_cap) {
         hipDeviceSynchronize();
         if (c->d_lane) hipFree(c->d_lane);
-    if (c->d_cdesc) hipFree(c->d_cdesc);
         c->d_lane = NULL; c->lane_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_lane, need));
         c->lane_cap = need;

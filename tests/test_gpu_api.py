@@ -247,6 +247,69 @@ def test_async_queue_coalesces_small_requests():
     sa.close(); sb.close(); sr.close()
 
 
+@pytest.mark.parametrize("lvl", [2, 3])
+def test_async_coalesced_levels_2_3_regrow_lane_scratch(lvl):
+    """Coalesced qzCompress2 launches at the greedy levels above 1 go through the one-chunk-per-lane path, whose scratch
+    grows with the batch: a fresh session, a small batch, then a larger one that regrows it (the per-slot descriptor
+    buffer of the launch must survive the regrow - ADVICE r1)."""
+    import threading
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536, comp_lvl=lvl)
+    L = s.L
+    for rnd, (count, n) in enumerate(((6, 20000), (40, 150000))):
+        srcs = [datagen.gen_bytes(("silesia", "text", "runs", "records")[i % 4], n + 37 * i, 900 + 50 * rnd + i) for i in range(count)]
+        bin_ = [C.create_string_buffer(x, len(x)) for x in srcs]
+        bout = [C.create_string_buffer(len(x) * 9 // 8 + 4096) for x in srcs]
+        res = [A.QzResult() for _ in srcs]
+        done, got = threading.Event(), []
+
+        def on_done(r):
+            got.append(r.contents.cb_tag)
+            if len(got) == len(srcs):
+                done.set()
+            return 0
+        cb = A.QzAsyncCallback(on_done)
+        for i, x in enumerate(srcs):
+            res[i].cb_tag = i + 1; res[i].src_len = len(x); res[i].dest_len = len(bout[i])
+            assert L.qzCompress2(C.byref(s.s), bin_[i], bout[i], cb, C.byref(res[i])) == A.QZ_OK
+        assert done.wait(300)
+        for i, x in enumerate(srcs):
+            exp = O.sw_compress("GZIP_EXT", x, 65536, lvl, cap=len(x) * 9 // 8 + 65536)[2]
+            assert res[i].status == A.QZ_OK and bout[i].raw[:res[i].dest_len] == exp, (lvl, rnd, i)
+    s.close()
+
+
+def test_async_teardown_from_callback_does_not_deadlock():
+    """a completion callback may tear down a session of its own batch: callbacks run after the whole batch
+    has left the running list"""
+    import threading
+    sa, sb = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536), A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    L = sa.L
+    srcs = [datagen.gen_bytes("text", 30000 + i, 70 + i) for i in range(8)]
+    bin_ = [C.create_string_buffer(x, len(x)) for x in srcs]
+    bout = [C.create_string_buffer(len(x) * 9 // 8 + 4096) for x in srcs]
+    res = [A.QzResult() for _ in srcs]
+    done, n_cb, torn = threading.Event(), [0], [False]
+
+    def on_done(r):
+        n_cb[0] += 1
+        if not torn[0]:
+            torn[0] = True
+            assert L.qzTeardownSession(C.byref(sb.s)) == A.QZ_OK      # sb's requests sit in this very batch
+        if n_cb[0] == len(srcs):
+            done.set()
+        return 0
+    cb = A.QzAsyncCallback(on_done)
+    for i, x in enumerate(srcs):
+        res[i].cb_tag = i + 1; res[i].src_len = len(x); res[i].dest_len = len(bout[i])
+        assert L.qzCompress2(C.byref((sa if i % 2 == 0 else sb).s), bin_[i], bout[i], cb, C.byref(res[i])) == A.QZ_OK
+    assert done.wait(120), "consumer thread deadlocked in a callback"
+    for i, x in enumerate(srcs):
+        if res[i].status == A.QZ_OK:
+            assert zlib.decompress(bout[i].raw[:res[i].dest_len], 31) == x
+    assert sum(1 for r in res if r.status == A.QZ_OK) >= len(srcs) // 2
+    sa.close()
+
+
 def test_crc_known_answer_like_reference_test():
     # test/main.c:4283-4337: qzCompressCrc's crc == zlib crc32(src) for 64 KB and 1023 B
     s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
