@@ -7,8 +7,17 @@ resident in HBM when the timed region starts.  One step = one pass of the hot pa
 compress every call, then decompress every call (the reference harness' "-D both", test/main.c:2204-2299).
 `value` = uncompressed bytes moved in both directions by all ranks / max-over-ranks wall time (the reference
 counts uncompressed bytes for either direction and doubles them for "both", test/main.c:2336-2346).
-Multi-GPU: independent chunks shard across ranks with no data-path collective (weak scaling: every rank
-owns its own buffer); gloo carries the barrier and the max/sum reductions of the timings.
+Multi-GPU: independent chunks shard across ranks with no data-path collective in the timed region (weak scaling:
+every rank owns its own buffer); gloo carries the barrier and the max/sum reductions of the timings.  After the timed
+region the ranks also build ONE gzip-ext member out of one shard each (config 5's shape): the compressed shards travel
+to rank 0's HBM as peer-to-peer copies over xGMI (qzd_shard_*, IPC memory), `config.one_stream` reports it.
+
+Beside the headline the line carries (rank 0, N = 1 only, all outside the timed region):
+  config.api_*          the same work through qatzip.h itself: qzCompress / qzDecompress on qzMalloc(PINNED_MEM) buffers
+  config.raw_sweep      BASELINE config 3: QZ_DEFLATE_RAW, hw_buff_sz 16 / 64 / 128 KB
+  config.lz4            BASELINE config 4: LZ4 frames of 64 KB with XXH32
+  roofline              the dominant kernel against the HBM peak (datasheet) and the copy rate measured on this box
+  cpu_baseline          the software path's port on every physical core of this host, and this host's own libz
 
 Prints ONE JSON line on rank 0.
 """
@@ -16,6 +25,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,6 +37,7 @@ import numpy as np  # noqa: E402
 CHUNK = 65536
 CALL_BYTES = 1 << 31            # one qzCompress-sized call (2 GiB)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+TILE_SKEW = 4099                # the distinct data is tiled with a period that is no multiple of any chunk size
 
 
 def dist_setup():
@@ -51,22 +62,215 @@ def allreduce(pg, v, op):
     return shard.allreduce(pg, v, op)
 
 
-def cpu_baseline(sample: bytes):
-    """The oracle (a port of the reference's SW path) timed on this box's host cores, 1 thread, bounded sample."""
-    import oracle_lib as O
+# ------------------------------------------------------------------ CPU baseline (reported, not the target)
+def host_cpu():
+    """(physical cores this process may use, model name)"""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip(); v = v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif k == "" and phys is not None and core is not None:
+                cores.add((phys, core)); phys = core = None
+    except OSError:
+        pass
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = min(len(cores), allowed) if cores else allowed
+    return max(1, n), model
+
+
+def _run_threads(nthr, fn):
+    """fn(i) on nthr threads (the C calls release the GIL); wall time of the slowest"""
+    out = [None] * nthr
+    start = threading.Barrier(nthr + 1)
+
+    def body(i):
+        start.wait()
+        out[i] = fn(i)
+    th = [threading.Thread(target=body, args=(i,)) for i in range(nthr)]
+    for t in th:
+        t.start()
+    start.wait()
     t0 = time.perf_counter()
-    rc, used, out, _ = O.sw_compress("GZIP_EXT", sample, CHUNK, 1, cap=len(sample) * 9 // 8 + 65536)
-    t1 = time.perf_counter()
-    assert rc == 0 and used == len(sample)
-    rc, cused, back = O.sw_decompress("GZIP_EXT", out, len(sample) + 64)
-    t2 = time.perf_counter()
-    assert rc == 0 and back == sample
-    both = 2 * len(sample) / (t2 - t0) / 1e9
-    return {"value": round(both, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "compress": round(len(sample) / (t1 - t0) / 1e9, 4), "decompress": round(len(sample) / (t2 - t1) / 1e9, 4),
-            "sample": "%d MiB of the same buffer, GZIP_EXT L1 64 KB chunks, compress + decompress, "
-                      "oracle/libqzoracle.so, 1 thread" % (len(sample) >> 20),
-            "ratio": round(len(out) / len(sample), 4)}
+    for t in th:
+        t.join()
+    return time.perf_counter() - t0, out
+
+
+def cpu_baseline(base: np.ndarray, shard_mb: int, max_threads: int):
+    """The oracle (a port of the reference's software path, src/qatzip_sw.c:77-441) on this box's host cores: one thread
+    alone, then one thread per physical core, each on its own contiguous shard of the bench buffer (the method of
+    test/performance_tests/run_perf_test.sh:100-123: N independent workers, rates summed).  Then the same loop over this
+    host's own libz when Python's zlib is linked to one (deflateInit2(1, 8, -15, 9, 0) + Z_FULL_FLUSH per 64 KB)."""
+    import zlib
+    import oracle_lib as O
+    ncores, model = host_cpu()
+    nthr = max(1, min(ncores, max_threads))
+    S = min(shard_mb << 20, len(base)) & ~(CHUNK - 1)
+    span = max(1, len(base) - S)
+    shards = [base[(i * 7919 * CHUNK) % span:][:S].tobytes() for i in range(nthr)]
+
+    def port_both(i):
+        src = shards[i]
+        t0 = time.perf_counter()
+        rc, used, out, _ = O.sw_compress("GZIP_EXT", src, CHUNK, 1, cap=len(src) * 9 // 8 + 65536)
+        t1 = time.perf_counter()
+        rc2, _, back = O.sw_decompress("GZIP_EXT", out, len(src) + 64)
+        t2 = time.perf_counter()
+        assert rc == 0 and used == len(src) and rc2 == 0 and back == src
+        return t1 - t0, t2 - t1, len(out)
+
+    w1, r1 = _run_threads(1, port_both)
+    wall, res = _run_threads(nthr, port_both)
+    tc = max(r[0] for r in res); td = max(r[1] for r in res)
+    total = float(S) * nthr
+
+    def libz_both(i):
+        src = shards[i]
+        t0 = time.perf_counter()
+        co = zlib.compressobj(1, zlib.DEFLATED, -15, 9, 0)
+        parts = []
+        for off in range(0, len(src), CHUNK):
+            last = off + CHUNK >= len(src)
+            parts.append(co.compress(src[off:off + CHUNK]) + co.flush(zlib.Z_FINISH if last else zlib.Z_FULL_FLUSH))
+        comp = b"".join(parts)
+        t1 = time.perf_counter()
+        back = zlib.decompress(comp, -15)
+        t2 = time.perf_counter()
+        assert back == src
+        return t1 - t0, t2 - t1, len(comp)
+
+    libz = None
+    try:
+        lw, lr = _run_threads(nthr, libz_both)
+        lw1, lr1 = _run_threads(1, libz_both)
+        libz = {"zlibVersion": zlib.ZLIB_RUNTIME_VERSION, "value": round(2 * total / lw / 1e9, 4),
+                "compress": round(total / max(r[0] for r in lr) / 1e9, 4), "decompress": round(total / max(r[1] for r in lr) / 1e9, 4),
+                "one_thread": round(2 * S / lw1 / 1e9, 4), "threads": nthr,
+                "note": "raw deflate level 1, memLevel 9, Z_FULL_FLUSH per 64 KB (the loop of src/qatzip_sw.c:178-231) through Python's zlib"}
+    except Exception as e:   # noqa: BLE001 - a host without a usable libz only loses this sub-field
+        libz = {"error": str(e)[:100]}
+    return {"value": round(2 * total / wall / 1e9, 4), "unit": "GB/s", "cores": nthr, "kind": "port",
+            "compress": round(total / tc / 1e9, 4), "decompress": round(total / td / 1e9, 4),
+            "one_thread": {"value": round(2 * S / w1 / 1e9, 4), "compress": round(S / r1[0][0] / 1e9, 4), "decompress": round(S / r1[0][1] / 1e9, 4)},
+            "cpu_model": model, "physical_cores": ncores,
+            "sample": "%d thread(s) x %d MiB contiguous shards of the same buffer, GZIP_EXT L1 64 KB chunks, compress + "
+                      "decompress, oracle/libqzoracle.so (%.1f s of CPU work)" % (nthr, S >> 20, sum(r[0] + r[1] for r in res)),
+            "ratio": round(sum(r[2] for r in res) / total, 4), "host_libz": libz}
+
+
+# ------------------------------------------------------------------ extra legs (outside the timed region)
+def api_leg(base, tile, mb):
+    """qzCompress / qzDecompress themselves, host to host on qzMalloc(PINNED_MEM) buffers: PCIe both ways included"""
+    import ctypes as C
+    from qatzip_amd import api as A
+    n = mb << 20
+    L = A.lib()
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, CHUNK)
+    cap = L.qzMaxCompressedLength(n, C.byref(s.s)) + 64
+    p_src, p_dst, p_back = L.qzMalloc(n, 0, A.PINNED_MEM), L.qzMalloc(cap, 0, A.PINNED_MEM), L.qzMalloc(n + 64, 0, A.PINNED_MEM)
+    assert p_src and p_dst and p_back, "qzMalloc(PINNED_MEM) failed"
+    hsrc = np.ctypeslib.as_array((C.c_ubyte * n).from_address(p_src))
+    for off in range(0, n, tile):
+        k = min(tile, n - off)
+        hsrc[off:off + k] = base[:k]
+    res = {}
+    comp_len = 0
+    for it in range(2):                                            # first pass sizes the session's buffers
+        sl, dl = C.c_uint(n), C.c_uint(cap)
+        t0 = time.perf_counter()
+        rc = L.qzCompress(C.byref(s.s), C.cast(p_src, C.c_char_p), C.byref(sl), p_dst, C.byref(dl), 1)
+        tc = time.perf_counter() - t0
+        assert rc == 0 and sl.value == n, rc
+        comp_len = dl.value
+        sl2, dl2 = C.c_uint(comp_len), C.c_uint(n + 64)
+        t0 = time.perf_counter()
+        rc = L.qzDecompress(C.byref(s.s), C.cast(p_dst, C.c_char_p), C.byref(sl2), p_back, C.byref(dl2))
+        td = time.perf_counter() - t0
+        assert rc == 0 and dl2.value == n, rc
+    back = np.ctypeslib.as_array((C.c_ubyte * n).from_address(p_back))
+    assert np.array_equal(back[:1 << 20], hsrc[:1 << 20]) and np.array_equal(back[-(1 << 20):], hsrc[-(1 << 20):])
+    res = {"api_bytes_MiB": mb, "api_compress_GBps": round(n / tc / 1e9, 3), "api_decompress_GBps": round(n / td / 1e9, 3),
+           "api_pinned": int(L.qzMemFindAddr(p_src + 12345)), "api_note": "one qzCompress + one qzDecompress call, host to host, "
+           "qzMalloc(PINNED_MEM) source and destination, PCIe included"}
+    for p in (p_src, p_dst, p_back):
+        L.qzFree(p)
+    s.close()
+    return res
+
+
+def raw_sweep(ctx, qz, d_src, mb):
+    """BASELINE config 3: raw deflate + raw inflate, hw_buff_sz 16 / 64 / 128 KB, data resident in HBM"""
+    n = mb << 20
+    out = {}
+    d_c = ctx.alloc(qz.max_deflate_len(n, 16384))
+    d_b = ctx.alloc(n + 4096)
+    for hw in (16384, 65536, 131072):
+        best_c = best_d = None
+        for _ in range(2):
+            ctx.sync(); t0 = time.perf_counter()
+            ctx.deflate_raw_async(view(qz, d_src, 0, n), n, hw, 1, 1, d_c); ctx.sync()
+            t1 = time.perf_counter()
+            cl = ctx.result()
+            t2 = time.perf_counter()
+            iu, ol, _ = ctx.inflate_stream(d_c, cl, d_b, hw, want_crc=False)
+            t3 = time.perf_counter()
+            assert iu == cl and ol == n
+            best_c = min(best_c or 1e9, t1 - t0); best_d = min(best_d or 1e9, t3 - t2)
+        k1 = ctx.timing()
+        out["%dK" % (hw >> 10)] = {"compress_GBps": round(n / best_c / 1e9, 2), "decompress_GBps": round(n / best_d / 1e9, 2),
+                                   "ratio": round(cl / n, 4), "lz77_ms_first_batch": round(k1[0], 2)}
+    assert ctx.crc32(d_b, n) == ctx.crc32(view(qz, d_src, 0, n), n)
+    d_c.free(); d_b.free()
+    out["bytes_MiB"] = mb
+    return out
+
+
+def lz4_leg(ctx, qz, d_src, mb):
+    """BASELINE config 4: one LZ4 frame (one 64 KB block, content size + XXH32) per 64 KB, compress then decompress"""
+    n = mb << 20
+    nfr = n // CHUNK
+    d_c = ctx.alloc(n + nfr * 64 + 4096)
+    d_b = ctx.alloc(n + 4096)
+    best_c = best_d = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        cl, lens = ctx.lz4_compress_frames(view(qz, d_src, 0, n), n, d_c, CHUNK)
+        t1 = time.perf_counter()
+        offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
+        segs = np.zeros(nfr, qz._lib.LZ4SEG_DT)
+        segs["in_off"] = offs; segs["out_off"] = np.arange(nfr, dtype=np.int64) * CHUNK; segs["in_len"] = lens; segs["out_cap"] = CHUNK
+        res = np.zeros(nfr, qz._lib.LZ4RES_DT)
+        t2 = time.perf_counter()
+        ctx._chk(ctx.L.qzd_lz4_decompress_frames(ctx.h, d_c.ptr, d_b.ptr, segs.ctypes.data, nfr, res.ctypes.data))
+        t3 = time.perf_counter()
+        assert (res["status"] == 0).all() and (res["out_len"] == CHUNK).all()
+        best_c = min(best_c or 1e9, t1 - t0); best_d = min(best_d or 1e9, t3 - t2)
+    assert ctx.crc32(d_b, n) == ctx.crc32(view(qz, d_src, 0, n), n)
+    d_c.free(); d_b.free()
+    return {"bytes_MiB": mb, "compress_GBps": round(n / best_c / 1e9, 2), "decompress_GBps": round(n / best_d / 1e9, 2),
+            "ratio": round(cl / n, 4), "note": "64 KB frames, XXH32 content checksum made and verified in-kernel, host call to host return"}
+
+
+def view(qz, buf, off, n):
+    v = qz.DevBuf.__new__(qz.DevBuf)
+    v.ctx, v.nbytes, v.ptr = buf.ctx, n, buf.ptr + off
+    return v
+
+
+def one_stream_leg(ctx, qz, pg, rank, world, d_src, shard_mb):
+    """config 5's shape: every rank deflates ONE shard of a logical buffer, the compressed shards travel to rank 0's HBM
+    as peer copies (xGMI between GPUs), rank 0 folds the CRCs and closes the gzip-ext member (qzd_shard_*)."""
+    from qatzip_amd import shard
+    n = shard_mb << 20
+    return shard.one_stream(ctx, pg, rank, world, view(qz, d_src, 0, n), n, CHUNK)
 
 
 def main():
@@ -76,8 +280,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mb", type=int, default=4096, help="buffer size per GPU in MiB (default: the 4 GB config)")
     ap.add_argument("--base-mb", type=int, default=128, help="distinct synthetic data generated per GPU (tiled)")
-    ap.add_argument("--cpu-mb", type=int, default=8, help="sample size for the CPU baseline")
+    ap.add_argument("--cpu-mb", type=int, default=16, help="CPU baseline: shard size per thread, MiB")
+    ap.add_argument("--cpu-threads", type=int, default=256, help="CPU baseline: at most this many threads")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the API / RAW sweep / LZ4 / one-stream legs")
+    ap.add_argument("--extra-mb", type=int, default=1024, help="bytes of the extra legs, MiB")
     args = ap.parse_args()
 
     rank, world, local, pg = dist_setup()
@@ -91,23 +298,21 @@ def main():
     base_n = min(args.base_mb << 20, total)
     base = datagen.gen("silesia", base_n, 20250523 + rank)
     d_src = ctx.alloc(total)
-    for off in range(0, total, base_n):       # tile: chunks are independent, nothing is shared across tiles
-        d_src.upload(base[:min(base_n, total - off)], off)
+    # tile with a period that is not a multiple of the chunk size: every copy of the distinct data is cut into chunks at
+    # different places, so no two chunks of the buffer are equal (and the decoder cannot profit from duplicates)
+    tile = base_n - TILE_SKEW if total > base_n else base_n
+    for off in range(0, total, tile):
+        d_src.upload(base[:min(tile, total - off)], off)
     ncalls = (total + CALL_BYTES - 1) // CALL_BYTES
     call_n = [min(CALL_BYTES, total - i * CALL_BYTES) for i in range(ncalls)]
     d_comp = [ctx.alloc(qatzip_amd.max_deflate_len(n, CHUNK)) for n in call_n]
     d_back = ctx.alloc(max(call_n))
 
-    def view(buf, off, n):
-        v = qatzip_amd.DevBuf.__new__(qatzip_amd.DevBuf)
-        v.ctx, v.nbytes, v.ptr = buf.ctx, n, buf.ptr + off
-        return v
-
     comp_len = [0] * ncalls
 
     def compress_all():
         for i, n in enumerate(call_n):
-            ctx.deflate_raw_async(view(d_src, i * CALL_BYTES, n), n, CHUNK, 1, 1, d_comp[i])
+            ctx.deflate_raw_async(view(qatzip_amd, d_src, i * CALL_BYTES, n), n, CHUNK, 1, 1, d_comp[i])
             ctx.sync()
             comp_len[i] = ctx.result()
 
@@ -123,7 +328,7 @@ def main():
     for _ in range(args.warmup):
         step()
     # parity guard outside the timed region: what came back is what went in
-    assert ctx.crc32(d_back, call_n[-1]) == ctx.crc32(view(d_src, (ncalls - 1) * CALL_BYTES, call_n[-1]), call_n[-1])
+    assert ctx.crc32(d_back, call_n[-1]) == ctx.crc32(view(qatzip_amd, d_src, (ncalls - 1) * CALL_BYTES, call_n[-1]), call_n[-1])
 
     ctx.k1_stats(reset=True)
     barrier(pg); ctx.sync()
@@ -139,22 +344,41 @@ def main():
     ctx.sync(); t1 = time.perf_counter(); compress_all(); ctx.sync(); tc = time.perf_counter() - t1
     t1 = time.perf_counter(); decompress_all(); ctx.sync(); td = time.perf_counter() - t1
     inf_ms = ctx.inflate_timing()
-    batch_chunks = ctx.batch_chunks()         # chunks per full K1 launch (three rounds over the resident workgroups)
+    batch_chunks = ctx.batch_chunks()         # chunks per full K1 launch (three rounds over the resident waves)
     probe_n = min(batch_chunks * CHUNK, call_n[0])
-    ctx.deflate_raw_async(view(d_src, 0, probe_n), probe_n, CHUNK, 1, 1, d_comp[0]); ctx.sync()
+    ctx.deflate_raw_async(view(qatzip_amd, d_src, 0, probe_n), probe_n, CHUNK, 1, 1, d_comp[0]); ctx.sync()
     k_ms = ctx.timing()                      # single batch => K1 ran alone on the chip
     comp_total = allreduce(pg, float(sum(comp_len)), "SUM")
     raw_total = float(total) * world
     tc = allreduce(pg, tc, "MAX"); td = allreduce(pg, td, "MAX")
 
+    extra = {}
+    one = None
+    if not args.no_extra:
+        if world > 1:
+            try:
+                one = one_stream_leg(ctx, qatzip_amd, pg, rank, world, d_src, min(256, args.mb))
+            except Exception as e:   # noqa: BLE001 - the headline must survive a box without peer access
+                one = {"error": str(e)[:200]}
+            barrier(pg)
+        elif rank == 0:
+            emb = min(args.extra_mb, args.mb)
+            for d in d_comp:
+                d.free()
+            d_back.free()
+            extra["hbm_copy_GBps"] = round(ctx.stream_copy_peak(1 << 30, 3), 1)
+            extra["raw_sweep"] = raw_sweep(ctx, qatzip_amd, d_src, emb)
+            extra["lz4"] = lz4_leg(ctx, qatzip_amd, d_src, emb)
+            extra.update(api_leg(base, tile, emb))
+
     if rank == 0:
         # HBM traffic per K1 launch: PMC counters cannot be read from inside this process; they come from the committed
-        # rocprofv3 --pmc passes of this same command (profiles/r1_pmc.json, tools/pmc_summary.py): FETCH_SIZE and
+        # rocprofv3 --pmc passes of this same command (profiles/r2_pmc.json, tools/pmc_summary.py): FETCH_SIZE and
         # WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note; quoted only when the
-        # profiled command had the same launch mix (same --mb).
+        # profiled command had the same launch mix (same --mb, same chunks per launch) - null otherwise, never stale.
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r2_pmc.json")) as f:
                 pj = json.load(f)
             pk = pj["kernels"].get(pj.get("k1_key", ""))
             if pk and pj.get("bench_mb") == args.mb and pj.get("k1_launch_chunks") == batch_chunks:
@@ -169,30 +393,36 @@ def main():
         alg_bytes = alg_total / max(k1_launches, 1)
         launch_ms = k1_ms / max(k1_launches, 1)
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        copy_peak = extra.get("hbm_copy_GBps")
         res = {
             "metric": "compress + decompress GB/s (input bytes), QZ_DEFLATE_GZIP_EXT L1, 64 KB chunks",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "QZ_DEFLATE_GZIP_EXT level 1, 64 KB chunks, %d MiB Silesia-like buffer per GPU "
-                                   "(%d MiB distinct, tiled), %d call(s) of <= 2 GiB, compress then decompress" %
-                                   (args.mb, base_n >> 20, ncalls),
+                                   "(%d MiB distinct, tiled with period %d B so that no two chunks are equal), %d call(s) of "
+                                   "<= 2 GiB, compress then decompress" % (args.mb, base_n >> 20, tile, ncalls),
                        "chunk": CHUNK, "ratio": round(ratio, 4), "parallelism": "chunks sharded over %d rank(s), "
-                       "no data-path collective" % world,
+                       "no data-path collective in the timed region" % world,
                        "compress_GBps": round(raw_total / tc / 1e9, 3), "decompress_GBps": round(raw_total / td / 1e9, 3)},
             "roofline": {"bound": "hbm", "kernel": "qzk_lz77_pull_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
+                         "peak_measured_copy": copy_peak,
+                         "frac_of_measured_copy": round(achieved / copy_peak, 6) if copy_peak else None,
                          "launch_ms": round(launch_ms, 3), "launches": int(k1_launches),
                          "chunks_per_launch": round(k1_chunks / max(k1_launches, 1), 1),
                          "full_launch_alone_ms": round(k_ms[0], 3), "full_launch_chunks": probe_n // CHUNK,
                          "other_kernels_ms": {"qzk_huff_kernel": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
-                                              "qzk_inflate_tok_kernel+qzk_lz_resolve_kernel(last call)": round(inf_ms[0], 3),
+                                              "inflate kernels (last call)": round(inf_ms[0], 3),
                                               "of which qzk_lz_resolve_kernel": round(inf_ms[2], 3),
                                               "qzk_crc_kernel(last call)": round(inf_ms[1], 3)}},
         }
-        if not args.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(base[:args.cpu_mb << 20].tobytes())
+        res["config"].update(extra)
+        if one is not None:
+            res["config"]["one_stream"] = one
+        if not args.no_cpu and world == 1:
+            res["cpu_baseline"] = cpu_baseline(base, args.cpu_mb, args.cpu_threads)
         print(json.dumps(res))
     if pg is not None:
         pg.destroy_process_group()

@@ -43,6 +43,10 @@ uint32_t qzd_batch_chunks(qzd_ctx *ctx);
  * since the last reset; harvested whenever qzd_sync() completes a compress call */
 int qzd_k1_stats(qzd_ctx *ctx, double *ms, uint64_t *launches, uint64_t *chunks, int reset);
 
+/* measured stream-copy rate of the device, read + written decimal GB per second (a hand-written 16-byte-per-lane copy
+ * kernel over two buffers of `bytes` each, best of `iters`): the yardstick beside the 8 TB/s datasheet figure */
+int qzd_stream_copy_peak(qzd_ctx *ctx, uint64_t bytes, int iters, double *gbps);
+
 /* plain HBM / pinned-host memory helpers (replace qaeMemAllocNUMA, src/qatzip_mem.c:169-224) */
 void *qzd_dev_alloc(qzd_ctx *ctx, size_t n);
 void qzd_dev_free(qzd_ctx *ctx, void *d_p);

@@ -21,7 +21,7 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    so = _build.SO
+    so = os.environ.get("QATZIP_AMD_SO") or _build.SO      # developer switch: a variant build of the same library
     if not os.path.exists(so):
         if not build_if_missing:
             raise QzdError("libqatzip_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
@@ -34,6 +34,7 @@ def load(build_if_missing=True):
     L.qzd_last_error.argtypes = [vp]; L.qzd_last_error.restype = C.c_char_p
     L.qzd_batch_chunks.argtypes = [vp]; L.qzd_batch_chunks.restype = C.c_uint32
     L.qzd_k1_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
+    L.qzd_stream_copy_peak.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.qzd_dev_alloc.argtypes = [vp, C.c_size_t]; L.qzd_dev_alloc.restype = vp
     L.qzd_dev_free.argtypes = [vp, vp]
     L.qzd_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -71,7 +72,8 @@ def exported_symbols():
             "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing", "qzd_inflate_segments",
             "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing",
             "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats",
-            "qzd_adler32_chunks", "qzd_adler32_combine"]
+            "qzd_adler32_chunks", "qzd_adler32_combine", "qzd_stream_copy_peak", "qzd_deflate_raw_from_host",
+            "qzd_deflate_slots", "qzd_inflate_stream_to_host", "qzamd_async_stats"]
 
 
 class DevBuf:
@@ -149,6 +151,12 @@ class Context:
         out_len = C.c_uint64(0)
         self._chk(self.L.qzd_result(self.h, C.byref(out_len), None, 0))
         return out_len.value
+
+    def stream_copy_peak(self, nbytes=1 << 30, iters=3):
+        """measured HBM stream-copy rate, GB/s of read + written bytes"""
+        g = C.c_double(0)
+        self._chk(self.L.qzd_stream_copy_peak(self.h, nbytes, iters, C.byref(g)))
+        return g.value
 
     def batch_chunks(self):
         return int(self.L.qzd_batch_chunks(self.h))

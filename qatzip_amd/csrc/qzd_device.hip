@@ -4,7 +4,8 @@
  *
  * A call is cut into batches of qzd_ctx::batch_chunks chunks (three rounds over the resident K1 workgroups).
  * Per batch, on one of two streams:
- *   K1 qzk_lz77_pull_kernel  (persistent single-wave workgroups, 16 per CU, each with its 512 KiB candidate table)
+ *   K1 qzk_lz77_pull_kernel  (persistent 16-wave workgroups, one per CU, every wave pulling chunks; the waves of a
+ *                             workgroup share the lines of one epoch-tagged candidate table)
  *   K2 qzk_huff_kernel       (one wave per chunk) -> per-chunk slot + length;  qzk_crc_chunks_kernel -> crc32
  *   scan of the lengths (running total carried in HBM, no host round trip)
  *   gather of the slots into the contiguous destination
@@ -64,6 +65,13 @@ __global__ void qzk_gather_kernel(const uint8_t *slots, uint32_t stride, const u
     for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x)
         ((qz_u32u *)d)[i].v = ((const uint32_t *)s)[i];
     for (uint32_t i = (nw << 2) + threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+}
+
+/* plain streaming copy, 16 bytes per lane and trip: the yardstick the roofline fractions are quoted against */
+__global__ void __launch_bounds__(256) qzk_copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
 }
 
 /* ------------------------------------------------------------------ context (qzd_internal.h) */
@@ -134,8 +142,8 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
     c->so_host = NULL; c->so_nat = NULL; c->so_sent = 0;
     for (int i = 0; i < QZD_K1EV; i++) { hipEventCreate(&c->k1ev[i][0]); hipEventCreate(&c->k1ev[i][1]); }
     {
-        /* K1 residency (measured): QZD_K1_WGS_PER_CU persistent single-wave workgroups per CU, each with
-         * its own 512 KiB candidate table.  QATZIP_AMD_K1_WGS=<n> overrides the total. */
+        /* K1 residency (measured): QZD_K1_WGS_PER_CU pulling waves per CU (one workgroup), each with its
+         * column of the workgroup's candidate table.  QATZIP_AMD_K1_WGS=<n> overrides the total number of waves. */
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) QZD_CREATE_FAIL;
         const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
@@ -144,10 +152,10 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         unsigned a = 0;
         if (e && sscanf(e, "%u", &a) == 1 && a > 0 && a <= 65536) c->k1_wgs = a;
         c->batch_chunks = QZD_BATCH_ROUNDS * c->k1_wgs;
-        /* the tables (512 KiB per workgroup, 2 GiB for a full device) are allocated by the first call that needs them and
+        /* the tables (16 MiB per workgroup, 4 GiB for a full device) are allocated by the first call that needs them and
          * only as many as its chunks can occupy: a session that decompresses, or only ever sees small calls, holds none
          * or few */
-        c->k1_tables = NULL; c->k1_tab_wgs = 0;
+        c->k1_tables = NULL; c->k1_tab_wgs = 0; c->k1_epoch = 1;
         if (hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) QZD_CREATE_FAIL;
     }
     if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) QZD_CREATE_FAIL;
@@ -188,6 +196,33 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     if (c->d_lane) hipFree(c->d_lane);
     if (c->d_cdesc) hipFree(c->d_cdesc);
     delete c;
+}
+
+/* measured HBM stream-copy rate of this device (read + written bytes per second, decimal GB): `bytes` per buffer (take
+ * it well above the 256 MiB Infinity Cache), best of `iters` passes */
+extern "C" int qzd_stream_copy_peak(qzd_ctx *c, uint64_t bytes, int iters, double *gbps)
+{
+    if (!c || !gbps || bytes < (1u << 20) || iters < 1) return QZD_ERR_PARAM;
+    hipSetDevice(c->device);
+    uint4 *a = NULL, *b = NULL;
+    if (hipMalloc(&a, bytes) != hipSuccess) return QZD_ERR_HIP;
+    if (hipMalloc(&b, bytes) != hipSuccess) { hipFree(a); return QZD_ERR_HIP; }
+    hipMemsetAsync(a, 0x5a, bytes, c->st[0]);
+    const size_t n16 = bytes / 16;
+    float best = 0;
+    for (int it = 0; it < iters + 1; it++) {                    /* pass 0 warms up */
+        hipEventRecord(c->ev_begin, c->st[0]);
+        hipLaunchKernelGGL(qzk_copy16_kernel, dim3(256 * 16), dim3(256), 0, c->st[0], a, b, n16);
+        hipEventRecord(c->ev_end, c->st[0]);
+        hipStreamSynchronize(c->st[0]);
+        float t = 0;
+        if (hipEventElapsedTime(&t, c->ev_begin, c->ev_end) != hipSuccess) t = 0;
+        if (it > 0 && t > 0 && (best == 0 || t < best)) best = t;
+    }
+    hipFree(a); hipFree(b);
+    if (best <= 0) return QZD_ERR_HIP;
+    *gbps = 2.0 * (double)bytes / (best * 1e-3) / 1e9;
+    return QZD_OK;
 }
 
 extern "C" uint32_t qzd_batch_chunks(qzd_ctx *c) { return c ? c->batch_chunks : 0; }
@@ -347,15 +382,27 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
     }
     int rc = ensure_scratch(c, chunk_sz, nchunks);
     if (rc) return rc;
+    const uint32_t max_wgs = (c->k1_wgs + QZK_K1_WAVES - 1) / QZK_K1_WAVES;      /* workgroups of a full launch (one per CU) */
     {
-        const uint32_t want = nchunks < c->k1_wgs ? nchunks : c->k1_wgs;
+        /* a launch of few chunks spreads them over workgroups (CUs) before it stacks them on the waves of one */
+        const uint32_t want = nchunks < max_wgs ? nchunks : max_wgs;
         if (want > c->k1_tab_wgs) {
             hipDeviceSynchronize();
             if (c->k1_tables) hipFree(c->k1_tables);
             c->k1_tables = NULL; c->k1_tab_wgs = 0;
-            const uint32_t get = want > c->k1_wgs / 4 ? c->k1_wgs : want;     /* a big call: take the whole set at once */
-            HIPCHK(c, hipMalloc(&c->k1_tables, (size_t)get * QZK_HSIZE * 8));
+            const uint32_t get = want > max_wgs / 4 ? max_wgs : want;     /* a big call: take the whole set at once */
+            const size_t tb = (size_t)get * QZK_HSIZE * QZK_K1_WAVES * sizeof(qzk_bkt);
+            HIPCHK(c, hipMalloc(&c->k1_tables, tb));
+            HIPCHK(c, hipMemset(c->k1_tables, 0, tb));                    /* epoch 0 = never valid */
+            HIPCHK(c, hipDeviceSynchronize());                            /* hipMemset of device memory returns early, and the
+                                                                           * (non-blocking) work streams do not wait for it */
             c->k1_tab_wgs = get;
+        }
+        if ((uint64_t)c->k1_epoch + nchunks + 1 >= 0xffffffffull) {        /* epochs wrapped: forget everything once */
+            hipDeviceSynchronize();
+            HIPCHK(c, hipMemset(c->k1_tables, 0, (size_t)c->k1_tab_wgs * QZK_HSIZE * QZK_K1_WAVES * sizeof(qzk_bkt)));
+            HIPCHK(c, hipDeviceSynchronize());
+            c->k1_epoch = 1;
         }
     }
     const uint32_t stride = slot_stride_for(chunk_sz);
@@ -373,6 +420,7 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
     /* with the input still on the host the first batch is one round of the persistent workgroups instead of three:
      * nothing can overlap its copy, so it is kept short */
     const uint32_t FIRST = h_src && nchunks > BATCH ? std::max<uint32_t>(c->k1_wgs, 1024u) : BATCH;
+    const uint32_t tab_wgs = c->k1_tab_wgs;
     if (FIRST != BATCH) c->nbatches = 1 + (nchunks - FIRST + BATCH - 1) / BATCH;
     for (uint32_t b = 0, k = 0, bnext = 0; b < nchunks; b = bnext, k++) {
         const int s = (int)(k % QZD_NBUF), so = (int)((k + 1) % QZD_NBUF);
@@ -399,12 +447,17 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
         /* the K1 workgroups of consecutive batches share the per-workgroup tables, so K1 of batch k starts when K1 of
          * batch k-1 is done; what overlaps with it is K2/scan/gather of batch k-1 */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->k1done[so], 0));
-        const uint32_t wgs = bn < c->k1_wgs ? bn : c->k1_wgs;
+        /* workgroups: one per CU at most (and per table); waves per workgroup: as many as it takes to give every chunk of
+         * a round its own wave - a small launch keeps one chunk per CU */
+        const uint32_t wgs = bn < tab_wgs ? bn : tab_wgs;
+        const uint32_t wpw = std::min<uint32_t>((uint32_t)QZK_K1_WAVES, std::min<uint32_t>((bn + wgs - 1) / wgs, (c->k1_wgs + wgs - 1) / wgs));
         HIPCHK(c, hipMemsetAsync(c->k1_counter + s, 0, 4, st));
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
         if (k < QZD_K1EV) HIPCHK(c, hipEventRecord(c->k1ev[k][0], st));
-        hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64), 0, st, d_src + boff, blen, chunk_sz, bn,
-                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_tables, c->k1_counter + s, cdesc ? cdesc + b : NULL);
+        hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64 * wpw), 0, st, d_src + boff, blen, chunk_sz, bn,
+                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
+                           c->k1_epoch);
+        c->k1_epoch += bn;
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));

@@ -12,7 +12,7 @@
 #define QZD_BATCH_ROUNDS 3u
 #define QZD_NBUF 2
 #define QZD_K1EV 64                  /* K1 launches per call that get their own pair of timing events */
-#define QZD_K1_WGS_PER_CU 16u
+#define QZD_K1_WGS_PER_CU ((uint32_t)(QZK_K1_WAVES * QZK_K1_OCC))   /* pulling waves per CU */
 
 struct qzd_ctx {
     int device;
@@ -22,10 +22,12 @@ struct qzd_ctx {
     /* scratch per buffer set */
     uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];
     qzk_lzmeta *meta[QZD_NBUF];
-    /* K1 (persistent pull kernel): one 512 KiB candidate table per resident workgroup, one chunk counter per buffer set */
-    uint64_t *k1_tables; uint32_t *k1_counter;
-    uint32_t k1_tab_wgs;                            /* workgroups k1_tables has room for (grown on demand up to k1_wgs) */
-    uint32_t k1_wgs;
+    /* K1 (persistent pull kernel): one candidate table (65536 x QZK_K1_WAVES entries of 16 bytes = 16 MiB) per resident
+     * workgroup, one chunk counter per buffer set */
+    qzk_bkt *k1_tables; uint32_t *k1_counter;
+    uint32_t k1_tab_wgs;                            /* workgroups k1_tables has room for (grown on demand) */
+    uint32_t k1_wgs;                                /* resident pulling WAVES (QZK_K1_WAVES per workgroup, one workgroup per CU) */
+    uint32_t k1_epoch;                              /* next unused chunk epoch (entries of the tables are tagged with it; never 0) */
     uint32_t batch_chunks;
     /* K1 launch durations (HIP events around every K1 launch, harvested at qzd_sync): bench.py's roofline input */
     hipEvent_t k1ev[QZD_K1EV][2]; uint32_t k1ev_chunks[QZD_K1EV]; uint32_t k1ev_n;

@@ -16,9 +16,14 @@
  *     to parse point with v_readlane, and only lanes whose hash bucket was also
  *     touched earlier in the same window take a slower exact path.
  *   - zlib's head[] + prev[] chains are kept as one table: per 16-bit hash the four
- *     newest inserted window positions (level 1 never follows more than four links),
- *     4 x u16 in HBM/L2 - one 8-byte gather and one scatter per window, no dependent
- *     chain reads; 512 KiB per resident workgroup (16 of them per CU).
+ *     newest inserted positions (level 1 never follows more than four links) - one
+ *     16-byte gather and one scatter per window, no dependent chain reads.  An entry is
+ *     4 x 24-bit chunk offsets + a 32-bit epoch (the chunk's number): a new chunk needs
+ *     no clear and zlib's window slide no pass over the table.  The sixteen waves of a
+ *     workgroup (one chunk each) share table LINES - bucket h of wave w sits next to
+ *     bucket h of wave w+1 - so the buckets every chunk of a corpus keeps hitting (its
+ *     common trigrams) are a few thousand fully used lines that stay in L2, instead of
+ *     sixteen times as many lines with one live entry each.
  *   - LDS (8 KiB) holds a 4 KiB ring of the most recent input, from which the lanes'
  *     own bytes and three quarters of the candidates are compared, and the per-window
  *     slot tables; far candidates are gathered from HBM/L2.
@@ -39,9 +44,42 @@
 #define QZK_NICE 8
 #define QZK_MAXINS 4
 #define QZK_HSIZE 65536            /* zlib hash_bits 16 at memLevel 9 */
+#ifndef QZK_NSLOT
 #define QZK_NSLOT 512
-#define QZK_RING 4096              /* bytes of recent input kept in LDS by the prev-in-HBM variant */
+#endif
+#ifndef QZK_RING
+#define QZK_RING 4096              /* bytes of recent input kept in LDS */
+#endif
+#ifndef QZK_K1_OCC
+#define QZK_K1_OCC 1               /* workgroups per CU the register budget is cut for */
+#endif
 #define QZK_RINGW (QZK_RING / 4)
+#ifndef QZK_K1_WAVES
+#define QZK_K1_WAVES 16            /* waves per K1 workgroup, one chunk each; they share the lines of the candidate table */
+#endif
+
+/* one bucket of the candidate table: the four newest inserted positions with this hash, newest first, as 24-bit chunk
+ * offsets (0 = none: offset 0 is zlib's NIL), valid only while ep equals the epoch of the chunk being parsed */
+typedef struct __attribute__((aligned(16))) { uint32_t w0, w1, w2, ep; } qzk_bkt;
+/* moved as ONE 16-byte access (a struct load lets the compiler fetch ep first and the rest behind a branch: two dependent
+ * round trips to HBM) */
+typedef uint32_t qzk_u32x4 __attribute__((vector_size(16)));
+
+/* The gather of a table entry is served by the L2 (agent-scope `sc1` load), never by this CU's vector L1: the sixteen
+ * waves of a workgroup keep their entries of one bucket in one cache line, and the L1 (write-through, no write-allocate,
+ * not coherent) may be filled with a copy of that line that is already missing a neighbour wave's latest store - which
+ * that wave would then read back as its own entry (seen on gfx950 as soon as two waves shared lines).  The L2 is the
+ * single home of the line within the XCD, and a wave's loads follow its own stores to it in issue order. */
+QZ_DEV qzk_u32x4 qzk_ld_bkt(const qzk_bkt *p)
+{
+#if defined(QZ_SIM) || defined(QZK_PLAIN_LD)
+    return *(const qzk_u32x4 *)p;
+#else
+    qzk_u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+#endif
+}
 
 #if defined(QZK_PROF) && !defined(QZ_SIM)
 #define QZK_T(k) do { uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; } while (0)
@@ -111,19 +149,21 @@ QZ_DEV int qzk_wave_matchlen(const uint8_t *src, uint64_t src_len, uint64_t a, u
 }
 
 /* One chunk, one wave.  zlib's head[] + prev[] chains (level 1 never follows more than four links) are kept as ONE
- * table: bkt[hash] = the four most recent inserted window positions with that 16-bit hash, newest first, 4 x u16
- * (0 = NIL) - exactly the candidates longest_match() would visit, in its order.  A lookup is a single 8-byte gather
- * instead of a gather plus up to three dependent ones; an insert shifts the entry.  512 KiB per resident workgroup,
- * in HBM/L2; LDS holds a ring of the most recent input and the per-window slot tables (8 KiB). */
+ * table: bkt[hash] = the four most recent inserted positions with that 16-bit hash, newest first - exactly the
+ * candidates longest_match() would visit, in its order.  A lookup is a single 16-byte gather instead of a gather plus up
+ * to three dependent ones; an insert shifts the entry.  tab points at this wave's column of its workgroup's table (entry
+ * h at tab[h * QZK_K1_WAVES]); LDS holds, per wave, a ring of the most recent input and the per-window slot tables. */
 QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t chunk,
-                           uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint64_t *bkt, const uint32_t *cdesc)
+                           uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tab, uint32_t epoch,
+                           const uint32_t *cdesc, int wv)
 {
-    QZ_LDS uint32_t slot[QZK_NSLOT];       /* per-window: min(lane<<16 | hash) over the lanes on a hash key */
-    QZ_LDS uint32_t scnt[QZK_NSLOT];       /* per-window: number of lanes on the key */
+    QZ_LDS uint32_t slot_all[QZK_K1_WAVES][QZK_NSLOT];    /* per-window: min(lane<<16 | hash) over the lanes on a hash key */
+    QZ_LDS uint32_t scnt_all[QZK_K1_WAVES][QZK_NSLOT];    /* per-window: number of lanes on the key */
     /* the last QZK_RING bytes of input (and ~100 ahead of the parse point) sit in LDS.  Every candidate compare
      * drags a 128-byte line through L2 for 16 bytes, three quarters of them less than 4 KiB back; with a dozen
      * waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
-    QZ_LDS uint32_t ring[QZK_RINGW];
+    QZ_LDS uint32_t ring_all[QZK_K1_WAVES][QZK_RINGW];
+    uint32_t *const slot = slot_all[wv], *const scnt = scnt_all[wv], *const ring = ring_all[wv];
     uint32_t rhi = 0;                      /* chunk offset the ring is filled up to (multiple of 256) */
 #define QZK_RING16(dst, ca) do { const uint32_t r_ = (ca) & (QZK_RING - 1), i_ = r_ >> 2, s_ = r_ & 3; \
         const uint32_t d0_ = ring[i_ & (QZK_RINGW - 1)], d1_ = ring[(i_ + 1) & (QZK_RINGW - 1)], d2_ = ring[(i_ + 2) & (QZK_RINGW - 1)], \
@@ -138,14 +178,9 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     uint16_t *odist = sym_dist + coff;
     qzk_lzmeta *mt = meta + chunk;
 
-    /* every entry NIL; one gather + one scatter of the table per window */
-    qz_wave_sync();
-    {   /* 16 bytes per lane and store: the clear is a fifth of the kernel's store instructions otherwise */
-        typedef struct __attribute__((aligned(16))) { uint64_t a, b; } qz_u128;
-        const qz_u128 z = {0, 0};
-        for (int i = lane; i < QZK_HSIZE / 2; i += 64) ((qz_u128 *)bkt)[i] = z;
-    }
-    qz_wave_sync();
+    /* nothing to clear: the entries of earlier chunks carry other epochs.  (All cross-lane ordering in here is
+     * wave-local - the waves of a workgroup never exchange anything - so the syncs are wavefront-scope: no vmcnt(0).) */
+    qz_lds_sync();
 
     uint32_t base = 0;                              /* chunk offset of window position 0 */
     uint32_t fill = n < 65536u ? n : 65536u;        /* chunk offset one past the data zlib has in its window */
@@ -162,18 +197,9 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         uint32_t look = fill - pos;
         if (look < QZK_MINLOOK) {
             if (pos - base >= (uint32_t)(QZK_WSIZE + QZK_MAXDIST)) {
+                /* zlib slide_hash(): positions at or below the new origin become NIL - here by the `> base` test of the
+                 * lookup (offsets are chunk-absolute), no pass over the table */
                 base += QZK_WSIZE;
-                qz_wave_sync();
-                for (int i = lane; i < QZK_HSIZE; i += 64) {       /* zlib slide_hash(): positions below the new origin become NIL */
-                    const uint64_t v = bkt[i];
-                    uint64_t r = 0;
-                    for (int f = 0; f < 4; f++) {
-                        const uint32_t q = (uint32_t)(v >> (16 * f)) & 0xffff;
-                        r |= (uint64_t)(q >= QZK_WSIZE ? q - QZK_WSIZE : 0) << (16 * f);
-                    }
-                    bkt[i] = r;
-                }
-                qz_wave_sync();
             }
             if (avail_in) {
                 uint32_t more = 65536u - (fill - base);
@@ -214,33 +240,41 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         const uint32_t key = h & (QZK_NSLOT - 1);
 
         QZK_T(1);
-        /* candidates as of the window start: one 8-byte gather; first candidate needs dist <= MAX_DIST, chained ones
+        /* candidates as of the window start: one 16-byte gather; first candidate needs dist <= MAX_DIST, chained ones
          * cur_match > limit (zlib's asymmetry), and the chain ends at the first one that fails */
-        /* the previous window's table stores must have landed before this gather (same wave, same CU) */
-        qz_wave_sync();
-        const uint64_t e0 = canh ? bkt[bucket] : 0;
-        const int q0 = (int)(e0 & 0xffff), q1 = (int)((e0 >> 16) & 0xffff), q2 = (int)((e0 >> 32) & 0xffff), q3 = (int)(e0 >> 48);
-        const int lo = p > QZK_MAXDIST ? (int)(p - QZK_MAXDIST) : 0;
+        /* the previous window's table stores are ahead of this gather in the wave's memory stream (same wave, same CU) */
+        qz_lds_sync();
+        qzk_u32x4 ev = {0, 0, 0, 0};
+#ifdef QZK_DIAG_NOGATHER      /* timing diagnostics only (wrong output): every lane reads one hot entry */
+        if (canh) ev = qzk_ld_bkt(&tab[(size_t)(bucket & 63) * QZK_K1_WAVES]);
+#else
+        if (canh) ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_WAVES]);
+#endif
+        const bool ev_ok = ev[3] == epoch;                /* another chunk's entry: as good as empty */
+        const uint32_t q0 = ev_ok ? ev[0] & 0xffffffu : 0, q1 = ev_ok ? (ev[0] >> 24) | ((ev[1] & 0xffffu) << 8) : 0,
+                       q2 = ev_ok ? (ev[1] >> 16) | ((ev[2] & 0xffu) << 16) : 0, q3 = ev_ok ? ev[2] >> 8 : 0;   /* chunk offsets, 0 = none */
+        /* chained candidates must lie above zlib's `limit` (window coordinates: strstart - MAX_DIST or NIL = 0) */
+        const uint32_t lo = base + (p > QZK_MAXDIST ? p - QZK_MAXDIST : 0);
         const int maxlen = avail < 258 ? avail : 258;
         const int nice = avail < QZK_NICE ? avail : QZK_NICE;
-        int best_len = 2, best_c = 0;
+        int best_len = 2; uint32_t best_c = 0;
         int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
         bool suspect;
-        int nc, c0, c1, c2, c3;
+        int nc; uint32_t c0, c1, c2, c3;
         {
             uint32_t x[4][4];
-#define QZK_LDC(k, ck) do { const uint32_t ca_ = base + (uint32_t)(ck); uint64_t g_ = coff + ca_; \
+#define QZK_LDC(k, ck) do { const uint32_t ca_ = (ck); uint64_t g_ = coff + ca_; \
         if ((int64_t)ca_ >= (int64_t)rhi - QZK_RING) QZK_RING16(x[k], ca_); \
         else if (!guard) { x[k][0] = qz_ld32(src + g_); x[k][1] = qz_ld32(src + g_ + 4); x[k][2] = qz_ld32(src + g_ + 8); x[k][3] = qz_ld32(src + g_ + 12); } \
         else { x[k][0] = qzk_ld32g(src, g_, src_len); x[k][1] = qzk_ld32g(src, g_ + 4, src_len); x[k][2] = qzk_ld32g(src, g_ + 8, src_len); x[k][3] = qzk_ld32g(src, g_ + 12, src_len); } } while (0)
             /* loads are predicated on the link being live: with a dozen waves per CU the kernel is bound by the
              * texture path (TA/TD ~ one lane-line per cycle), so dead lanes must not ride along */
             for (int k = 0; k < 4; k++) x[k][0] = x[k][1] = x[k][2] = x[k][3] = 0;
-            const bool ok0 = canh && q0 != 0 && (int)p - q0 <= QZK_MAXDIST;
+            const bool ok0 = canh && q0 > base && pa - q0 <= QZK_MAXDIST;      /* at or below the window origin: NIL */
             const bool ok1 = ok0 && q1 > lo;
             const bool ok2 = ok1 && q2 > lo;
             const bool ok3 = ok2 && q3 > lo;
-            c0 = ok0 ? q0 : (int)p; c1 = ok1 ? q1 : (int)p; c2 = ok2 ? q2 : (int)p; c3 = ok3 ? q3 : (int)p;
+            c0 = ok0 ? q0 : pa; c1 = ok1 ? q1 : pa; c2 = ok2 ? q2 : pa; c3 = ok3 ? q3 : pa;
             if (ok0) QZK_LDC(0, c0);
             if (ok1) QZK_LDC(1, c1);
             if (ok2) QZK_LDC(2, c2);
@@ -262,7 +296,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             }
             bool done = false;
             for (int k = 0; k < 4; k++) {
-                int ck = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                const uint32_t ck = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
                 int len = 0;
                 if (k < nc) {
                     uint32_t d;
@@ -281,9 +315,9 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             }
         }
         uint32_t mlen = best_len >= 3 ? (uint32_t)best_len : 0;     /* 0 => literal */
-        uint32_t mdist = mlen ? p - (uint32_t)best_c : 0;
+        uint32_t mdist = mlen ? pa - best_c : 0;
         const bool capped = (best_len == QZK_CAP) && (maxlen > QZK_CAP);
-        const bool exact0 = nc > 0 && (int)p - c0 == QZK_MAXDIST;
+        const bool exact0 = nc > 0 && pa - c0 == QZK_MAXDIST;
 
         QZK_T(3);
         const uint64_t CANH = qz_ballot(canh);
@@ -377,12 +411,12 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 const bool ex_l = qz_readlane((uint32_t)exact0, l) != 0;
                 if (!fin && !(had_intra && ex_l)) {
                     for (int k = 0; k < nc_l && cnt < 4 && !fin; k++) {
-                        int ck = (int)qz_readlane((uint32_t)(k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3), l);
+                        const uint32_t ck = qz_readlane(k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3, l);
                         int len = (int)qz_readlane((uint32_t)(k == 0 ? l0 : k == 1 ? l1 : k == 2 ? l2 : l3), l);
                         if (len == QZK_CAP && maxlen_l > QZK_CAP)
-                            len = qzk_wave_matchlen(src, src_len, coff + pos + (uint32_t)l, coff + base + (uint32_t)ck, maxlen_l, lane);
+                            len = qzk_wave_matchlen(src, src_len, coff + pos + (uint32_t)l, coff + ck, maxlen_l, lane);
                         cnt++;
-                        if (len > bl) { bl = len; bd = (B + (uint32_t)l) - (uint32_t)ck; }
+                        if (len > bl) { bl = len; bd = (pos + (uint32_t)l) - ck; }
                         if (len >= nice_l) fin = true;
                     }
                 }
@@ -429,7 +463,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
          * drops out).  Suspect inserted lanes, in position order: the entry is [me, the (up to three) most recent
          * inserted lanes of this window with my hash, then what the table held at window start], and every earlier
          * lane with that hash is superseded - only the last writer of a hash stores. */
-        uint64_t myent = (uint64_t)p | (e0 << 16);
+        uint32_t n0 = pa, n1 = q0, n2 = q1, n3 = q2;       /* clean lane: me, then what the table held at window start */
         bool store = isI;
         {
             uint64_t todo = I & qz_ballot(suspect);
@@ -440,19 +474,31 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 uint32_t b_j = qz_readlane(bucket, j);
                 const uint64_t same = qz_ballot(canh && bucket == b_j) & I;
                 uint64_t mates = same & qz_below(j);
-                uint64_t ent = (uint64_t)(B + (uint32_t)j);
+                uint32_t m1 = 0, m2 = 0, m3 = 0;            /* up to three most recent inserted lanes with lane j's hash */
                 int nf = 1;
                 while (mates && nf < 4) {
                     const int m = qz_msb64(mates);
                     mates &= ~(1ull << m);
-                    ent |= (uint64_t)(B + (uint32_t)m) << (16 * nf);
+                    const uint32_t mp = pos + (uint32_t)m;
+                    if (nf == 1) m1 = mp; else if (nf == 2) m2 = mp; else m3 = mp;
                     nf++;
                 }
-                if (lane == j) myent = nf < 4 ? ent | (e0 << (16 * nf)) : ent;
+                if (lane == j) {
+                    if (nf == 2) { n1 = m1; n2 = q0; n3 = q1; }
+                    else if (nf == 3) { n1 = m1; n2 = m2; n3 = q0; }
+                    else if (nf == 4) { n1 = m1; n2 = m2; n3 = m3; }
+                }
                 if (((same >> lane) & 1) && lane < j) store = false;
             }
         }
-        if (store) bkt[bucket] = myent;
+        if (store) {
+            const qzk_u32x4 e = {n0 | (n1 << 24), (n1 >> 8) | (n2 << 16), (n2 >> 16) | (n3 << 8), epoch};
+#ifdef QZK_DIAG_NOSCATTER
+            *(qzk_u32x4 *)&tab[(size_t)(bucket & 63) * QZK_K1_WAVES] = e;
+#else
+            *(qzk_u32x4 *)&tab[(size_t)bucket * QZK_K1_WAVES] = e;
+#endif
+        }
         pos += (uint32_t)l;
         QZK_T(12);
     }
@@ -466,14 +512,16 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 #undef QZK_RING16
 }
 
-/* K1 launch shape: persistent single-wave workgroups pull chunk numbers from a counter, so the 512 KiB table is per
- * resident workgroup - it stays warm in L2/MALL as far as it fits - and uneven chunks balance themselves.
- * tables: blockIdx.x * 65536 entries. */
-QZ_KERNEL_MAX(64) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
-                                       uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, uint64_t *tables,
-                                       uint32_t *counter, const uint32_t *cdesc)
+/* K1 launch shape: persistent workgroups of QZK_K1_WAVES waves, one per CU; every WAVE pulls chunk numbers from a
+ * counter (uneven chunks balance themselves) and owns one column of its workgroup's table: entry h of wave w at
+ * tables[(blockIdx.x * 65536 + h) * QZK_K1_WAVES + w].  The waves never talk to each other - what they share is cache
+ * lines.  epoch_base + chunk number = the chunk's epoch (host: unique per chunk across launches, never 0). */
+QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
+                                                     uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tables,
+                                                     uint32_t *counter, const uint32_t *cdesc, uint32_t epoch_base)
 {
-    uint64_t *bkt = tables + (uint64_t)blockIdx.x * QZK_HSIZE;
+    const int wv = (int)(threadIdx.x >> 6);
+    qzk_bkt *tab = tables + (size_t)blockIdx.x * QZK_HSIZE * QZK_K1_WAVES + wv;
     for (;;) {
         /* no `if (lane == 0)` anywhere on this loop's path: the compiler threads lane-0-only blocks of consecutive
          * iterations together, after which the other 63 lanes would run readfirstlane without lane 0 (seen on
@@ -481,7 +529,7 @@ QZ_KERNEL_MAX(64) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uin
         uint32_t chunk = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);
         chunk = qz_readfirstlane(chunk);
         if (chunk >= nchunks) break;
-        qzk_lz77_chunk(src, src_len, chunk_sz, chunk, sym_lc, sym_dist, meta, bkt, cdesc);
+        qzk_lz77_chunk(src, src_len, chunk_sz, chunk, sym_lc, sym_dist, meta, tab, epoch_base + chunk, cdesc, wv);
     }
 }
 

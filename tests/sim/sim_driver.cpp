@@ -19,14 +19,23 @@
 
 extern "C" {
 
-/* K1 through its persistent pull kernel: `wgs` workgroups share the chunk counter (the emulator runs them one after
- * the other, so the first one takes every chunk and its table is reused dirty - the interesting case). */
+/* K1 through its persistent pull kernel: `wgs` workgroups of QZK_K1_WAVES waves share the chunk counter.  The emulator
+ * runs the workgroups one after the other and the waves of a workgroup interleaved, so the waves of the first workgroup
+ * take every chunk between them, each reusing its column of the (dirty, epoch-tagged) table chunk after chunk - the
+ * interesting case.  The table starts out as garbage with a foreign epoch, and the epochs continue from run to run. */
+static uint32_t g_k1_epoch = 1;
 static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint32_t nchunks,
-                   uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta, const uint32_t *cdesc = nullptr)
+                   uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta, const uint32_t *cdesc = nullptr, uint32_t waves = 3)
 {
-    std::vector<uint64_t> tables((size_t)wgs * QZK_HSIZE, 0xabcdabcdabcdabcdull);
+    static std::vector<qzk_bkt> tables;
+    const size_t need = (size_t)wgs * QZK_HSIZE * QZK_K1_WAVES;
+    if (tables.size() < need) {
+        qzk_bkt junk; junk.w0 = 0xabcdabcdu; junk.w1 = 0x12345678u; junk.w2 = 0x9abcdef0u; junk.ep = 0;
+        tables.assign(need, junk);
+    }
     uint32_t counter = 0;
-    sim::launch(wgs, 64, 0, [&] { qzk_lz77_pull_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, tables.data(), &counter, cdesc); });
+    sim::launch(wgs, 64 * waves, 0, [&] { qzk_lz77_pull_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, tables.data(), &counter, cdesc, g_k1_epoch); });
+    g_k1_epoch += nchunks;
 }
 
 /* K1 only: symbols + meta of every chunk */
