@@ -59,7 +59,7 @@ __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list
  * segment; K > 1: K lanes per segment decode speculatively, and whatever that kernel hands back (QZK_INF_ESPEC: stored
  * or several blocks, bad data, ...) goes through the K == 1 launch afterwards.  h_res receives every result. */
 static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qzk_infseg *hs, uint32_t nsegs,
-                     qzk_infres *h_res, uint32_t K, hipStream_t st)
+                     qzk_infres *h_res, uint32_t K, hipStream_t st, bool run_b = true)
 {
     const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
     int rc = qzd_aux_reserve(c, sb + rb + 64);
@@ -83,8 +83,8 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     const size_t rcb = K == 1 ? 0 : (((size_t)nsegs * K * QZK_SPEC_NREC * sizeof(qzk_rec) + 255) & ~(size_t)255);
     const size_t litb = (lit_total + 511) & ~(uint64_t)255, seqb = seq_total * sizeof(qzk_seq);
     /* output streaming: only the plain decode of a whole member (every segment writes, known output offsets) */
-    const bool stream_out = c->so_host && c->so_nat && K == 1 && nsegs >= QZD_LANE_MIN_SEGS;
-    const size_t ordb = stream_out ? (((size_t)nsegs * 4 + 255) & ~(size_t)255) : 0;
+    const bool stream_out = run_b && c->so_host && c->so_nat && K == 1 && nsegs >= QZD_LANE_MIN_SEGS;
+    const size_t ordb = ((size_t)nsegs * 4 + 255) & ~(size_t)255;
     const size_t need = tabb + tsb + chb + rcb + litb + seqb + ordb + 256;
     if (need > c->big_cap) {
         hipDeviceSynchronize();
@@ -125,6 +125,16 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
 #undef QZD_SPEC_LAUNCH
     }
     HIPCHK(c, hipEventRecord(c->ev[1][0], st));
+    c->tp.segs = d_segs; c->tp.res = d_res; c->tp.ts = ts_d; c->tp.lits = lit_d; c->tp.seqs = seq_d; c->tp.chains = ch_d;
+    c->tp.ord = ord_d; c->tp.nsegs = nsegs; c->tp.K = K;
+    if (!run_b) {
+        /* phase A only (K == 1): its results say which candidates are real segments and where their output belongs;
+         * two_phase_resolve() runs phase B once the host has decided */
+        HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipGetLastError());
+        return QZD_OK;
+    }
     if (!stream_out) {
         hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
                            d_comp, d_out, d_segs, d_res, nsegs, ts_d, K, lit_d, seq_d, ch_d, (const uint32_t *)NULL, 0u);
@@ -175,6 +185,46 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     rc = two_phase(c, d_comp, d_out, rs.data(), (uint32_t)redo.size(), rr.data(), 1, st);
     if (rc) return rc;
     for (size_t i = 0; i < redo.size(); i++) h_res[redo[i]] = rr[i];
+    return QZD_OK;
+}
+
+/* Phase B for the segments of the last two_phase(run_b = false) call that the host found to be real: hs = the same
+ * records with their final out_off (candidates that are no segments carry QZK_INF_COUNT_ONLY and are skipped),
+ * h_order = the real ones in output order.  With h_dst the output leaves for the host range by range behind the launches
+ * (off_of / end_of give a range's bytes).  Results (phase B can still find a bad distance) come back in h_res. */
+static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qzk_infseg *hs, uint32_t nsegs,
+                             const uint32_t *h_order, uint32_t count, qzk_infres *h_res, uint8_t *h_dst, hipStream_t st)
+{
+    if (nsegs != c->tp.nsegs || c->tp.K != 1 || count == 0) return QZD_ERR_PARAM;
+    qzk_infseg *d_segs = (qzk_infseg *)c->tp.segs; qzk_infres *d_res = (qzk_infres *)c->tp.res;
+    HIPCHK(c, hipMemcpyAsync(d_segs, hs, (size_t)nsegs * sizeof(qzk_infseg), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->tp.ord, h_order, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev[1][0], st));
+    const uint32_t parts = h_dst && count >= QZD_LANE_MIN_SEGS ? QZD_SO_PARTS : 1u;
+    uint64_t off[QZD_SO_PARTS + 1];
+    for (uint32_t p = 0; p < parts; p++) {
+        const uint32_t first = (uint32_t)((uint64_t)count * p / parts), end = (uint32_t)((uint64_t)count * (p + 1) / parts);
+        off[p] = hs[h_order[first]].out_off;
+        off[p + 1] = hs[h_order[end - 1]].out_off + hs[h_order[end - 1]].out_cap;
+        hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((end - first + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
+                           d_comp, d_out, d_segs, d_res, nsegs, (const qzk_tokseg *)c->tp.ts, 1u, (const uint8_t *)c->tp.lits,
+                           (const qzk_seq *)c->tp.seqs, (const qzk_chain *)c->tp.chains, (const uint32_t *)(c->tp.ord + first), end - first);
+        if (h_dst) HIPCHK(c, hipEventRecord(c->so_ev[p], st));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1][2], st));
+    if (h_dst) {
+        for (uint32_t p = 0; p < parts; p++) {
+            HIPCHK(c, hipStreamWaitEvent(c->st[1], c->so_ev[p], 0));
+            HIPCHK(c, hipMemcpyAsync(h_dst + off[p], d_out + off[p], off[p + 1] - off[p], hipMemcpyDeviceToHost, c->st[1]));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->st[1]));
+        c->so_sent = off[parts];
+    }
+    HIPCHK(c, hipMemcpyAsync(h_res, d_res, (size_t)nsegs * sizeof(qzk_infres), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    float t = 0;
+    if (hipEventElapsedTime(&t, c->ev[1][0], c->ev[1][2]) == hipSuccess) c->inf_ms[2] += t;
     return QZD_OK;
 }
 
@@ -401,8 +451,74 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
     uint64_t total_out = 0, total_in = 0;
     bool done = false;
 
-    /* --- 2. optimistic single pass --- */
-    if (scan_ok && seg_hint && ns > 1) {
+    /* --- 2a. thousands of candidates: phase A (Huffman decoding into position-independent token streams) runs over
+     * every candidate, the host then walks the chain of real segments through the results - a candidate that is no
+     * boundary (00 00 FF FF inside compressed data or a stored block) simply drops out - gives each real segment its
+     * output offset, and phase B writes only those.  One pass whatever the candidates look like. --- */
+    const char *force_path = getenv("QATZIP_AMD_INFLATE");
+    const bool lanes = force_path ? force_path[0] == 'l' : ns >= QZD_LANE_MIN_SEGS;
+    {
+        if (scan_ok && seg_hint && ns > 1 && lanes) {
+            auto clen = [&](uint32_t k) { return (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k]; };
+            std::vector<uint32_t> order(ns);
+            {   /* largest compressed size first (32-byte classes): lanes of a wave carry similar work, the longest start first */
+                const uint32_t NB = 8192;
+                std::vector<uint32_t> cnt(NB + 1, 0);
+                auto rcls = [&](uint32_t k) { uint32_t v = clen(k) >> 5; return NB - 1 - (v < NB ? v : NB - 1); };
+                for (uint32_t i = 0; i < ns; i++) cnt[rcls(i) + 1]++;
+                for (uint32_t i = 0; i < NB; i++) cnt[i + 1] += cnt[i];
+                for (uint32_t i = 0; i < ns; i++) order[cnt[rcls(i)]++] = i;
+            }
+            std::vector<qzk_infseg> ps(ns);
+            std::vector<qzk_infres> pr(ns);
+            std::vector<uint32_t> where(ns);                    /* candidate -> its place in the launch */
+            for (uint32_t i = 0; i < ns; i++) {
+                const uint32_t k = order[i];
+                where[k] = i;
+                ps[i].in_off = start[k]; ps[i].in_len = (uint32_t)(n - start[k]);
+                ps[i].out_off = 0; ps[i].out_cap = seg_hint; ps[i].flags = 0; ps[i].pad = clen(k);
+            }
+            lap("segment records");
+            HIPCHK(c, hipEventRecord(c->ev[0][0], c->st[0]));
+            rc = two_phase(c, d_src, d_dst, ps.data(), ns, pr.data(), 1, c->st[0], false);
+            if (rc) return rc;
+            lap("phase A");
+            std::vector<uint32_t> chain;                        /* launch indices of the real segments, in output order */
+            uint64_t oo = 0; uint32_t k = 0; bool ok = true;
+            for (;;) {
+                const qzk_infres &r = pr[where[k]];
+                if (r.status != QZK_INF_FINAL && r.status != QZK_INF_FLUSH) { ok = false; break; }
+                ps[where[k]].out_off = oo; ps[where[k]].out_cap = r.out_len; ps[where[k]].flags = 0x80000000u;   /* marks a member */
+                chain.push_back(where[k]);
+                oo += r.out_len;
+                if (r.status == QZK_INF_FINAL) { total_in = (uint64_t)start[k] + r.in_used; break; }
+                const uint32_t nxt = start[k] + r.in_used;
+                auto it = std::lower_bound(start.begin() + k + 1, start.end(), nxt);
+                if (it == start.end() || *it != nxt) { ok = false; break; }
+                k = (uint32_t)(it - start.begin());
+            }
+            if (ok && oo > dst_cap) return QZD_ERR_DSTCAP;
+            if (ok) {
+                for (uint32_t i = 0; i < ns; i++) ps[i].flags = ps[i].flags == 0x80000000u ? 0 : QZK_INF_COUNT_ONLY;   /* the rest is skipped */
+                c->so_sent = 0;
+                rc = two_phase_resolve(c, d_src, d_dst, ps.data(), ns, chain.data(), (uint32_t)chain.size(), pr.data(), h_dst, c->st[0]);
+                if (rc) return rc;
+                for (uint32_t i : chain) if (pr[i].status < 0) { ok = false; break; }
+                HIPCHK(c, hipEventRecord(c->ev[0][1], c->st[0]));
+                HIPCHK(c, hipStreamSynchronize(c->st[0]));
+                float t = 0;
+                if (hipEventElapsedTime(&t, c->ev[0][0], c->ev[0][1]) == hipSuccess) c->inf_ms[0] += t;
+                lap("phase B");
+                if (ok) {
+                    total_out = oo; done = true;
+                    if (h_sent && h_dst && c->so_sent >= total_out) *h_sent = 1;
+                }
+            }
+        }
+    }
+
+    /* --- 2b. optimistic single pass (fewer candidates: one wave per segment) --- */
+    if (!done && scan_ok && seg_hint && ns > 1 && !lanes) {
         for (uint32_t k = 0; k < ns; k++) {
             uint64_t oo = (uint64_t)k * seg_hint;
             segs[k].in_off = start[k]; segs[k].in_len = (uint32_t)(n - start[k]);

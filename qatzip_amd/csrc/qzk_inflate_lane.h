@@ -244,47 +244,50 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
     S->state = QZK_LS_SYM;
 }
 
-/* What phase A writes, per lane.  A lane's next input load queues behind its own outstanding stores (vector memory
- * completes in order), so stores must be rare: literals leave 32 bytes at a time and sequence records 8 at a time,
- * staged in registers picked by compare-selects. */
+/* What phase A writes, per lane.  Vector memory operations of a wave complete in order, so a lane's store delays the
+ * next input load of EVERY lane of its wave until the store has reached memory - and lanes that decode different data
+ * fill their buffers at different moments: with sixteen segments per wave nearly every trip of the hot loop had one
+ * (measured on data without duplicate chunks: 2.6 us per trip, five times what identical segments took).  So symbols are
+ * only STAGED in registers, and the whole wave stores together at the end of a round of QZK_TOK_ROUND trips (a trip
+ * appends at most two literals or one sequence): one queue of stores per round instead of one per lane and buffer. */
+#define QZK_TOK_ROUND 8
 typedef struct {
     uint8_t *lp; qzk_seq *sq;
-    uint32_t lrun, nseq;                /* literals since the last sequence, sequences so far */
-    uint32_t lw, ln, lq;                /* literal bytes in HBM, bytes (0..7) in lbuf, words (0..3) in lq0..2 */
-    uint64_t lbuf, lq0, lq1, lq2;
-    uint64_t s0, s1, s2, s3, s4, s5, s6;
+    uint32_t lrun, nseq;                /* literals since the last sequence, sequences so far (staged ones included) */
+    uint32_t lw, ln;                    /* literal bytes in HBM, bytes staged in l0..l2 (< 8 after a round's flush, <= 23 within one) */
+    uint64_t l0, l1, l2;
+    uint32_t sk;                        /* sequences staged in s0..s7 */
+    uint64_t s0, s1, s2, s3, s4, s5, s6, s7;
     bool count_only;
 } qzk_tok_out;
+#define QZK_NLIT(O_) ((O_).lw + (O_).ln)    /* literal bytes appended so far */
 
-QZ_DEV void qzk_tok_word(qzk_tok_out *O, uint64_t w)
+QZ_DEV void qzk_tok_init(qzk_tok_out *O, uint8_t *lp, qzk_seq *sq, bool count_only)
 {
-    if (O->lq == 3) {
-        qz_u64u *d = (qz_u64u *)(O->lp + O->lw);       /* 32-byte aligned unless a flush intervened */
-        d[0].v = O->lq0; d[1].v = O->lq1; d[2].v = O->lq2; d[3].v = w;
-        O->lw += 32; O->lq = 0;
-    } else {
-        O->lq0 = O->lq == 0 ? w : O->lq0; O->lq1 = O->lq == 1 ? w : O->lq1; O->lq2 = O->lq == 2 ? w : O->lq2;
-        O->lq++;
-    }
+    O->lp = lp; O->sq = sq; O->count_only = count_only;
+    O->lrun = 0; O->nseq = 0; O->lw = 0; O->ln = 0; O->sk = 0;
+    O->l0 = O->l1 = O->l2 = 0;
+    O->s0 = O->s1 = O->s2 = O->s3 = O->s4 = O->s5 = O->s6 = O->s7 = 0;
 }
 QZ_DEV void qzk_tok_byte(qzk_tok_out *O, uint32_t byte)
 {
     if (!O->count_only) {
-        O->lbuf |= (uint64_t)byte << (8 * O->ln);
-        if (++O->ln == 8) { qzk_tok_word(O, O->lbuf); O->lbuf = 0; O->ln = 0; }
+        const uint32_t w = O->ln >> 3;
+        const uint64_t v = (uint64_t)byte << (8 * (O->ln & 7));
+        O->l0 |= w == 0 ? v : 0; O->l1 |= w == 1 ? v : 0; O->l2 |= w == 2 ? v : 0;
+        O->ln++;
     }
     O->lrun++;
 }
-/* append the low k (1..8) bytes of v */
+/* append the low k (1..8) bytes of v; the caller flushes after every call (ln < 8 on entry) */
 QZ_DEV void qzk_tok_bytes(qzk_tok_out *O, uint64_t v, uint32_t k)
 {
     if (!O->count_only) {
         if (k < 8) v &= (1ull << (8 * k)) - 1;
-        O->lbuf |= v << (8 * O->ln);
-        if (O->ln + k >= 8) {
-            qzk_tok_word(O, O->lbuf);
-            O->lbuf = O->ln ? v >> (8 * (8 - O->ln)) : 0; O->ln = O->ln + k - 8;
-        } else O->ln += k;
+        const uint32_t sh = 8 * (O->ln & 7);
+        O->l0 |= v << sh;
+        O->l1 |= sh ? v >> (64 - sh) : 0;
+        O->ln += k;
     }
     O->lrun += k;
 }
@@ -292,38 +295,47 @@ QZ_DEV void qzk_tok_seq(qzk_tok_out *O, uint32_t mlen, uint32_t dm1)
 {
     if (!O->count_only) {
         const uint64_t w = (uint64_t)O->lrun | (uint64_t)mlen << 32 | (uint64_t)dm1 << 48;
-        const uint32_t k = O->nseq & 7;
-        if (k == 7) {
-            uint64_t *d = (uint64_t *)(O->sq + O->nseq - 7);
-            d[0] = O->s0; d[1] = O->s1; d[2] = O->s2; d[3] = O->s3; d[4] = O->s4; d[5] = O->s5; d[6] = O->s6; d[7] = w;
-        } else {
-            O->s0 = k == 0 ? w : O->s0; O->s1 = k == 1 ? w : O->s1; O->s2 = k == 2 ? w : O->s2; O->s3 = k == 3 ? w : O->s3;
-            O->s4 = k == 4 ? w : O->s4; O->s5 = k == 5 ? w : O->s5; O->s6 = k == 6 ? w : O->s6;
-        }
+        const uint32_t k = O->sk;
+        O->s0 = k == 0 ? w : O->s0; O->s1 = k == 1 ? w : O->s1; O->s2 = k == 2 ? w : O->s2; O->s3 = k == 3 ? w : O->s3;
+        O->s4 = k == 4 ? w : O->s4; O->s5 = k == 5 ? w : O->s5; O->s6 = k == 6 ? w : O->s6; O->s7 = k == 7 ? w : O->s7;
+        O->sk = k + 1;
     }
     O->nseq++; O->lrun = 0;
 }
+/* end of a round: the whole words of the staged literals and all staged sequences leave, every lane at the same point
+ * of the instruction stream */
+QZ_DEV void qzk_tok_round_flush(qzk_tok_out *O)
+{
+    if (O->count_only) return;
+    const uint32_t nw = O->ln >> 3;
+    uint8_t *d = O->lp + O->lw;
+    if (nw >= 1) qzk_st64u(d, O->l0);
+    if (nw >= 2) qzk_st64u(d + 8, O->l1);
+    O->l0 = nw == 0 ? O->l0 : nw == 1 ? O->l1 : O->l2;
+    O->l1 = nw == 0 ? O->l1 : nw == 1 ? O->l2 : 0;
+    O->l2 = nw == 0 ? O->l2 : 0;
+    O->lw += 8 * nw; O->ln &= 7;
+    const uint32_t k = O->sk;
+    uint64_t *q = (uint64_t *)(O->sq + (O->nseq - k));
+    if (k > 0) q[0] = O->s0;
+    if (k > 1) q[1] = O->s1;
+    if (k > 2) q[2] = O->s2;
+    if (k > 3) q[3] = O->s3;
+    if (k > 4) q[4] = O->s4;
+    if (k > 5) q[5] = O->s5;
+    if (k > 6) q[6] = O->s6;
+    if (k > 7) q[7] = O->s7;
+    O->sk = 0;
+}
 /* make everything appended so far visible in memory and leave the stream ready for more (used between the rounds
- * of the speculative phase A); after it the literal position is no longer 32-byte aligned, which only costs speed */
+ * of the speculative phase A, and at the end); after it the literal position is no longer 8-byte aligned, which only
+ * costs speed */
 QZ_DEV void qzk_tok_flush(qzk_tok_out *O)
 {
     if (O->count_only) return;
-    uint64_t *d = (uint64_t *)(O->lp + O->lw);
-    if (O->lq > 0) ((qz_u64u *)d)[0].v = O->lq0;
-    if (O->lq > 1) ((qz_u64u *)d)[1].v = O->lq1;
-    if (O->lq > 2) ((qz_u64u *)d)[2].v = O->lq2;
-    O->lw += 8 * O->lq;
-    for (uint32_t i = 0; i < O->ln; i++) O->lp[O->lw + i] = (uint8_t)(O->lbuf >> (8 * i));
-    O->lw += O->ln; O->lq = 0; O->ln = 0; O->lbuf = 0;
-    const uint32_t k = O->nseq & 7;
-    d = (uint64_t *)(O->sq + (O->nseq & ~7u));
-    if (k > 0) d[0] = O->s0;
-    if (k > 1) d[1] = O->s1;
-    if (k > 2) d[2] = O->s2;
-    if (k > 3) d[3] = O->s3;
-    if (k > 4) d[4] = O->s4;
-    if (k > 5) d[5] = O->s5;
-    if (k > 6) d[6] = O->s6;
+    qzk_tok_round_flush(O);
+    for (uint32_t i = 0; i < O->ln; i++) O->lp[O->lw + i] = (uint8_t)(O->l0 >> (8 * i));
+    O->lw += O->ln; O->ln = 0; O->l0 = 0;
 }
 
 QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
@@ -408,11 +420,13 @@ QZ_KERNEL_MAX(64) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *
     S.lmax = 0; S.dmax = 0; S.status = QZK_INF_EDATA; S.state = QZK_LS_HDR;
     S.through = sg.flags & QZK_INF_THROUGH_FLUSH;
     qzk_tok_out O;
-    O.count_only = sg.flags & QZK_INF_COUNT_ONLY;
-    O.lp = lits; O.sq = seqs;
-    if (!O.count_only) { O.lp += ts[sidx].lit_off; O.sq += ts[sidx].seq_off; }
-    O.lrun = 0; O.nseq = 0; O.lw = 0; O.ln = 0; O.lq = 0; O.lbuf = 0; O.lq0 = O.lq1 = O.lq2 = 0;
-    O.s0 = O.s1 = O.s2 = O.s3 = O.s4 = O.s5 = O.s6 = 0;
+    {
+        const bool co = sg.flags & QZK_INF_COUNT_ONLY;
+        qzk_tok_init(&O, co ? lits : lits + ts[sidx].lit_off, co ? seqs : seqs + ts[sidx].seq_off, co);
+    }
+    /* the pieces phase B puts the segment together from: runs of sequences, and stored blocks as they lie in the input */
+    qzk_chain *const C = chains + sidx;
+    uint32_t nel = 0, piece_seq0 = 0, piece_lit0 = 0;
 
     while (S.state != QZK_LS_DONE) {
         qzk_lbits *b = &S.b;
@@ -420,14 +434,18 @@ QZ_KERNEL_MAX(64) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *
             /* ---- the hot loop.  Branch-free refill: the 8 bytes at the read position are always already in flight
              * (pw), each trip ORs them in above the valid bits, steps over the bytes that fitted and issues the load
              * for the next trip, whose latency the symbol decode then covers; >= 56 valid bits per trip is a whole
-             * symbol (15 + 5 + 15 + 13).  Bounded so that lanes parked in a cold state get their turn. ---- */
+             * symbol (15 + 5 + 15 + 13).  Rounds of QZK_TOK_ROUND trips, the stores of a round at its end; bounded so
+             * that lanes parked in a cold state get their turn. ---- */
             b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;     /* hand whole bytes back */
             uint64_t pw = qzk_ld64u(b->p + b->pos);
-            for (int trip = 0; trip < 256 && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
-                b->bb |= pw << b->bc;
-                b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
-                pw = qzk_ld64u(b->p + b->pos);
-                qzk_lane_symbol<false, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0);
+            for (int round = 0; round < 32 && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; round++) {
+                for (int trip = 0; trip < QZK_TOK_ROUND && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
+                    b->bb |= pw << b->bc;
+                    b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
+                    pw = qzk_ld64u(b->p + b->pos);
+                    qzk_lane_symbol<false, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0);
+                }
+                qzk_tok_round_flush(&O);
             }
             b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;
             const uint32_t keep = (uint32_t)b->bc; const uint64_t low = b->bb;
@@ -435,31 +453,50 @@ QZ_KERNEL_MAX(64) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *
             b->bb = low; b->bc = (int)keep;
         } else if (S.state == QZK_LS_SYM) {
             /* last bytes of the input: the careful reader */
-            for (int trip = 0; trip < 64 && S.state == QZK_LS_SYM; trip++) {
-                qzk_lrefill(b);
-                qzk_lane_symbol<true, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0);
+            for (int round = 0; round < 8 && S.state == QZK_LS_SYM; round++) {
+                for (int trip = 0; trip < QZK_TOK_ROUND && S.state == QZK_LS_SYM; trip++) {
+                    qzk_lrefill(b);
+                    qzk_lane_symbol<true, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0);
+                }
+                qzk_tok_round_flush(&O);
             }
         } else if (S.state == QZK_LS_HDR) qzk_lane_header(&S, T, lroot, droot);
         else if (S.state == QZK_LS_RAW) {
-            /* stored block: its bytes join the literal stream, <= 8 per trip, <= 512 per visit */
-            for (int trip = 0; trip < 64 && S.clen; trip++) {
-                const uint32_t k = S.clen < 8 ? S.clen : 8;
-                uint64_t v = 0;
-                if (!O.count_only) {
+            if (O.count_only) { S.op += S.clen; S.rpos += S.clen; S.clen = 0; }         /* nothing to move */
+            else if (nel + 3 <= QZK_CHAIN_MAXEL) {
+                /* a stored block never enters the literal stream: phase B copies it straight from the input.  The
+                 * sequences so far become a piece of their own (their pending literals end it) */
+                if (O.lrun) qzk_tok_seq(&O, 0u, 0u);
+                if (O.nseq > piece_seq0) {
+                    qzk_chain_el e; e.sub = 0; e.seq_first = piece_seq0; e.seq_count = O.nseq - piece_seq0; e.lit_first = piece_lit0; e.lrun_skip = 0;
+                    C->el[nel++] = e;
+                }
+                qzk_chain_el r; r.sub = QZK_PIECE_RAW; r.seq_first = S.rpos; r.seq_count = S.clen; r.lit_first = 0; r.lrun_skip = 0;
+                C->el[nel++] = r;
+                piece_seq0 = O.nseq; piece_lit0 = QZK_NLIT(O);
+                S.op += S.clen; S.rpos += S.clen; S.clen = 0;
+            } else {
+                /* (more stored blocks than a chain holds pieces) its bytes join the literal stream, <= 8 per trip */
+                for (int trip = 0; trip < 64 && S.clen; trip++) {
+                    const uint32_t k = S.clen < 8 ? S.clen : 8;
+                    uint64_t v = 0;
                     if (S.rpos + 8 <= b->end) v = qzk_ld64u(b->p + S.rpos);
                     else for (uint32_t i = 0; i < k; i++) v |= (uint64_t)b->p[S.rpos + i] << (8 * i);
+                    qzk_tok_bytes(&O, v, k);
+                    qzk_tok_round_flush(&O);
+                    S.op += k; S.rpos += k; S.clen -= k;
                 }
-                qzk_tok_bytes(&O, v, k);
-                S.op += k; S.rpos += k; S.clen -= k;
             }
             if (!S.clen) { if (S.last) { S.status = QZK_INF_FINAL; S.state = QZK_LS_DONE; } else S.state = QZK_LS_HDR; }
         }
     }
     qzk_tok_finish(&O);
     if (!O.count_only) {
-        qzk_chain C; C.nel = 1; C.pad = 0;
-        C.el[0].sub = 0; C.el[0].seq_first = 0; C.el[0].seq_count = O.nseq; C.el[0].lit_first = 0; C.el[0].lrun_skip = 0;
-        chains[sidx] = C;
+        if (O.nseq > piece_seq0 || nel == 0) {
+            qzk_chain_el e; e.sub = 0; e.seq_first = piece_seq0; e.seq_count = O.nseq - piece_seq0; e.lit_first = piece_lit0; e.lrun_skip = 0;
+            C->el[nel++] = e;
+        }
+        C->nel = nel; C->pad = 0;
     }
     qzk_infres r;
     r.status = S.status; r.out_len = S.op; r.nblocks = S.nblocks;

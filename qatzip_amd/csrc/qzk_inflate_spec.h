@@ -74,10 +74,7 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
     S.lmax = 0; S.dmax = 0; S.status = QZK_INF_EDATA; S.state = QZK_LS_HDR;
     S.through = sg.flags & QZK_INF_THROUGH_FLUSH;
     qzk_tok_out O;
-    O.count_only = false;
-    O.lp = lits + ts[slot].lit_off; O.sq = seqs + ts[slot].seq_off;
-    O.lrun = 0; O.nseq = 0; O.lw = 0; O.ln = 0; O.lq = 0; O.lbuf = 0; O.lq0 = O.lq1 = O.lq2 = 0;
-    O.s0 = O.s1 = O.s2 = O.s3 = O.s4 = O.s5 = O.s6 = 0;
+    qzk_tok_init(&O, lits + ts[slot].lit_off, seqs + ts[slot].seq_off, false);
     const uint32_t lit_cap = (uint32_t)QZK_SPEC_LITCAP(sg.out_cap, K) - 64, seq_cap = (uint32_t)QZK_SPEC_SEQCAP(sg.out_cap, K) - 10;
     const uint32_t limit_bits = 8u * (sg.pad != 0 && sg.pad < sg.in_len ? sg.pad : sg.in_len);
 
@@ -86,7 +83,6 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
     int seg_status = QZK_INF_ESPEC;                                 /* set to FINAL / FLUSH when the segment ends well */
     uint32_t why = 0;                                               /* developer aid: why the segment was handed back */
     bool seg_done = !live;                                          /* lane 0: nothing more to do for this segment */
-#define QZK_NLIT(O_) ((O_).lw + 8 * (O_).lq + (O_).ln)
 
     for (;;) {
         /* ---- 1. lane 0: block headers and stored blocks up to the next Huffman block ---- */
@@ -181,6 +177,7 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
                             b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
                             pw = qzk_ld64u(b->p + b->pos);
                             qzk_lane_symbol<false, false>(&S, &O, T, lroot, droot, (uint64_t)1 << 40);
+                            qzk_tok_round_flush(&O);        /* one symbol a trip here: whole words leave as they fill */
                         }
                     }
                     b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;
@@ -193,6 +190,7 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
                         if (st.kind == QZK_ST_RUN) {
                             qzk_lrefill(b);
                             qzk_lane_symbol<true, false>(&S, &O, T, lroot, droot, (uint64_t)1 << 40);
+                            qzk_tok_round_flush(&O);
                         }
                     }
                 }
@@ -255,7 +253,6 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
         C->nel = nel; C->pad = 0;
         res[sidx] = r;
     }
-#undef QZK_NLIT
 }
 
 #endif
