@@ -164,6 +164,30 @@ int qzd_lz4_compress_frames(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint
 int qzd_lz4_decompress_frames(qzd_ctx *ctx, const uint8_t *d_comp, uint8_t *d_out, const void *h_segs,
                               uint32_t nsegs, void *h_res);
 
+/* ------------------------------------------------------------------ one member from several GPUs
+ *
+ * What is left of the reference's in-order retire (doCompressOut: payload copy + crc32_combine + footer,
+ * src/qatzip.c:1691-1718) when the chunks of ONE logical buffer are deflated by several GPUs, one process each: rank r
+ * holds the raw-deflate stream of its contiguous chunk range (qzd_deflate_raw with last = 0, the last rank last = 1) and
+ * its CRC-32.  The root (rank 0) owns a window in its HBM that every rank maps through HIP IPC; qzd_shard_put() publishes
+ * a 32-byte record {raw bytes, compressed bytes, CRC-32}, derives the shard's offset from the records of the ranks before
+ * it and copies the shard there - a peer-to-peer write over xGMI, no host bounce, no collective;  qzd_shard_finish() on
+ * the root waits for all shards, folds the CRCs (crc32_combine) and closes the member: the 24-byte gzip-ext header with
+ * both sizes in front, CRC-32 + ISIZE behind - byte for byte what one qzCompress() call over the whole buffer writes.
+ * The launcher only has to hand the root's 64-byte handle to the other ranks (any transport; bench.py uses gloo).
+ * seq != 0 names the stream; the window is reused for the next one under the next number.  Waits give up after
+ * timeout_s seconds. */
+typedef struct qzd_shard qzd_shard;
+int qzd_shard_root_create(qzd_ctx *ctx, uint32_t world, uint64_t cap_bytes, uint8_t handle_out[64], qzd_shard **out);
+int qzd_shard_attach(qzd_ctx *ctx, uint32_t rank, uint32_t world, const uint8_t handle[64], uint64_t cap_bytes, qzd_shard **out);
+int qzd_shard_put(qzd_shard *s, const uint8_t *d_comp, uint64_t comp_len, uint64_t raw_len, uint32_t crc32, uint32_t seq,
+                  double timeout_s, uint64_t *h_offset);
+int qzd_shard_finish(qzd_shard *s, uint32_t seq, double timeout_s, uint8_t **d_stream, uint64_t *stream_len,
+                     uint32_t *crc_out, uint64_t *raw_total);
+void qzd_shard_close(qzd_shard *s);
+/* zlib crc32_combine(): CRC-32 of A || B from the CRC-32s of A and B and the length of B */
+uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+
 /* GPU time (ms) of the last qzd_inflate_stream call: [0] inflate kernels, [1] crc kernels, [2] the part of [0]
  * spent in the match-resolve phase of the two-phase path (0 on the wave-per-segment path), [3] reserved (0) */
 int qzd_last_inflate_timing(qzd_ctx *ctx, float ms[4]);

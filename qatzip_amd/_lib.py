@@ -54,6 +54,13 @@ def load(build_if_missing=True):
     L.qzd_lz4_compress_frames.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
     L.qzd_lz4_decompress_frames.argtypes = [vp, u8p, u8p, vp, C.c_uint32, vp]
     L.qzd_chunk_lens.argtypes = [vp, vp, C.c_uint32]
+    L.qzd_shard_root_create.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_char_p, C.POINTER(vp)]
+    L.qzd_shard_attach.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(vp)]
+    L.qzd_shard_put.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_uint64)]
+    L.qzd_shard_finish.argtypes = [vp, C.c_uint32, C.c_double, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint64)]
+    L.qzd_shard_close.argtypes = [vp]
+    L.qzd_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]; L.qzd_crc32_combine.restype = C.c_uint32
     _lib = L
     return L
 
@@ -73,7 +80,8 @@ def exported_symbols():
             "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing",
             "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats",
             "qzd_adler32_chunks", "qzd_adler32_combine", "qzd_stream_copy_peak", "qzd_deflate_raw_from_host",
-            "qzd_deflate_slots", "qzd_inflate_stream_to_host", "qzamd_async_stats"]
+            "qzd_deflate_slots", "qzd_inflate_stream_to_host", "qzamd_async_stats", "qzd_shard_root_create",
+            "qzd_shard_attach", "qzd_shard_put", "qzd_shard_finish", "qzd_shard_close", "qzd_crc32_combine"]
 
 
 class DevBuf:

@@ -75,6 +75,86 @@ def all_gather_records(pg, rank_record: bytes, world: int):
     return [struct.unpack("<QII", bytes(o.tolist())) for o in outs]
 
 
+def broadcast_bytes(pg, data: bytes, nbytes: int, src: int = 0) -> bytes:
+    """a small blob from rank `src` to everybody (gloo, CPU tensors): how the root's IPC handle travels"""
+    import torch
+    t = torch.zeros(nbytes, dtype=torch.uint8)
+    if data is not None:
+        t[:len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+    pg.broadcast(t, src)
+    return bytes(t.tolist())
+
+
+def one_stream(ctx, pg, rank, world, d_src, n, chunk, level=1, timeout_s=60.0, seq=1, verify=None):
+    """ONE gzip-ext member out of `world` shards of n bytes each (rank r holds shard r in d_src): every rank deflates its
+    shard on its GPU, the compressed shards travel to rank 0's HBM as peer copies (qzd_shard_*), rank 0 closes the member.
+    Returns a dict (rank 0: sizes, time, the member's bytes under "stream" if verify == "full"); other ranks: {}.
+    verify: None | "sample" (rank 0's own shard prefix against the oracle + trailer against the ranks' CPU CRCs) | "full"."""
+    import ctypes as C
+    import time
+    import zlib
+    import numpy as np
+    from . import _lib
+    L = ctx.L
+    cap = world * (_lib.max_deflate_len(n, chunk) + 64)
+    hbuf = C.create_string_buffer(64)
+    win = C.c_void_p()
+    if rank == 0:
+        ctx._chk(L.qzd_shard_root_create(ctx.h, world, cap, hbuf, C.byref(win)))
+    handle = broadcast_bytes(pg, hbuf.raw if rank == 0 else None, 64, 0) if world > 1 else hbuf.raw
+    if rank != 0:
+        ctx._chk(L.qzd_shard_attach(ctx.h, rank, world, handle, cap, C.byref(win)))
+    d_comp = ctx.alloc(_lib.max_deflate_len(n, chunk))
+    if pg is not None:
+        pg.barrier()
+    t0 = time.perf_counter()
+    clen, crcs = ctx.deflate_raw(d_src, n, chunk, level, 1 if rank == world - 1 else 0, d_comp)
+    crc = 0
+    for i, c in enumerate(crcs):                                # the shard's CRC-32 from its chunks' (crc32_combine algebra)
+        cl = min(chunk, n - i * chunk)
+        crc = int(c) if i == 0 else L.qzd_crc32_combine(crc, int(c), cl)
+    off = C.c_uint64(0)
+    ctx._chk(L.qzd_shard_put(win, d_comp.ptr, clen, n, crc, seq, timeout_s, C.byref(off)))
+    out = {}
+    if rank == 0:
+        dptr, slen, fcrc, raw = C.c_void_p(), C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+        ctx._chk(L.qzd_shard_finish(win, seq, timeout_s, C.byref(dptr), C.byref(slen), C.byref(fcrc), C.byref(raw)))
+        dt = time.perf_counter() - t0
+        out = {"ranks": world, "raw_bytes": raw.value, "member_bytes": slen.value, "ms": round(dt * 1e3, 2),
+               "GBps": round(raw.value / dt / 1e9, 2), "crc32": "%08x" % fcrc.value,
+               "transport": "peer copies into an IPC window in rank 0's HBM (xGMI between GPUs)"}
+    if pg is not None:
+        pg.barrier()
+    if verify:
+        host = d_src.download(n)
+        my_crc = zlib.crc32(host.tobytes()) & 0xffffffff
+        recs = all_gather_records(pg, pack_record(n, clen, my_crc), world) if world > 1 else [(n, clen, my_crc)]
+        if rank == 0:
+            _, raw_t, comp_t, crc_t = fold_records(recs)
+            member = np.empty(out["member_bytes"], np.uint8)
+            ctx._chk(L.qzd_d2h(ctx.h, member.ctypes.data, dptr.value, member.size))
+            mb = member.tobytes()
+            ok = mb[:4] == b"\x1f\x8b\x08\x04" and int.from_bytes(mb[16:20], "little") == raw_t and \
+                int.from_bytes(mb[20:24], "little") == comp_t and int.from_bytes(mb[-8:-4], "little") == crc_t and \
+                int.from_bytes(mb[-4:], "little") == (raw_t & 0xffffffff) and fcrc.value == crc_t
+            if ok:
+                import sys
+                import os
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+                import oracle_lib as O
+                k = min(n, 4 << 20) // chunk * chunk
+                if k:
+                    exp = O.sw_compress("RAW", host[:k].tobytes(), chunk, level, last=0 if (world > 1 or k < n) else 1, cap=k * 9 // 8 + 65536)[2]
+                    ok = mb[24:24 + len(exp)] == exp
+            out["verified"] = bool(ok)
+            if verify == "full":
+                out["stream"] = mb
+    ctx._chk(0)
+    L.qzd_shard_close(win)
+    d_comp.free()
+    return out
+
+
 def allreduce(pg, v: float, op: str) -> float:
     if pg is None:
         return v

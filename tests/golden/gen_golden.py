@@ -72,6 +72,30 @@ def main():
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(man, f, separators=(",", ":"))
     print(len(cases), "cases", os.path.getsize(os.path.join(HERE, "manifest.json")), "bytes")
+    gen_lz4_linked()
+
+
+def gen_lz4_linked():
+    """Frames for src_len > 64 KB: LZ4F_compressFrame links the blocks of one frame (FLG 0x4C, src/qatzip_sw.c:451-456) -
+    what a QZ_LZ4 session of the reference writes for such a call.  The frames themselves are committed (small), so the GPU
+    box can decode them and compare its own frames with them without liblz4."""
+    d = os.path.join(HERE, "lz4_linked")
+    os.makedirs(d, exist_ok=True)
+    idx = []
+    for kind, n, seed in (("text", 65537, 11), ("text", 200777, 12), ("runs", 131072, 13), ("records", 300000, 14),
+                          ("rand", 70000, 15), ("lzmix", 66000, 16), ("silesia", 262144 + 4097, 17), ("allA", 140000, 18),
+                          ("mod200", 65536 * 2 + 1, 19)):
+        src = datagen.gen_bytes(kind, n, seed)
+        out = R.sw_compress(R.FMT_LZ4, src, 65536, 1)
+        assert out[4] == 0x4c, hex(out[4])
+        name = "%s_%d_%d.lz4" % (kind, n, seed)
+        with open(os.path.join(d, name), "wb") as f:
+            f.write(out)
+        idx.append({"kind": kind, "n": n, "seed": seed, "file": name, "in_sha": datagen.sha(src), "out_len": len(out),
+                    "out_sha": datagen.sha(out)})
+    with open(os.path.join(d, "index.json"), "w") as f:
+        json.dump({"lz4": R.lz4lib().LZ4_versionString().decode(), "frames": idx}, f, indent=1)
+    print("lz4 linked frames:", len(idx), sum(i["out_len"] for i in idx), "bytes")
 
 
 if __name__ == "__main__":
