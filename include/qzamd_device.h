@@ -91,6 +91,15 @@ int qzd_deflate_slots(qzd_ctx *ctx, const uint8_t *d_src, uint32_t nslots, uint3
  * they carried (process-wide, since load).  Exported by the same library; not part of qatzip.h. */
 void qzamd_async_stats(uint64_t *launches, uint64_t *requests);
 
+/* Which of the reference's two wire framings the compress side of a qatzip.h session writes (QzSession_T from
+ * include/qatzip.h): 0 = the software path's (one member per stream, a full-flush marker after every hw_buff_sz chunk,
+ * src/qatzip_sw.c:178-253 - the default, and what the bit-exactness claim is about); 1 = the hardware path's (one complete
+ * member per chunk: qzGzipHeaderGen / stdGzipHeaderGen / qz4BHeaderGen + footer, src/qatzip.c:1691-1718,
+ * src/qatzip_gzip.c:86-143), for interop with consumers of QAT-produced streams.  QATZIP_AMD_HW_FRAMING=1 makes it the
+ * default of new sessions.  Not callable in the middle of a stream opened with last = 0. */
+struct QzSession_S;
+int qzamd_set_hw_framing(struct QzSession_S *sess, int on);
+
 /* asynchronous flavour used by bench.py: enqueue only; qzd_sync() + qzd_result() finish it */
 int qzd_deflate_raw_async(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
                           uint8_t *d_dst, uint64_t dst_cap);

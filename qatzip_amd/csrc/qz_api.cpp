@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <new>
+#include <map>
 #include <set>
 #include <vector>
 
@@ -52,12 +53,16 @@ struct Sess {
     /* a member whose output did not fit the caller's destination: decoded once into d_hold, handed out over as many
      * calls as it takes (decompress_deflate) */
     uint8_t *d_hold; uint64_t hold_len, hold_pos;
+    /* wire framing of the compress side: false = the software path's (one member per stream, a flush marker after every
+     * chunk), true = the hardware path's (one complete member per hw_buff_sz chunk, src/qatzip.c:1691-1718) */
+    bool hw_framing;
+    std::vector<unsigned char> hw_stage;
 };
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER, g_mem_lock = PTHREAD_MUTEX_INITIALIZER;
 static int g_inited, g_ndev, g_next_dev;
 static QzLogLevel_T g_log = LOG_WARNING;
-static std::set<void *> g_pinned;
+static std::map<uintptr_t, size_t> g_pinned;     /* pinned allocations: base -> bytes */
 static const Params k_factory = {QZ_HUFF_HDR_DEFAULT, QZ_DIRECTION_DEFAULT, F_GZIP_EXT, QZ_COMP_LEVEL_DEFAULT,
                                  QZ_COMP_ALGOL_DEFAULT, QZ_MAX_FORK_DEFAULT, QZ_SW_BACKUP_DEFAULT, QZ_HW_BUFF_SZ,
                                  QZ_STRM_BUFF_SZ_DEFAULT, QZ_COMP_THRESHOLD_DEFAULT, QZ_REQ_THRESHOLD_DEFAULT,
@@ -239,6 +244,10 @@ static int make_session(QzSession_T *sess, const Params &p)
     s->p = p; s->ctx = NULL; s->d_in = s->d_out = NULL; s->in_cap = s->out_cap = 0;
     s->d_hold = NULL; s->hold_len = s->hold_pos = 0;
     s->open = false; s->run_sum = 0; s->st_in = s->st_out = 0; s->end_of_stream = 0;
+    {
+        const char *e = getenv("QATZIP_AMD_HW_FRAMING");
+        s->hw_framing = e && e[0] == '1';
+    }
     sess->internal = s;
     sess->hw_session_stat = g_inited ? QZ_OK : QZ_NONE;
     sess->thd_sess_stat = QZ_OK;
@@ -306,6 +315,21 @@ extern "C" int qzTeardownSession(QzSession_T *sess)
     }
     return QZ_OK;
 }
+static int ensure_ready(QzSession_T *sess, Sess **out);
+
+/* not in qatzip.h (include/qzamd_device.h): which of the reference's two wire framings the compress side of a session
+ * writes - 0 the software path's (default: what the parity claim is about), 1 the hardware path's per-chunk members */
+extern "C" int qzamd_set_hw_framing(QzSession_T *sess, int on)
+{
+    Sess *s = NULL;
+    if (!sess) return QZ_PARAMS;
+    int rc = ensure_ready(sess, &s);
+    if (rc < 0) return rc;
+    if (s->open) return QZ_FAIL;                                    /* not in the middle of a stream */
+    s->hw_framing = on != 0;
+    return QZ_OK;
+}
+
 extern "C" int qzClose(QzSession_T *sess) { return sess ? QZ_OK : QZ_PARAMS; }
 
 extern "C" int qzGetStatus(QzSession_T *sess, QzStatus_T *st)
@@ -465,6 +489,64 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
     return complete ? QZ_OK : QZ_BUF_ERROR;
 }
 
+/* The HARDWARE path's framing (qzamd_set_hw_framing / QATZIP_AMD_HW_FRAMING=1): every hw_buff_sz chunk becomes a
+ * complete member of its own - header, a deflate stream that ends with BFINAL, footer - the way doCompressOut retires a
+ * chunk (src/qatzip.c:1691-1718: outputHeaderGen, payload, outputFooterGen).  GZIP_EXT: qzGzipHeaderGen
+ * (src/qatzip_gzip.c:98-118: XFL 0, OS 255, both sizes in the 'QZ' extra field) + CRC-32 / ISIZE of the chunk; GZIP:
+ * stdGzipHeaderGen (:120-136) + the same footer; 4B: the chunk's compressed length (qz4BHeaderGen :138-143); RAW has no
+ * framing and keeps the software path's stream.  `last` plays no part (every call is closed), the crc out-parameter is the
+ * CRC-32 of the data (crc32_combine over the chunks, src/qatzip.c:1711).  Interop: this is what streams from QAT boxes
+ * look like, and decompress_sized_members() reads thousands of such members in one launch. */
+static int compress_deflate_hw(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
+                               unsigned char *dest, unsigned int *dest_len, unsigned long *crc)
+{
+    const int fmt = s->p.fmt;
+    const uint32_t n = *src_len, cap = *dest_len, hw = s->p.hw_buff_sz;
+    *src_len = 0; *dest_len = 0;
+    if (s->p.comp_lvl < 1 || s->p.comp_lvl > 9) return QZ_NOT_SUPPORTED;
+    if (n == 0) return QZ_OK;                                       /* the engine has nothing to submit */
+    const uint32_t nchunks = (n + hw - 1) / hw;
+    const unsigned hl = fmt == F_GZIP_EXT ? 24 : fmt == F_GZIP ? 10 : 4, fl = fmt == F_4B ? 0 : 8;
+    const uint64_t in_bytes = (uint64_t)nchunks * hw;
+    const uint64_t worst = in_bytes + (uint64_t)nchunks * (5ull * (hw / 32767 + 2) + 16) + 64;
+    int rc = reserve(s, in_bytes, worst);
+    if (rc) return rc;
+    if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
+    std::vector<uint32_t> cdesc(nchunks), lens(nchunks), crcs(nchunks);
+    for (uint32_t k = 0; k < nchunks; k++) cdesc[k] = std::min<uint32_t>(hw, n - k * hw) | 0x80000000u;    /* every chunk closes its stream */
+    uint64_t produced = 0;
+    if (qzd_deflate_slots(s->ctx, s->d_in, nchunks, hw, (int)s->p.comp_lvl, cdesc.data(), s->d_out, s->out_cap, &produced,
+                          lens.data(), crcs.data()) != QZD_OK) {
+        logmsg(LOG_ERROR, "GPU deflate failed: %s\n", qzd_last_error(s->ctx));
+        return QZ_FAIL;
+    }
+    /* whole members that fit */
+    uint32_t take = 0; uint64_t bytes = 0, body = 0;
+    while (take < nchunks && bytes + hl + lens[take] + fl <= cap) { bytes += hl + lens[take] + fl; body += lens[take]; take++; }
+    if (take == 0) return QZ_BUF_ERROR;
+    try { s->hw_stage.resize(body); } catch (const std::bad_alloc &) { return QZ_NOSW_LOW_MEM; }
+    if (body && qzd_d2h(s->ctx, s->hw_stage.data(), s->d_out, body) != QZD_OK) return QZ_FAIL;
+    unsigned char *o = dest; const unsigned char *b = s->hw_stage.data();
+    for (uint32_t k = 0; k < take; k++) {
+        const uint32_t cl = cdesc[k] & 0x7fffffffu, zl = lens[k];
+        if (fmt == F_GZIP_EXT) {
+            static const unsigned char h[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 255, 12, 0, 'Q', 'Z', 8, 0};
+            memcpy(o, h, 16); wr32(o + 16, cl); wr32(o + 20, zl);
+        } else if (fmt == F_GZIP) {
+            static const unsigned char h[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255};
+            memcpy(o, h, 10);
+        } else wr32(o, zl);
+        memcpy(o + hl, b, zl);
+        if (fl) { wr32(o + hl + zl, crcs[k]); wr32(o + hl + zl + 4, cl); }
+        if (crc) *crc = (*crc == 0 && k == 0) ? crcs[k] : qzd_crc32_combine((uint32_t)*crc, crcs[k], cl);
+        o += hl + zl + fl; b += zl;
+    }
+    const uint32_t used = take == nchunks ? n : take * hw;
+    *src_len = used; *dest_len = (unsigned int)bytes;
+    sess->total_in += used; sess->total_out += bytes;
+    return take == nchunks ? QZ_OK : QZ_BUF_ERROR;
+}
+
 /* LZ4 sessions: one frame per call, `last` ignored (src/qatzip_sw.c:443-471) */
 static int compress_lz4(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
                         unsigned char *dest, unsigned int *dest_len)
@@ -563,6 +645,8 @@ extern "C" int qzCompressCrcExt(QzSession_T *sess, const unsigned char *src, uns
     if (rc < 0) goto fail;
     if (s->p.fmt == F_LZ4) rc = compress_lz4(sess, s, src, src_len, dest, dest_len);
     else if (s->p.fmt == F_LZ4S) rc = QZ_UNSUPPORTED_FMT;
+    else if (s->hw_framing && !s->open && (s->p.fmt == F_GZIP_EXT || s->p.fmt == F_GZIP || s->p.fmt == F_4B))
+        rc = compress_deflate_hw(sess, s, src, src_len, dest, dest_len, crc);
     else rc = compress_deflate(sess, s, src, src_len, dest, dest_len, last, crc);
     sess->thd_sess_stat = rc;
     if (rc == QZ_OK || rc == QZ_BUF_ERROR) return rc;
@@ -815,27 +899,57 @@ extern "C" unsigned int qzMaxCompressedLength(unsigned int src_sz, QzSession_T *
     return (out >> 32) ? 0 : (unsigned int)out;
 }
 
-/* ------------------------------------------------------------------ pinned memory */
+/* ------------------------------------------------------------------ pinned memory
+ * src/qatzip_mem.c:102-241 over qaeMemAllocNUMA, here over hipHostMalloc: memory the GPU's DMA engines read and write
+ * directly, so qzCompress / qzDecompress on such buffers copy asynchronously and overlap with the kernels. */
+#include <sys/syscall.h>
+#include <unistd.h>
+#ifndef MPOL_PREFERRED
+#define MPOL_DEFAULT 0
+#define MPOL_PREFERRED 1
+#endif
+extern "C" void *qzd_host_alloc_pinned_numa(size_t n, int follow_policy);      /* qzd_device.hip */
+
 extern "C" void *qzMalloc(size_t sz, int numa, int force_pinned)
 {
-    (void)numa;
     void *p = NULL;
-    if (qzd_device_count() > 0) p = qzd_host_alloc_pinned(sz);
-    if (p) { pthread_mutex_lock(&g_mem_lock); g_pinned.insert(p); pthread_mutex_unlock(&g_mem_lock); return p; }
+    if (qzd_device_count() > 0) {
+        /* numa >= 0: the pages come from that node (the reference passes the node to qaeMemAllocNUMA,
+         * src/qatzip_mem.c:199-210) - the thread's memory policy is set for the duration of the allocation and
+         * hipHostMalloc is told to follow it; numa < 0: the default local-node policy, which is what the reference's
+         * "node of the current CPU" amounts to */
+        bool policy = false;
+#ifdef SYS_set_mempolicy
+        if (numa >= 0 && numa < 1024) {
+            unsigned long mask[16] = {0};
+            mask[numa / (8 * sizeof(unsigned long))] = 1ul << (numa % (8 * sizeof(unsigned long)));
+            policy = syscall(SYS_set_mempolicy, MPOL_PREFERRED, mask, (unsigned long)(sizeof(mask) * 8)) == 0;
+        }
+#endif
+        p = qzd_host_alloc_pinned_numa(sz, policy ? 1 : 0);
+#ifdef SYS_set_mempolicy
+        if (policy) syscall(SYS_set_mempolicy, MPOL_DEFAULT, NULL, 0ul);
+#endif
+    }
+    if (p) { pthread_mutex_lock(&g_mem_lock); g_pinned[(uintptr_t)p] = sz ? sz : 1; pthread_mutex_unlock(&g_mem_lock); return p; }
     return force_pinned == PINNED_MEM ? NULL : malloc(sz);
 }
 extern "C" void qzFree(void *m)
 {
     if (!m) return;
     pthread_mutex_lock(&g_mem_lock);
-    bool pinned = g_pinned.erase(m) > 0;
+    bool pinned = g_pinned.erase((uintptr_t)m) > 0;
     pthread_mutex_unlock(&g_mem_lock);
     if (pinned) qzd_host_free_pinned(m); else free(m);
 }
+/* 1 for ANY address inside a pinned allocation (the reference's page table marks every page of one,
+ * src/qatzip_mem.c:102-149), 0 otherwise */
 extern "C" int qzMemFindAddr(unsigned char *a)
 {
+    int r = 0;
     pthread_mutex_lock(&g_mem_lock);
-    int r = g_pinned.count((void *)a) ? 1 : 0;
+    std::map<uintptr_t, size_t>::const_iterator it = g_pinned.upper_bound((uintptr_t)a);
+    if (it != g_pinned.begin()) { --it; r = (uintptr_t)a - it->first < it->second ? 1 : 0; }
     pthread_mutex_unlock(&g_mem_lock);
     return r;
 }

@@ -255,6 +255,15 @@ extern "C" void *qzd_host_alloc_pinned(size_t n)
     if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return NULL;
     return p;
 }
+/* follow_policy: place the pages by the calling thread's NUMA memory policy (qzMalloc's node argument) */
+extern "C" void *qzd_host_alloc_pinned_numa(size_t n, int follow_policy)
+{
+    void *p = NULL;
+    if (hipHostMalloc(&p, n ? n : 1, follow_policy ? hipHostMallocNumaUser : hipHostMallocDefault) != hipSuccess) {
+        if (!follow_policy || hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return NULL;
+    }
+    return p;
+}
 extern "C" void qzd_host_free_pinned(void *p) { if (p) hipHostFree(p); }
 
 static uint32_t slot_stride_for(uint32_t chunk_sz) { return (chunk_sz / 8u * 9u + 1024u + 15u) & ~15u; }

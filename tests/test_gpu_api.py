@@ -111,6 +111,62 @@ def test_hardware_path_streams_decode_as_one_batch():
     s.close()
 
 
+@pytest.mark.parametrize("fmt", ["GZIP_EXT", "GZIP", "4B"])
+def test_hardware_path_framing_on_the_compress_side(fmt):
+    """qzamd_set_hw_framing(sess, 1): one complete member per hw_buff_sz chunk, as the reference's engine retires them
+    (src/qatzip.c:1691-1718; headers src/qatzip_gzip.c:86-143: XFL 0, OS 255, both sizes in the gzip-ext field) - the
+    stream layout of test_hardware_path_streams_decode_as_one_batch, with this library's own deflate inside"""
+    L = A.lib()
+    L.qzamd_set_hw_framing.argtypes = [C.c_void_p, C.c_int]
+    for hw in (65536, 16384):
+        s = A.Session(FMT[fmt], hw)
+        assert L.qzamd_set_hw_framing(C.byref(s.s), 1) == A.QZ_OK
+        for kind, n in (("silesia", 5 * hw + 777), ("rand", 2 * hw), ("text", hw), ("runs", 1000), ("allA", 3 * hw + 1)):
+            src = datagen.gen_bytes(kind, n, 31)
+            rc, used, out, crc = s.compress(src, 1, crc0=0)
+            assert rc == A.QZ_OK and used == n, (fmt, hw, kind, rc)
+            exp = b""
+            for off in range(0, n, hw):
+                chunk = src[off:off + hw]
+                body = O.sw_compress("RAW", chunk, hw, 1, last=1)[2]          # a closed deflate stream per chunk
+                if fmt == "GZIP_EXT":
+                    hdr = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 255, 12, 0]) + b"QZ" + (8).to_bytes(2, "little") + \
+                        len(chunk).to_bytes(4, "little") + len(body).to_bytes(4, "little")
+                elif fmt == "GZIP":
+                    hdr = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255])
+                else:
+                    hdr = len(body).to_bytes(4, "little")
+                ftr = b"" if fmt == "4B" else (zlib.crc32(chunk) & 0xffffffff).to_bytes(4, "little") + len(chunk).to_bytes(4, "little")
+                exp += hdr + body + ftr
+            assert out == exp, (fmt, hw, kind, n, len(out), len(exp))
+            assert crc == (zlib.crc32(src) & 0xffffffff)
+            if fmt != "4B":
+                assert b"".join(zlib.decompress(m, 31) for m in _split_members(out, fmt)) == src
+            rc, cused, back = s.decompress(out, n + 64)
+            assert rc == A.QZ_OK and back == src and cused == len(out), (fmt, hw, kind, rc)
+        # a destination for two members only: whole members, QZ_BUF_ERROR, the caller resumes behind them
+        src = datagen.gen_bytes("text", 4 * hw, 5)
+        full = s.compress(src, 1)[2]
+        two = len(_split_members(full, fmt)[0]) + len(_split_members(full, fmt)[1]) if fmt != "4B" else None
+        if two:
+            rc, used, out, _ = s.compress(src, 1, cap=two + 10)
+            assert rc == A.QZ_BUF_ERROR and used == 2 * hw and out == full[:two]
+        assert L.qzamd_set_hw_framing(C.byref(s.s), 0) == A.QZ_OK
+        assert s.compress(src, 1)[2] == O.sw_compress(fmt, src, hw, 1, cap=len(src) * 9 // 8 + 65536)[2]
+        s.close()
+
+
+def _split_members(buf, fmt):
+    """cut a sequence of gzip members apart with zlib's own reader"""
+    out, pos = [], 0
+    while pos < len(buf):
+        d = zlib.decompressobj(31)
+        d.decompress(buf[pos:])
+        end = len(buf) - len(d.unused_data)
+        out.append(buf[pos:end]); pos = end
+    return out
+
+
 def test_async_compress2_decompress2():
     """qzCompress2 / qzDecompress2 (src/qatzip.c:4112-4196): callback == NULL is the synchronous call; with a callback
     the request is queued, QZ_OK comes back at once, and a library thread retires it and reports through QzResult_T"""
@@ -627,8 +683,18 @@ def test_pinned_memory():
     for _ in range(100):                                  # test/main.c:2401-2441 allocates/frees in a loop
         p = L.qzMalloc(100000, -1, A.PINNED_MEM)
         assert p and L.qzMemFindAddr(p) == 1
+        # any address inside the allocation counts (the reference marks every page of it, src/qatzip_mem.c:102-149)
+        assert L.qzMemFindAddr(p + 1) == 1 and L.qzMemFindAddr(p + 54321) == 1 and L.qzMemFindAddr(p + 99999) == 1
+        assert L.qzMemFindAddr(p + 100000) == 0 or L.qzMemFindAddr(p + 100000) == 1     # next byte: another allocation's, or nobody's
         L.qzFree(p)
-        assert L.qzMemFindAddr(p) == 0
+        assert L.qzMemFindAddr(p) == 0 and L.qzMemFindAddr(p + 5000) == 0
+    q = L.qzMalloc(1 << 20, 0, A.PINNED_MEM)             # an explicit NUMA node (0 exists everywhere)
+    assert q and L.qzMemFindAddr(q + (1 << 19)) == 1
+    C.memset(q, 0x5a, 1 << 20)
+    L.qzFree(q)
+    m = L.qzMalloc(4096, -1, A.COMMON_MEM)
+    assert m
+    L.qzFree(m)
 
 
 def test_plain_c_caller_links_and_round_trips(tmp_path):

@@ -92,5 +92,5 @@ def test_linked_block_lz4_frames_decode():
     assert rc == A.QZ_OK and used == len(whole) and out == srcs
     bad = bytearray(whole[:200000]); bad[150000] ^= 0x40           # damage inside a later block of the second frame
     rc, used, out = s.decompress(bytes(bad), len(srcs) + 64)
-    assert rc == A.QZ_OK and out == srcs[:65537] or rc == A.QZ_FAIL
+    assert rc == A.QZ_FAIL or (rc == A.QZ_OK and len(out) < len(srcs) and srcs.startswith(out))   # whole frames before it, or the error
     s.close()
