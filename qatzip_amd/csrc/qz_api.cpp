@@ -635,14 +635,23 @@ static int decompress_lz4(QzSession_T *sess, Sess *s, const unsigned char *src, 
     return (ti < n && to >= cap) ? QZ_OK : QZ_OK;
 }
 
-extern "C" int qzCompressCrcExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
-                                unsigned int *dest_len, unsigned int last, unsigned long *crc, uint64_t *ext_rc)
+/* Small synchronous calls from many threads share launches too (below: sync_via_queue) */
+static bool sync_via_queue(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                           unsigned int *dest_len, unsigned long *crc, bool compress, int *rc_out);
+
+/* the call itself, never through the queue (the queue's own fallback comes here) */
+static int compress_direct(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                           unsigned int *dest_len, unsigned int last, unsigned long *crc, uint64_t *ext_rc, bool may_queue)
 {
     int rc; Sess *s = NULL;
     if (!sess || !src || !src_len || !dest || !dest_len || (last != 0 && last != 1)) { rc = QZ_PARAMS; goto fail; }
     if (ext_rc) *ext_rc = 0;
     rc = ensure_ready(sess, &s);
     if (rc < 0) goto fail;
+    if (may_queue && last == 1 && sync_via_queue(sess, s, src, src_len, dest, dest_len, crc, true, &rc)) {
+        if (rc == QZ_OK || rc == QZ_BUF_ERROR) return rc;
+        goto fail;
+    }
     if (s->p.fmt == F_LZ4) rc = compress_lz4(sess, s, src, src_len, dest, dest_len);
     else if (s->p.fmt == F_LZ4S) rc = QZ_UNSUPPORTED_FMT;
     else if (s->hw_framing && !s->open && (s->p.fmt == F_GZIP_EXT || s->p.fmt == F_GZIP || s->p.fmt == F_4B))
@@ -655,6 +664,9 @@ fail:
     if (dest_len) *dest_len = 0;
     return rc;
 }
+extern "C" int qzCompressCrcExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                                unsigned int *dest_len, unsigned int last, unsigned long *crc, uint64_t *ext_rc)
+{ return compress_direct(sess, src, src_len, dest, dest_len, last, crc, ext_rc, true); }
 extern "C" int qzCompressExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
                              unsigned int *dest_len, unsigned int last, uint64_t *ext_rc)
 {
@@ -862,8 +874,8 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
     return ret;
 }
 
-extern "C" int qzDecompressCrcExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
-                                  unsigned int *dest_len, unsigned long *crc, uint64_t *ext_rc)
+static int decompress_direct(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                             unsigned int *dest_len, unsigned long *crc, uint64_t *ext_rc, bool may_queue)
 {
     int rc; Sess *s = NULL;
     if (!sess || !src || !src_len || !dest || !dest_len) { rc = QZ_PARAMS; goto fail; }
@@ -871,6 +883,10 @@ extern "C" int qzDecompressCrcExt(QzSession_T *sess, const unsigned char *src, u
     if (*src_len == 0) { *dest_len = 0; return QZ_OK; }
     rc = ensure_ready(sess, &s);
     if (rc < 0) goto fail;
+    if (may_queue && sync_via_queue(sess, s, src, src_len, dest, dest_len, crc, false, &rc)) {
+        if (rc == QZ_OK || rc == QZ_BUF_ERROR) return rc;
+        goto fail;
+    }
     if (s->p.fmt == F_LZ4) rc = decompress_lz4(sess, s, src, src_len, dest, dest_len);
     else if (s->p.fmt == F_LZ4S) rc = QZ_UNSUPPORTED_FMT;
     else rc = decompress_deflate(sess, s, src, src_len, dest, dest_len, crc);
@@ -881,6 +897,9 @@ fail:
     if (dest_len) *dest_len = 0;
     return rc;
 }
+extern "C" int qzDecompressCrcExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                                  unsigned int *dest_len, unsigned long *crc, uint64_t *ext_rc)
+{ return decompress_direct(sess, src, src_len, dest, dest_len, crc, ext_rc, true); }
 extern "C" int qzDecompress(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest, unsigned int *dest_len)
 { return qzDecompressCrcExt(sess, src, src_len, dest, dest_len, NULL, NULL); }
 extern "C" int qzDecompressExt(QzSession_T *sess, const unsigned char *src, unsigned int *src_len, unsigned char *dest, unsigned int *dest_len, uint64_t *ext_rc)
@@ -1074,7 +1093,16 @@ extern "C" int qzEndStream(QzSession_T *sess, QzStream_T *strm)
  * QzResult_T.crc); otherwise the request is queued and a library thread retires it and calls callback(res)
  * (the reference's ring + consumer thread, src/qatzip.c:3103-4110).  Here: one FIFO and one consumer thread per
  * process; requests retire in submission order, so a session's requests never run concurrently. */
-struct AsyncReq { QzSession_T *sess; const unsigned char *src; unsigned char *dest; qzAsyncCallbackFn cb; QzResult_T *res; bool compress; };
+struct AsyncReq { QzSession_T *sess; const unsigned char *src; unsigned char *dest; qzAsyncCallbackFn cb; QzResult_T *res; bool compress;
+                  unsigned long *crcp;      /* a synchronous caller's crc in/out parameter (asynchronous ones carry it in res->crc) */
+                  volatile int *done; };    /* a synchronous caller waits for this flag instead of a callback */
+static pthread_cond_t g_aq_done = PTHREAD_COND_INITIALIZER;
+static unsigned long *req_crc(const AsyncReq &q)
+{
+    if (q.crcp) return q.crcp;
+    QzResult_T *r = q.res;
+    return (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
+}
 static pthread_mutex_t g_aq_lock = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_aq_more = PTHREAD_COND_INITIALIZER, g_aq_idle = PTHREAD_COND_INITIALIZER;
 static std::vector<AsyncReq> g_aq;          /* pending, oldest first */
@@ -1082,11 +1110,11 @@ static size_t g_aq_head = 0;
 static std::vector<QzSession_T *> g_aq_running;   /* sessions of the requests being executed (one launch can carry many) */
 static bool g_aq_thread = false;
 
-static int run_sync2(QzSession_T *sess, const unsigned char *src, unsigned char *dest, QzResult_T *r, bool compress)
+static int run_sync2(QzSession_T *sess, const unsigned char *src, unsigned char *dest, QzResult_T *r, bool compress, unsigned long *crcp = NULL)
 {
-    unsigned long *crc = (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
-    int rc = compress ? qzCompressCrcExt(sess, src, &r->src_len, dest, &r->dest_len, 1, crc, &r->ext_rc)
-                      : qzDecompressCrcExt(sess, src, &r->src_len, dest, &r->dest_len, crc, &r->ext_rc);
+    unsigned long *crc = crcp ? crcp : (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
+    int rc = compress ? compress_direct(sess, src, &r->src_len, dest, &r->dest_len, 1, crc, &r->ext_rc, false)
+                      : decompress_direct(sess, src, &r->src_len, dest, &r->dest_len, crc, &r->ext_rc, false);
     r->status = rc;
     return rc;
 }
@@ -1163,10 +1191,10 @@ static bool compress_batch(const std::vector<AsyncReq> &run, const std::vector<S
         for (uint32_t k = 0; k < nch; k++) body += lens[k0 + k];
         const uint64_t bpos = pos; pos += body;
         if (hl + body + fl > r->dest_len) {                     /* too small for the whole member: the one-call path knows the partial-progress rules */
-            run_sync2(run[i].sess, run[i].src, dest, r, true);
+            run_sync2(run[i].sess, run[i].src, dest, r, true, run[i].crcp);
             continue;
         }
-        unsigned long *crc = (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
+        unsigned long *crc = req_crc(run[i]);
         write_header(dest, fmt, lvl);
         memcpy(dest + hl, stage + bpos, body);
         uint32_t sum = 0, done = 0;
@@ -1236,11 +1264,11 @@ static bool decompress_batch(const std::vector<AsyncReq> &run, const std::vector
         const unsigned char *tr = run[i].src + pay[i] + segs[i].in_len;
         const uint32_t usz = segs[i].out_cap;
         if (res[i].status != 0 || res[i].out_len != usz || res[i].in_used != segs[i].in_len || rd32(tr) != c32[i] || rd32(tr + 4) != usz) {
-            run_sync2(run[i].sess, run[i].src, run[i].dest, r, false);      /* the one-call path reports what is wrong with it */
+            run_sync2(run[i].sess, run[i].src, run[i].dest, r, false, run[i].crcp);      /* the one-call path reports what is wrong with it */
             continue;
         }
         memcpy(run[i].dest, stage + segs[i].out_off, usz);
-        unsigned long *crc = (r->crc && (r->crc->valid_flags & QZ_CRC32_VALID_MASK)) ? (unsigned long *)r->crc->in_crc.crc_32 : NULL;
+        unsigned long *crc = req_crc(run[i]);
         if (crc) *crc = *crc == 0 ? c32[i] : qzd_crc32_combine((uint32_t)*crc, c32[i], usz);
         r->dest_len = usz; r->ext_rc = 0; r->status = QZ_OK;        /* src_len: the whole member */
         ss[i]->end_of_stream = 1;
@@ -1299,14 +1327,16 @@ static void *async_consumer(void *)
             catch (const std::bad_alloc &) { done = false; }        /* out of host memory for the batch: one request at a time */
             if (done) { pthread_mutex_lock(&g_aq_lock); g_aq_batches++; g_aq_batched_reqs += run.size(); pthread_mutex_unlock(&g_aq_lock); }
         }
-        if (!done) for (size_t i = 0; i < run.size(); i++) run_sync2(run[i].sess, run[i].src, run[i].dest, run[i].res, run[i].compress);
+        if (!done) for (size_t i = 0; i < run.size(); i++) run_sync2(run[i].sess, run[i].src, run[i].dest, run[i].res, run[i].compress, run[i].crcp);
         /* every request of the batch is finished before the first callback runs, and none of their sessions counts as
          * running any more: a callback may tear down its own session, or another one of the same batch */
         pthread_mutex_lock(&g_aq_lock);
         g_aq_running.clear();
+        for (size_t i = 0; i < run.size(); i++) if (run[i].done) *run[i].done = 1;      /* synchronous callers of this batch */
         pthread_cond_broadcast(&g_aq_idle);
+        pthread_cond_broadcast(&g_aq_done);
         pthread_mutex_unlock(&g_aq_lock);
-        for (size_t i = 0; i < run.size(); i++) run[i].cb(run[i].res);
+        for (size_t i = 0; i < run.size(); i++) if (run[i].cb) run[i].cb(run[i].res);
     }
     return NULL;
 }
@@ -1329,7 +1359,8 @@ static void async_drain(QzSession_T *sess)
         for (size_t i = 0; i < dropped.size(); i++) {
             QzResult_T *r = dropped[i].res;
             r->status = QZ_FAIL; r->src_len = 0; r->dest_len = 0;
-            dropped[i].cb(r);
+            if (dropped[i].cb) dropped[i].cb(r);
+            if (dropped[i].done) { pthread_mutex_lock(&g_aq_lock); *dropped[i].done = 1; pthread_cond_broadcast(&g_aq_done); pthread_mutex_unlock(&g_aq_lock); }
         }
         return;
     }
@@ -1343,19 +1374,65 @@ static void async_drain(QzSession_T *sess)
     pthread_mutex_unlock(&g_aq_lock);
 }
 
+static bool consumer_started_locked()
+{
+    if (!g_aq_thread) {
+        pthread_t th;
+        if (pthread_create(&th, NULL, async_consumer, NULL) != 0) return false;
+        pthread_detach(th);
+        g_aq_tid = th; g_aq_thread = true;
+    }
+    return true;
+}
+
+/* A synchronous qzCompress / qzDecompress of a small request does what the asynchronous API does and waits: alone it
+ * would occupy ONE wave of the GPU for milliseconds (a chunk's parse is serial); queued, the calls that many threads make
+ * at the same time - the reference's perf harness issues one qzCompress per block from every thread,
+ * test/main.c:2175-2299, and its engine keeps <= 32 chunks in flight per instance, src/qatzip_internal.h:65-70 - share
+ * launches.  Only requests the batch paths can carry whole (closed members of a deflate format; single sized gzip-ext
+ * members to decode); everything else, and everything when QATZIP_AMD_SYNC_COALESCE=0, runs as its own call. */
+#define AQ_SYNC_MAX_REQ (1u << 20)
+static bool sync_via_queue(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len, unsigned char *dest,
+                           unsigned int *dest_len, unsigned long *crc, bool compress, int *rc_out)
+{
+    static const bool enabled = !(getenv("QATZIP_AMD_SYNC_COALESCE") && getenv("QATZIP_AMD_SYNC_COALESCE")[0] == '0');
+    if (!enabled || *src_len > AQ_SYNC_MAX_REQ || *src_len == 0) return false;
+    if (g_aq_thread && pthread_equal(pthread_self(), g_aq_tid)) return false;      /* a callback calling back in */
+    const int f = s->p.fmt;
+    if (compress) {
+        if (!(f == F_GZIP || f == F_GZIP_EXT || f == F_RAW || f == F_4B) || s->open || s->hw_framing) return false;
+        if (s->p.comp_lvl < 1 || s->p.comp_lvl > 9) return false;
+    } else {
+        if (f != F_GZIP_EXT || s->d_hold || s->p.stop_at_stream_end) return false;
+        uint32_t es = 0, ed = 0;
+        const int hl = parse_header(F_GZIP_EXT, src, *src_len, &es, &ed);
+        if (hl < 0 || es == 0 || ed == 0 || (uint64_t)hl + ed + 8 != *src_len || es > *dest_len || es > AQ_BATCH_MAX_REQ) return false;
+    }
+    QzResult_T r;
+    memset(&r, 0, sizeof(r));
+    r.src_len = *src_len; r.dest_len = *dest_len;
+    volatile int done = 0;
+    pthread_mutex_lock(&g_aq_lock);
+    if (!consumer_started_locked()) { pthread_mutex_unlock(&g_aq_lock); return false; }
+    AsyncReq q = { sess, src, dest, NULL, &r, compress, crc, &done };
+    g_aq.push_back(q);
+    pthread_cond_signal(&g_aq_more);
+    while (!done) pthread_cond_wait(&g_aq_done, &g_aq_lock);
+    pthread_mutex_unlock(&g_aq_lock);
+    *src_len = r.src_len; *dest_len = r.dest_len;
+    *rc_out = r.status;
+    sess->thd_sess_stat = r.status;
+    return true;
+}
+
 static int submit2(QzSession_T *sess, const unsigned char *src, unsigned char *dest, qzAsyncCallbackFn cb, QzResult_T *r, bool compress)
 {
     if (!r) return QZ_PARAMS;
     if (!cb) return run_sync2(sess, src, dest, r, compress);
     if (!sess || !src || !dest) return QZ_PARAMS;
     pthread_mutex_lock(&g_aq_lock);
-    if (!g_aq_thread) {
-        pthread_t th;
-        if (pthread_create(&th, NULL, async_consumer, NULL) != 0) { pthread_mutex_unlock(&g_aq_lock); return QZ_FAIL; }
-        pthread_detach(th);
-        g_aq_tid = th; g_aq_thread = true;
-    }
-    AsyncReq q = { sess, src, dest, cb, r, compress };
+    if (!consumer_started_locked()) { pthread_mutex_unlock(&g_aq_lock); return QZ_FAIL; }
+    AsyncReq q = { sess, src, dest, cb, r, compress, NULL, NULL };
     g_aq.push_back(q);
     pthread_cond_signal(&g_aq_more);
     pthread_mutex_unlock(&g_aq_lock);

@@ -8,11 +8,15 @@
  *
  *   bt_sweep sweep <start> <end> <step>       round-trip sweep, exit 0 when all equal
  *   bt_sweep perf <mbytes> <block> <loops>    per-block calls, prints comp/decomp Gbps
+ *   bt_sweep perfmt <mbytes> <block> <loops> <threads>   the harness' -t: every thread its own session and its own
+ *                                             <mbytes> of data, one qzCompress / qzDecompress per block, started together
+ *                                             (test/main.c:2175-2202), rates summed as run_perf_test.sh:111-123 does
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
 #include "qatzip.h"
 
 static void fill(unsigned char *p, size_t n, int corpus)
@@ -99,8 +103,77 @@ static int perf(unsigned mb, unsigned block, unsigned loops)
     return 0;
 }
 
+/* ---- threads: one session each, synchronous calls, everybody started by a barrier ---- */
+typedef struct { unsigned mb, block, loops, id; double tc, td; int rc; pthread_barrier_t *bar; } mt_arg;
+
+static void *mt_body(void *p)
+{
+    mt_arg *a = (mt_arg *)p;
+    QzSession_T sess;
+    size_t total = (size_t)a->mb << 20, off, nblk = (total + a->block - 1) / a->block, i;
+    unsigned cap = qzMaxCompressedLength(a->block, NULL) + 64, l, seed = 17 + a->id;
+    unsigned char *src = qzMalloc(total, 0, COMMON_MEM), *comp = qzMalloc((size_t)cap * nblk, 0, COMMON_MEM), *back = qzMalloc(total, 0, COMMON_MEM);
+    unsigned *csz = malloc(nblk * sizeof(unsigned));
+    double t0;
+    memset(&sess, 0, sizeof(sess));
+    a->rc = 2; a->tc = a->td = 0;
+    if (src && comp && back && csz) {
+        for (off = 0; off < total;) {           /* genRandomData-style runs, a different stream per thread */
+            size_t run = (size_t)(rand_r(&seed) % 100), k; unsigned char v = (unsigned char)(rand_r(&seed) % 65 + 90);
+            for (k = 0; k < run && off < total; k++) src[off++] = v;
+        }
+        a->rc = 0;
+        {   /* the session (and its device context) exists before the clock starts */
+            unsigned sl = a->block < total ? a->block : (unsigned)total, dl = cap;
+            if (qzCompress(&sess, src, &sl, comp, &dl, 1) != QZ_OK) a->rc = 3;
+        }
+    }
+    pthread_barrier_wait(a->bar);
+    for (l = 0; l < a->loops; l++) {             /* a thread that failed still keeps the barriers' count */
+        t0 = now();
+        for (i = 0, off = 0; i < nblk && a->rc == 0; i++, off += a->block) {
+            unsigned sl = (unsigned)(total - off < a->block ? total - off : a->block), dl = cap;
+            if (qzCompress(&sess, src + off, &sl, comp + (size_t)i * cap, &dl, 1) != QZ_OK) a->rc = 3;
+            csz[i] = dl;
+        }
+        a->tc += now() - t0;
+        pthread_barrier_wait(a->bar);
+        t0 = now();
+        for (i = 0, off = 0; i < nblk && a->rc == 0; i++, off += a->block) {
+            unsigned cl = csz[i], ol = (unsigned)(total - off < a->block ? total - off : a->block);
+            if (qzDecompress(&sess, comp + (size_t)i * cap, &cl, back + off, &ol) != QZ_OK) a->rc = 4;
+        }
+        a->td += now() - t0;
+        pthread_barrier_wait(a->bar);
+    }
+    if (a->rc == 0 && memcmp(src, back, total)) a->rc = 5;
+    qzTeardownSession(&sess);
+    qzFree(src); qzFree(comp); qzFree(back); free(csz);
+    return NULL;
+}
+
+static int perfmt(unsigned mb, unsigned block, unsigned loops, unsigned nthr)
+{
+    pthread_t th[256]; mt_arg arg[256]; pthread_barrier_t bar;
+    unsigned t; double gc = 0, gd = 0; int bad = 0;
+    if (nthr < 1 || nthr > 256) return 64;
+    qzSetLogLevel(LOG_NONE);
+    pthread_barrier_init(&bar, NULL, nthr);
+    for (t = 0; t < nthr; t++) { arg[t].mb = mb; arg[t].block = block; arg[t].loops = loops; arg[t].id = t; arg[t].bar = &bar; pthread_create(&th[t], NULL, mt_body, &arg[t]); }
+    for (t = 0; t < nthr; t++) {
+        pthread_join(th[t], NULL);
+        if (arg[t].rc) { printf("perfmt: thread %u failed (%d)\n", t, arg[t].rc); bad = 1; continue; }
+        gc += (double)mb * 1048576.0 * 8 * loops / 1073741824.0 / arg[t].tc;
+        gd += (double)mb * 1048576.0 * 8 * loops / 1073741824.0 / arg[t].td;
+    }
+    printf("perfmt: %u thread(s) x %u MiB, block %u, loops %u  compress %.3f Gbps  decompress %.3f Gbps (sum over threads, host to host)\n",
+           nthr, mb, block, loops, gc, gd);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 6 && !strcmp(argv[1], "perfmt")) return perfmt(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
     if (argc >= 5 && !strcmp(argv[1], "sweep")) return sweep(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
     if (argc >= 5 && !strcmp(argv[1], "perf")) return perf(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
     fprintf(stderr, "usage: bt_sweep sweep <start> <end> <step> | perf <mbytes> <block> <loops>\n");

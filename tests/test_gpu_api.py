@@ -366,6 +366,51 @@ def test_async_teardown_from_callback_does_not_deadlock():
     sa.close()
 
 
+def test_synchronous_calls_of_many_threads_share_launches():
+    """qzCompress / qzDecompress of small requests issued by several threads at once (the reference's perf harness,
+    test/main.c:2175-2299, one call per block per thread): the calls wait in the same queue as qzCompress2 requests and
+    whatever is waiting goes to the GPU as one launch; every caller still gets exactly the member its own call would have
+    written, its own lengths, return code and CRC."""
+    import threading
+    L = A.lib()
+    L.qzamd_async_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    l0, r0 = C.c_uint64(), C.c_uint64()
+    L.qzamd_async_stats(C.byref(l0), C.byref(r0))
+    NT, PER = 8, 12
+    errs, start = [], threading.Barrier(NT)
+
+    def body(t):
+        try:
+            s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+            s.compress(b"warm up the session", 1)
+            start.wait()
+            for i in range(PER):
+                kind = ("silesia", "text", "rand", "runs")[(t + i) % 4]
+                n = (65536, 1000, 200000, 65537, 30000)[(t * 3 + i) % 5]
+                src = datagen.gen_bytes(kind, n, 1000 + 50 * t + i)
+                rc, used, out, crc = s.compress(src, 1, crc0=0)
+                exp = O.sw_compress("GZIP_EXT", src, 65536, 1, cap=n * 9 // 8 + 65536)
+                assert rc == A.QZ_OK and used == n and out == exp[2] and crc == exp[3], (t, i, kind, n, rc)
+                rc, cused, back, dcrc = s.decompress(out, n + 16, want_crc=True)
+                assert rc == A.QZ_OK and back == src and cused == len(out) and dcrc == (zlib.crc32(src) & 0xffffffff), (t, i, rc)
+                if i == 5:                                          # a destination that is too small: this caller's error only
+                    rc, used, out2, _ = s.compress(src, 1, cap=40)
+                    assert rc in (A.QZ_BUF_ERROR, A.QZ_FAIL) and used == 0
+            s.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append((t, repr(e)))
+    th = [threading.Thread(target=body, args=(t,)) for t in range(NT)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(600)
+    assert not errs, errs
+    l1, r1 = C.c_uint64(), C.c_uint64()
+    L.qzamd_async_stats(C.byref(l1), C.byref(r1))
+    print("sync calls of %d threads: %d coalesced launches carried %d requests" % (NT, l1.value - l0.value, r1.value - r0.value))
+    assert r1.value - r0.value >= NT                         # calls did share launches
+
+
 def test_crc_known_answer_like_reference_test():
     # test/main.c:4283-4337: qzCompressCrc's crc == zlib crc32(src) for 64 KB and 1023 B
     s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
@@ -701,11 +746,16 @@ def test_plain_c_caller_links_and_round_trips(tmp_path):
     exe = str(tmp_path / "bt_sweep")
     subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c", "bt_sweep.c"), "-o", exe,
-                           "-L", os.path.join(ROOT, "qatzip_amd"), "-lqatzip_amd",
+                           "-L", os.path.join(ROOT, "qatzip_amd"), "-lqatzip_amd", "-lpthread",
                            "-Wl,-rpath," + os.path.join(ROOT, "qatzip_amd")])
     r = subprocess.run([exe, "sweep", "1", "200000", "9973"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     r = subprocess.run([exe, "perf", "64", "65536", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Gbps" in r.stdout, r.stdout + r.stderr
+    print(r.stdout)
+    # the harness' -t: eight threads, a session each, one synchronous call per 64 KB block - calls that wait at the same
+    # time share launches (and every byte comes back right)
+    r = subprocess.run([exe, "perfmt", "8", "65536", "1", "8"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "Gbps" in r.stdout, r.stdout + r.stderr
     print(r.stdout)
     # two 1 GiB calls each way: the sizes at which input and output travel in pieces beside the kernels (batched
