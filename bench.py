@@ -25,7 +25,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -86,54 +85,26 @@ def host_cpu():
     return max(1, n), model
 
 
-def _run_threads(nthr, fn):
-    """fn(i) on nthr threads (the C calls release the GIL); wall time of the slowest"""
-    out = [None] * nthr
-    start = threading.Barrier(nthr + 1)
-
-    def body(i):
-        start.wait()
-        out[i] = fn(i)
-    th = [threading.Thread(target=body, args=(i,)) for i in range(nthr)]
-    for t in th:
-        t.start()
-    start.wait()
-    t0 = time.perf_counter()
-    for t in th:
-        t.join()
-    return time.perf_counter() - t0, out
-
-
-def cpu_baseline(base: np.ndarray, shard_mb: int, max_threads: int):
-    """The oracle (a port of the reference's software path, src/qatzip_sw.c:77-441) on this box's host cores: one thread
-    alone, then one thread per physical core, each on its own contiguous shard of the bench buffer (the method of
-    test/performance_tests/run_perf_test.sh:100-123: N independent workers, rates summed).  Then the same loop over this
-    host's own libz when Python's zlib is linked to one (deflateInit2(1, 8, -15, 9, 0) + Z_FULL_FLUSH per 64 KB)."""
+def cpu_worker(idx: int, shard_mb: int, base_mb: int):
+    """one worker process of the CPU baseline: its own contiguous shard of the bench data (regenerated from the same
+    seed), the software path's port, then this host's libz; prints one JSON line"""
     import zlib
+    import datagen
     import oracle_lib as O
-    ncores, model = host_cpu()
-    nthr = max(1, min(ncores, max_threads))
+    base = datagen.gen("silesia", base_mb << 20, 20250523)
     S = min(shard_mb << 20, len(base)) & ~(CHUNK - 1)
     span = max(1, len(base) - S)
-    shards = [base[(i * 7919 * CHUNK) % span:][:S].tobytes() for i in range(nthr)]
-
-    def port_both(i):
-        src = shards[i]
-        t0 = time.perf_counter()
-        rc, used, out, _ = O.sw_compress("GZIP_EXT", src, CHUNK, 1, cap=len(src) * 9 // 8 + 65536)
-        t1 = time.perf_counter()
-        rc2, _, back = O.sw_decompress("GZIP_EXT", out, len(src) + 64)
-        t2 = time.perf_counter()
-        assert rc == 0 and used == len(src) and rc2 == 0 and back == src
-        return t1 - t0, t2 - t1, len(out)
-
-    w1, r1 = _run_threads(1, port_both)
-    wall, res = _run_threads(nthr, port_both)
-    tc = max(r[0] for r in res); td = max(r[1] for r in res)
-    total = float(S) * nthr
-
-    def libz_both(i):
-        src = shards[i]
+    src = base[(idx * 7919 * CHUNK) % span:][:S].tobytes()
+    del base
+    O.sw_compress("GZIP_EXT", src[:CHUNK], CHUNK, 1)                 # tables built, pages touched
+    t0 = time.perf_counter()
+    rc, used, out, _ = O.sw_compress("GZIP_EXT", src, CHUNK, 1, cap=len(src) * 9 // 8 + 65536)
+    t1 = time.perf_counter()
+    rc2, _, back = O.sw_decompress("GZIP_EXT", out, len(src) + 64)
+    t2 = time.perf_counter()
+    assert rc == 0 and used == len(src) and rc2 == 0 and back == src
+    res = {"n": S, "tc": t1 - t0, "td": t2 - t1, "clen": len(out)}
+    try:
         t0 = time.perf_counter()
         co = zlib.compressobj(1, zlib.DEFLATED, -15, 9, 0)
         parts = []
@@ -145,25 +116,56 @@ def cpu_baseline(base: np.ndarray, shard_mb: int, max_threads: int):
         back = zlib.decompress(comp, -15)
         t2 = time.perf_counter()
         assert back == src
-        return t1 - t0, t2 - t1, len(comp)
+        res.update({"ztc": t1 - t0, "ztd": t2 - t1, "zver": zlib.ZLIB_RUNTIME_VERSION})
+    except Exception as e:   # noqa: BLE001
+        res["zerr"] = str(e)[:100]
+    print(json.dumps(res))
 
+
+def cpu_baseline(shard_mb: int, base_mb: int, max_workers: int):
+    """The oracle (a port of the reference's software path, src/qatzip_sw.c:77-441) on this box's host cores, the way
+    the reference measures itself (test/performance_tests/run_perf_test.sh:100-123): N independent worker PROCESSES, one
+    per physical core, each on its own contiguous shard of the bench buffer, rates summed; one worker alone beside it.
+    Each worker then runs the same loop over this host's own libz (deflateInit2(1, 8, -15, 9, 0) + Z_FULL_FLUSH per
+    64 KB through Python's zlib)."""
+    import subprocess
+    ncores, model = host_cpu()
+    nw = max(1, min(ncores, max_workers))
+
+    def run(count):
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--cpu-mb", str(shard_mb),
+                                "--base-mb", str(base_mb)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+              for i in range(count)]
+        out = []
+        for p in ps:
+            o, _ = p.communicate(timeout=600)
+            line = [x for x in o.splitlines() if x.startswith("{")]
+            if p.returncode == 0 and line:
+                out.append(json.loads(line[-1]))
+        return out
+    one = run(1)
+    many = run(nw)
+    if not one or not many:
+        return {"error": "CPU baseline workers failed"}
+
+    def rates(rs, kc, kd):
+        c = sum(r["n"] / r[kc] for r in rs) / 1e9; d = sum(r["n"] / r[kd] for r in rs) / 1e9
+        both = sum(2 * r["n"] / (r[kc] + r[kd]) for r in rs) / 1e9
+        return round(both, 4), round(c, 4), round(d, 4)
+    v, c, d = rates(many, "tc", "td"); v1, c1, d1 = rates(one, "tc", "td")
     libz = None
-    try:
-        lw, lr = _run_threads(nthr, libz_both)
-        lw1, lr1 = _run_threads(1, libz_both)
-        libz = {"zlibVersion": zlib.ZLIB_RUNTIME_VERSION, "value": round(2 * total / lw / 1e9, 4),
-                "compress": round(total / max(r[0] for r in lr) / 1e9, 4), "decompress": round(total / max(r[1] for r in lr) / 1e9, 4),
-                "one_thread": round(2 * S / lw1 / 1e9, 4), "threads": nthr,
+    zs = [r for r in many if "ztc" in r]
+    if zs:
+        zv, zc, zd = rates(zs, "ztc", "ztd"); z1 = rates([r for r in one if "ztc" in r] or zs[:1], "ztc", "ztd")
+        libz = {"zlibVersion": zs[0]["zver"], "value": zv, "compress": zc, "decompress": zd, "one_worker": z1[0], "workers": len(zs),
                 "note": "raw deflate level 1, memLevel 9, Z_FULL_FLUSH per 64 KB (the loop of src/qatzip_sw.c:178-231) through Python's zlib"}
-    except Exception as e:   # noqa: BLE001 - a host without a usable libz only loses this sub-field
-        libz = {"error": str(e)[:100]}
-    return {"value": round(2 * total / wall / 1e9, 4), "unit": "GB/s", "cores": nthr, "kind": "port",
-            "compress": round(total / tc / 1e9, 4), "decompress": round(total / td / 1e9, 4),
-            "one_thread": {"value": round(2 * S / w1 / 1e9, 4), "compress": round(S / r1[0][0] / 1e9, 4), "decompress": round(S / r1[0][1] / 1e9, 4)},
+    return {"value": v, "unit": "GB/s", "cores": len(many), "kind": "port", "compress": c, "decompress": d,
+            "one_worker": {"value": v1, "compress": c1, "decompress": d1},
             "cpu_model": model, "physical_cores": ncores,
-            "sample": "%d thread(s) x %d MiB contiguous shards of the same buffer, GZIP_EXT L1 64 KB chunks, compress + "
-                      "decompress, oracle/libqzoracle.so (%.1f s of CPU work)" % (nthr, S >> 20, sum(r[0] + r[1] for r in res)),
-            "ratio": round(sum(r[2] for r in res) / total, 4), "host_libz": libz}
+            "sample": "%d worker process(es) x %d MiB contiguous shards of the same buffer, GZIP_EXT L1 64 KB chunks, compress + "
+                      "decompress, oracle/libqzoracle.so, per-worker rates summed (%.1f s of CPU work)"
+                      % (len(many), many[0]["n"] >> 20, sum(r["tc"] + r["td"] for r in many)),
+            "ratio": round(sum(r["clen"] for r in many) / sum(r["n"] for r in many), 4), "host_libz": libz}
 
 
 # ------------------------------------------------------------------ extra legs (outside the timed region)
@@ -281,11 +283,15 @@ def main():
     ap.add_argument("--mb", type=int, default=4096, help="buffer size per GPU in MiB (default: the 4 GB config)")
     ap.add_argument("--base-mb", type=int, default=128, help="distinct synthetic data generated per GPU (tiled)")
     ap.add_argument("--cpu-mb", type=int, default=16, help="CPU baseline: shard size per thread, MiB")
-    ap.add_argument("--cpu-threads", type=int, default=256, help="CPU baseline: at most this many threads")
+    ap.add_argument("--cpu-threads", type=int, default=256, help="CPU baseline: at most this many worker processes")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the API / RAW sweep / LZ4 / one-stream legs")
     ap.add_argument("--extra-mb", type=int, default=1024, help="bytes of the extra legs, MiB")
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        cpu_worker(args.cpu_worker, args.cpu_mb, args.base_mb)
+        return
 
     rank, world, local, pg = dist_setup()
     import datagen
@@ -422,7 +428,7 @@ def main():
         if one is not None:
             res["config"]["one_stream"] = one
         if not args.no_cpu and world == 1:
-            res["cpu_baseline"] = cpu_baseline(base, args.cpu_mb, args.cpu_threads)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_mb, args.base_mb, args.cpu_threads)
         print(json.dumps(res))
     if pg is not None:
         pg.destroy_process_group()

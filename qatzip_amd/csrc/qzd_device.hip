@@ -71,7 +71,12 @@ __global__ void qzk_gather_kernel(const uint8_t *slots, uint32_t stride, const u
 __global__ void __launch_bounds__(256) qzk_copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {                 /* four loads in flight per lane */
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 /* ------------------------------------------------------------------ context (qzd_internal.h) */
@@ -212,7 +217,7 @@ extern "C" int qzd_stream_copy_peak(qzd_ctx *c, uint64_t bytes, int iters, doubl
     float best = 0;
     for (int it = 0; it < iters + 1; it++) {                    /* pass 0 warms up */
         hipEventRecord(c->ev_begin, c->st[0]);
-        hipLaunchKernelGGL(qzk_copy16_kernel, dim3(256 * 16), dim3(256), 0, c->st[0], a, b, n16);
+        hipLaunchKernelGGL(qzk_copy16_kernel, dim3(256 * 8), dim3(256), 0, c->st[0], a, b, n16);
         hipEventRecord(c->ev_end, c->st[0]);
         hipStreamSynchronize(c->st[0]);
         float t = 0;
