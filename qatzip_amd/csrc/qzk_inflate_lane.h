@@ -138,7 +138,7 @@ typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chai
 #define QZK_TOK_SEQCAP(out_cap) ((uint64_t)(out_cap) / 3 + 2)
 
 enum { QZK_LS_HDR = 0, QZK_LS_SYM, QZK_LS_RAW, QZK_LS_DONE };
-#define QZK_LIT_RUN 2              /* literals one trip of the serial phase A may take */
+#define QZK_LIT_RUN 4              /* literals one trip of the serial phase A may take */
 
 /* slow half of a symbol decode: the root entry was empty (code longer than the root) */
 QZ_DEV int qzk_ldecode_long(qzk_lbits *b, int rootbits, const uint16_t *sorted, const uint16_t *count,
@@ -152,6 +152,39 @@ QZ_DEV int qzk_ldecode_long(qzk_lbits *b, int rootbits, const uint16_t *sorted, 
         const uint32_t c = count[l], f = first[l];
         if (c && code >= f && code - f < c) { QZK_DROP(b, l); sym = sorted[index[l] + code - f]; }
     }
+    return sym;
+}
+
+/* The literal/length codes longer than the root table, without a loop and without memory: for each length l the
+ * canonical codes of that length are the interval [first[l], first[l] + count[l]) of the l leading bits read MSB first,
+ * so a lane keeps the six intervals of l = 10..15 in registers (LR[0..5] = first | limit << 15, LR[6..8] = index - first,
+ * two per word) and tests all of them on the next 15 bits at once; what is left is ONE load of the symbol from the
+ * segment's sorted list.  (The ranges in the per-segment HBM record cost a lane two dependent loads per length tried -
+ * and the fifteen other lanes of its wave wait with it: with rare long codes in every segment nearly every trip of a
+ * wave had one.) */
+#define QZK_LR_WORDS 9
+QZ_DEV void qzk_longtab_load(uint32_t *LR, const qzk_inf_tab *T, int lmax)
+{
+    for (int k = 0; k < 6; k++) {
+        const int l = QZK_LLROOT + 1 + k;
+        uint32_t first = 0, limit = 0, d = 0;
+        if (l <= lmax) { first = T->lfirst[l]; limit = first + T->lcount[l]; d = ((uint32_t)T->lindex[l] - first) & 0xffffu; }
+        LR[k] = first | (limit << 15);
+        if (k & 1) LR[6 + (k >> 1)] |= d << 16; else LR[6 + (k >> 1)] = d;
+    }
+}
+QZ_DEV int qzk_ldecode_long_reg(qzk_lbits *b, const uint32_t *LR, const uint16_t *sorted, int maxlen)
+{
+    const uint32_t V = qzk_rev((uint32_t)b->bb & 0x7fffu, 15);
+    uint32_t sel_l = 0, sel_i = 0;
+    for (int k = 5; k >= 0; k--) {                              /* longest first: the shortest hit is kept */
+        const int l = QZK_LLROOT + 1 + k;
+        const uint32_t first = LR[k] & 0x7fffu, limit = LR[k] >> 15, c = V >> (15 - l);
+        const uint32_t d = (LR[6 + (k >> 1)] >> (16 * (k & 1))) & 0xffffu;
+        if (l <= maxlen && l <= b->bc && c >= first && c < limit) { sel_l = (uint32_t)l; sel_i = (c + d) & 0xffffu; }
+    }
+    int sym = -1;
+    if (sel_l) { QZK_DROP(b, sel_l); sym = sorted[sel_i]; }
     return sym;
 }
 
@@ -249,13 +282,13 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
  * fill their buffers at different moments: with sixteen segments per wave nearly every trip of the hot loop had one
  * (measured on data without duplicate chunks: 2.6 us per trip, five times what identical segments took).  So symbols are
  * only STAGED in registers, and the whole wave stores together at the end of a round of QZK_TOK_ROUND trips (a trip
- * appends at most two literals or one sequence): one queue of stores per round instead of one per lane and buffer. */
+ * appends at most QZK_LIT_RUN literals or one sequence): one queue of stores per round instead of one per lane and buffer. */
 #define QZK_TOK_ROUND 8
 typedef struct {
     uint8_t *lp; qzk_seq *sq;
     uint32_t lrun, nseq;                /* literals since the last sequence, sequences so far (staged ones included) */
-    uint32_t lw, ln;                    /* literal bytes in HBM, bytes staged in l0..l2 (< 8 after a round's flush, <= 23 within one) */
-    uint64_t l0, l1, l2;
+    uint32_t lw, ln;                    /* literal bytes in HBM, bytes staged in l0..l4 (< 8 after a round's flush, <= 39 within one) */
+    uint64_t l0, l1, l2, l3, l4;
     uint32_t sk;                        /* sequences staged in s0..s7 */
     uint64_t s0, s1, s2, s3, s4, s5, s6, s7;
     bool count_only;
@@ -266,19 +299,25 @@ QZ_DEV void qzk_tok_init(qzk_tok_out *O, uint8_t *lp, qzk_seq *sq, bool count_on
 {
     O->lp = lp; O->sq = sq; O->count_only = count_only;
     O->lrun = 0; O->nseq = 0; O->lw = 0; O->ln = 0; O->sk = 0;
-    O->l0 = O->l1 = O->l2 = 0;
+    O->l0 = O->l1 = O->l2 = O->l3 = O->l4 = 0;
     O->s0 = O->s1 = O->s2 = O->s3 = O->s4 = O->s5 = O->s6 = O->s7 = 0;
 }
-QZ_DEV void qzk_tok_byte(qzk_tok_out *O, uint32_t byte)
+/* append k (1..4) literals packed in v, lowest byte first */
+QZ_DEV void qzk_tok_lits(qzk_tok_out *O, uint32_t v, uint32_t k)
 {
     if (!O->count_only) {
-        const uint32_t w = O->ln >> 3;
-        const uint64_t v = (uint64_t)byte << (8 * (O->ln & 7));
-        O->l0 |= w == 0 ? v : 0; O->l1 |= w == 1 ? v : 0; O->l2 |= w == 2 ? v : 0;
-        O->ln++;
+        const uint32_t w = O->ln >> 3, sh = 8 * (O->ln & 7);
+        const uint64_t lo = (uint64_t)v << sh, hi = sh > 32 ? (uint64_t)v >> (64 - sh) : 0;     /* bytes that spill into the next word */
+        O->l0 |= w == 0 ? lo : 0;
+        O->l1 |= w == 1 ? lo : w == 0 ? hi : 0;
+        O->l2 |= w == 2 ? lo : w == 1 ? hi : 0;
+        O->l3 |= w == 3 ? lo : w == 2 ? hi : 0;
+        O->l4 |= w == 4 ? lo : w == 3 ? hi : 0;
+        O->ln += k;
     }
-    O->lrun++;
+    O->lrun += k;
 }
+QZ_DEV void qzk_tok_byte(qzk_tok_out *O, uint32_t byte) { qzk_tok_lits(O, byte, 1); }
 /* append the low k (1..8) bytes of v; the caller flushes after every call (ln < 8 on entry) */
 QZ_DEV void qzk_tok_bytes(qzk_tok_out *O, uint64_t v, uint32_t k)
 {
@@ -307,13 +346,18 @@ QZ_DEV void qzk_tok_seq(qzk_tok_out *O, uint32_t mlen, uint32_t dm1)
 QZ_DEV void qzk_tok_round_flush(qzk_tok_out *O)
 {
     if (O->count_only) return;
-    const uint32_t nw = O->ln >> 3;
+    const uint32_t nw = O->ln >> 3;              /* 0..4 whole words */
     uint8_t *d = O->lp + O->lw;
     if (nw >= 1) qzk_st64u(d, O->l0);
     if (nw >= 2) qzk_st64u(d + 8, O->l1);
-    O->l0 = nw == 0 ? O->l0 : nw == 1 ? O->l1 : O->l2;
-    O->l1 = nw == 0 ? O->l1 : nw == 1 ? O->l2 : 0;
-    O->l2 = nw == 0 ? O->l2 : 0;
+    if (nw >= 3) qzk_st64u(d + 16, O->l2);
+    if (nw >= 4) qzk_st64u(d + 24, O->l3);
+    const uint64_t a0 = O->l0, a1 = O->l1, a2 = O->l2, a3 = O->l3, a4 = O->l4;
+    O->l0 = nw == 0 ? a0 : nw == 1 ? a1 : nw == 2 ? a2 : nw == 3 ? a3 : a4;
+    O->l1 = nw == 0 ? a1 : nw == 1 ? a2 : nw == 2 ? a3 : nw == 3 ? a4 : 0;
+    O->l2 = nw == 0 ? a2 : nw == 1 ? a3 : nw == 2 ? a4 : 0;
+    O->l3 = nw == 0 ? a3 : nw == 1 ? a4 : 0;
+    O->l4 = nw == 0 ? a4 : 0;
     O->lw += 8 * nw; O->ln &= 7;
     const uint32_t k = O->sk;
     uint64_t *q = (uint64_t *)(O->sq + (O->nseq - k));
@@ -349,18 +393,20 @@ QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
  * straight-line code.  MIDREFILL: the caller's reader guarantees < 48 valid bits, refill before the distance code. */
 template <bool MIDREFILL, bool PAIR>
 QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, const uint16_t *lroot,
-                            const uint16_t *droot, uint64_t hist)
+                            const uint16_t *droot, uint64_t hist, const uint32_t *LR = 0)
 {
     qzk_lbits *b = &S->b;
     const uint32_t e = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
     int sym;
     if (e != 0 && (int)(e & 15) <= b->bc) { QZK_DROP(b, e & 15); sym = (int)(e >> 4); }
-    else sym = e ? -1 : qzk_ldecode_long(b, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, S->lmax);
+    else if (e) sym = -1;
+    else if (LR) sym = qzk_ldecode_long_reg(b, LR, T->lsorted, S->lmax);
+    else sym = qzk_ldecode_long(b, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, S->lmax);
     if (sym < 256) {
         if (sym < 0) { S->status = b->pos >= b->end && b->bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA; S->state = QZK_LS_DONE; }
         else if (S->op >= S->out_cap) { S->status = QZK_INF_EOUT; S->state = QZK_LS_DONE; }
         else {
-            qzk_tok_byte(O, (uint32_t)sym); S->op++;
+            uint32_t lv = (uint32_t)sym, lk = 1;
             if (PAIR) {
                 /* literals come in runs: take up to QZK_LIT_RUN in one trip while their codes sit in the 9-bit root table
                  * (15 + 3 * 9 bits fit the 56 a trip starts with).  Not for the speculative decoders, whose trips must
@@ -368,13 +414,14 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
                 bool run = true;
                 for (int extra = 0; extra < QZK_LIT_RUN - 1; extra++) {
                     const uint32_t e2 = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
-                    run = run && e2 != 0 && (e2 >> 4) < 256 && (int)(e2 & 15) <= b->bc && S->op < S->out_cap;
+                    run = run && e2 != 0 && (e2 >> 4) < 256 && (int)(e2 & 15) <= b->bc && S->op + lk < S->out_cap;
                     if (run) {
                         QZK_DROP(b, e2 & 15);
-                        qzk_tok_byte(O, e2 >> 4); S->op++;
+                        lv |= (e2 >> 4) << (8 * lk); lk++;
                     }
                 }
             }
+            qzk_tok_lits(O, lv, lk); S->op += lk;
         }
     } else if (sym == 256) {
         if (S->last) { S->status = QZK_INF_FINAL; S->state = QZK_LS_DONE; } else S->state = QZK_LS_HDR;
@@ -403,8 +450,9 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
 }
 
 /* LPW = segments (active lanes) per single-wave workgroup: LPW * 1.25 KiB of LDS (16 -> eight workgroups per CU) */
-template <int LPW>
-QZ_KERNEL_MAX(64) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
+/* OCC = waves per SIMD the register budget is cut for (LPW 16: the LDS admits 8 waves per CU = 2 per SIMD; LPW 8: 16 = 4) */
+template <int LPW, int OCC = 2>
+QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                  qzk_inf_tab *tabs, const qzk_tokseg *ts, uint8_t *lits, qzk_seq *seqs,
                                  qzk_chain *chains)
 {
@@ -427,6 +475,11 @@ QZ_KERNEL_MAX(64) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *
     /* the pieces phase B puts the segment together from: runs of sequences, and stored blocks as they lie in the input */
     qzk_chain *const C = chains + sidx;
     uint32_t nel = 0, piece_seq0 = 0, piece_lit0 = 0;
+#ifdef QZK_INF_PROF
+    uint32_t prof_trips = 0; const uint64_t prof_t0 = __builtin_readcyclecounter();
+#endif
+    uint32_t LR[QZK_LR_WORDS];                  /* the long literal/length codes of the current block (registers) */
+    for (int i = 0; i < QZK_LR_WORDS; i++) LR[i] = 0;
 
     while (S.state != QZK_LS_DONE) {
         qzk_lbits *b = &S.b;
@@ -443,7 +496,10 @@ QZ_KERNEL_MAX(64) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *
                     b->bb |= pw << b->bc;
                     b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
                     pw = qzk_ld64u(b->p + b->pos);
-                    qzk_lane_symbol<false, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0);
+                    qzk_lane_symbol<false, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0, LR);
+#ifdef QZK_INF_PROF
+                    prof_trips++;
+#endif
                 }
                 qzk_tok_round_flush(&O);
             }
@@ -456,11 +512,14 @@ QZ_KERNEL_MAX(64) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *
             for (int round = 0; round < 8 && S.state == QZK_LS_SYM; round++) {
                 for (int trip = 0; trip < QZK_TOK_ROUND && S.state == QZK_LS_SYM; trip++) {
                     qzk_lrefill(b);
-                    qzk_lane_symbol<true, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0);
+                    qzk_lane_symbol<true, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0, LR);
                 }
                 qzk_tok_round_flush(&O);
             }
-        } else if (S.state == QZK_LS_HDR) qzk_lane_header(&S, T, lroot, droot);
+        } else if (S.state == QZK_LS_HDR) {
+            qzk_lane_header(&S, T, lroot, droot);
+            if (S.state == QZK_LS_SYM) qzk_longtab_load(LR, T, S.lmax);
+        }
         else if (S.state == QZK_LS_RAW) {
             if (O.count_only) { S.op += S.clen; S.rpos += S.clen; S.clen = 0; }         /* nothing to move */
             else if (nel + 3 <= QZK_CHAIN_MAXEL) {
@@ -501,6 +560,9 @@ QZ_KERNEL_MAX(64) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *
     qzk_infres r;
     r.status = S.status; r.out_len = S.op; r.nblocks = S.nblocks;
     r.in_used = S.b.pos - (uint32_t)(S.b.bc >> 3);
+#ifdef QZK_INF_PROF                     /* profiling builds only: trips of the hot loop / shader cycles of this lane */
+    r.nblocks = prof_trips; r.in_used = (uint32_t)((__builtin_readcyclecounter() - prof_t0) >> 6);
+#endif
     res[sidx] = r;
 }
 

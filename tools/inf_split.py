@@ -35,3 +35,14 @@ for flags, name in ((1, "count-only"), (0, "decode+copy")):
     ms = ctx.inflate_timing()
     assert (res["status"] >= 0).all() and (res["out_len"] == 65536).all()
     print("%-12s %4d MiB: %7.1f ms wall  %6.2f GB/s   kernels %.1f ms of which phase B %.1f" % (name, mb, dt * 1e3, n / dt / 1e9, ms[0], ms[2]))
+
+if os.environ.get("QATZIP_AMD_SO", "").endswith("prof.so"):
+    # profiling build: nblocks = trips of the hot loop, in_used = shader cycles / 64, per segment (launch order = `order`)
+    trips = res["nblocks"].astype(np.int64); cyc = res["in_used"].astype(np.int64) * 64
+    w = trips.reshape(-1, 16); cw = cyc.reshape(-1, 16)
+    print("trips per segment: min %d  median %d  max %d;   per wave (max lane): median %d  max %d" %
+          (trips.min(), np.median(trips), trips.max(), np.median(w.max(1)), w.max(1).max()))
+    print("cycles per lane: min %.2e median %.2e max %.2e;  cycles per trip (wave max cyc / wave max trips): p10 %.0f  p50 %.0f  p90 %.0f" %
+          (cyc.min(), np.median(cyc), cyc.max(), *np.percentile(cw.max(1) / np.maximum(w.max(1), 1), [10, 50, 90])))
+    for lo, hi in ((0, 64), (64, 512), (512, 1024), (1024, 1536), (1536, 2048)):
+        print("  waves %4d-%4d: trips(max lane) %6.0f  cycles %.2e  comp bytes %d" % (lo, hi, w[lo:hi].max(1).mean(), cw[lo:hi].max(1).mean(), lens[order][lo * 16:hi * 16].mean()))
