@@ -165,9 +165,14 @@ typedef struct { int32_t status; uint32_t in_used, out_len, pad; } qzd_lz4res;
 
 /* every frame_sz (<= 64 KB) bytes of d_src -> one LZ4 frame exactly as LZ4F_compressFrame emits it for the
  * preferences of src/qatzip_sw.c:451-456 (content size + content checksum, one independent block, stored
- * when incompressible); frames are written back to back.  h_frame_len (optional) <- size of every frame. */
+ * when incompressible) when it is called on that piece alone; frames are written back to back.  h_frame_len (optional) <- size of every frame. */
 int qzd_lz4_compress_frames(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t frame_sz, uint8_t *d_dst,
                             uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len);
+/* ONE call above 64 KB as the one frame LZ4F_compressFrame writes for it (src/qatzip_sw.c:451-456): FLG 0x4C, the 64 KB
+ * blocks linked - one parse state for the whole frame, hence one wave's serial work; 64 KB < n <= 0x7fff0000 (beyond that
+ * liblz4 rescales its 32-bit positions, which is not reproduced) */
+int qzd_lz4_compress_linked(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                            uint64_t *h_out_len);
 /* decode nsegs frames (any block mode, content checksum verified on the GPU); replaces LZ4F_decompress,
  * src/qatzip_sw.c:496 */
 int qzd_lz4_decompress_frames(qzd_ctx *ctx, const uint8_t *d_comp, uint8_t *d_out, const void *h_segs,

@@ -52,6 +52,7 @@ def load(build_if_missing=True):
     L.qzd_crc32_ranges.argtypes = [vp, u8p, vp, C.c_uint32, vp]
     L.qzd_last_inflate_timing.argtypes = [vp, C.POINTER(C.c_float * 4)]
     L.qzd_lz4_compress_frames.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
+    L.qzd_lz4_compress_linked.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.qzd_lz4_decompress_frames.argtypes = [vp, u8p, u8p, vp, C.c_uint32, vp]
     L.qzd_chunk_lens.argtypes = [vp, vp, C.c_uint32]
     L.qzd_shard_root_create.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_char_p, C.POINTER(vp)]
@@ -81,7 +82,7 @@ def exported_symbols():
             "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats",
             "qzd_adler32_chunks", "qzd_adler32_combine", "qzd_stream_copy_peak", "qzd_deflate_raw_from_host",
             "qzd_deflate_slots", "qzd_inflate_stream_to_host", "qzamd_async_stats", "qzd_shard_root_create",
-            "qzd_shard_attach", "qzd_shard_put", "qzd_shard_finish", "qzd_shard_close", "qzd_crc32_combine"]
+            "qzd_shard_attach", "qzd_lz4_compress_linked", "qzd_shard_put", "qzd_shard_finish", "qzd_shard_close", "qzd_crc32_combine"]
 
 
 class DevBuf:

@@ -305,7 +305,7 @@ int main(int argc, char **argv)
         }
     }
     qzSetLogLevel(LOG_NONE);
-    /* this backend writes one LZ4 frame of <= 64 KB content per call (larger calls would need liblz4's linked blocks) */
+    /* one LZ4 frame of <= 64 KB content per call: every frame is one wave of work (a larger call would be ONE linked frame, a serial chain) */
     if (g.fmt == FMT_LZ4 && g.block > 65536) g.block = 65536;
     if (optind == argc) {                               /* stdin -> stdout */
         unsigned long long n_in = 0, n_out = 0;

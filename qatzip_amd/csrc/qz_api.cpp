@@ -553,20 +553,23 @@ static int compress_lz4(QzSession_T *sess, Sess *s, const unsigned char *src, un
 {
     const uint32_t n = *src_len, cap = *dest_len;
     *src_len = 0; *dest_len = 0;
-    /* Up to 64 KB a call is one frame with one block, byte for byte what LZ4F_compressFrame writes.  Above that the
-     * software path would link the blocks of ONE frame (each block may reach 64 KB back into the previous ones and the
-     * match table carries over), which makes the whole call one serial chain; like the hardware path
-     * (qzLZ4HeaderGen per chunk, src/qatzip_lz4.c:62-120) the call becomes a sequence of independent frames instead,
-     * one per 64 KB, each exactly the frame a call of its own would have produced.  Any LZ4 frame reader takes it. */
+    /* Up to 64 KB a call is one frame with one block; above, ONE frame whose 64 KB blocks are linked (each may reach
+     * 64 KB back into the ones before it, one match table for the frame) - byte for byte what LZ4F_compressFrame writes
+     * either way.  The linked frame is one serial chain, so it is one wave's work (qzd_lz4_compress_linked); callers that
+     * want throughput make calls of at most 64 KB, like the reference's own harness (test/main.c:2204-2231) and its
+     * hardware path, whose chunks are frames of their own (src/qatzip_lz4.c:104-132).  Only past 0x7fff0000 bytes, where
+     * liblz4 starts rescaling its 32-bit positions, the call is written as one independent frame per 64 KB instead. */
     if (s->p.comp_lvl >= 3) return QZ_NOT_SUPPORTED;               /* level >= 3 is LZ4-HC in liblz4 */
+    const bool linked = n > 65536 && n <= 0x7fff0000u;
     const uint64_t nfr = n ? ((uint64_t)n + 65535) >> 16 : 1;
-    const uint64_t bound = nfr * (19 + 4 + 8) + (uint64_t)n;       /* LZ4F_compressFrameBound of every piece */
+    const uint64_t bound = linked ? 19 + 4 * nfr + (uint64_t)n + 8 : nfr * (19 + 4 + 8) + (uint64_t)n;   /* LZ4F_compressFrameBound */
     if (cap < bound) return QZ_FAIL;                               /* LZ4F_ERROR_dstMaxSize_tooSmall => QZ_FAIL */
     int rc = reserve(s, n, bound + 64);
     if (rc) return rc;
     if (n && qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
     uint64_t produced = 0;
-    if (qzd_lz4_compress_frames(s->ctx, s->d_in, n, 65536, s->d_out, s->out_cap, &produced, NULL) != QZD_OK) return QZ_FAIL;
+    if (linked) { if (qzd_lz4_compress_linked(s->ctx, s->d_in, n, s->d_out, s->out_cap, &produced) != QZD_OK) return QZ_FAIL; }
+    else if (qzd_lz4_compress_frames(s->ctx, s->d_in, n, 65536, s->d_out, s->out_cap, &produced, NULL) != QZD_OK) return QZ_FAIL;
     if (qzd_d2h(s->ctx, dest, s->d_out, produced) != QZD_OK) return QZ_FAIL;
     *src_len = n; *dest_len = (unsigned int)produced;
     sess->total_in += n; sess->total_out += produced;

@@ -750,6 +750,28 @@ extern "C" int qzd_lz4_compress_frames(qzd_ctx *c, const uint8_t *d_src, uint64_
     return QZD_OK;
 }
 
+/* one call above 64 KB as the ONE frame with linked blocks that LZ4F_compressFrame writes for it (one wave, serial) */
+extern "C" int qzd_lz4_compress_linked(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                                       uint64_t *h_out_len)
+{
+    if (!c || !d_src || !d_dst || !h_out_len) return QZD_ERR_PARAM;
+    if (n <= QZK_LZ4_MAXBLK || n > 0x7fff0000ull) { snprintf(c->err, sizeof(c->err), "linked LZ4 frames: 64 KB < n <= 0x7fff0000"); return QZD_ERR_UNSUPPORTED; }
+    const uint64_t bound = 19 + 4 * ((n + 65535) >> 16) + n + 8;
+    if (dst_cap < bound) { snprintf(c->err, sizeof(c->err), "destination too small"); return QZD_ERR_DSTCAP; }
+    hipSetDevice(c->device);
+    hipStream_t st = c->st[0];
+    HIPCHK(c, hipEventRecord(c->ev_begin, st));
+    hipLaunchKernelGGL(qzk_lz4c_linked_kernel, dim3(1), dim3(64), 0, st, d_src, (uint32_t)n, d_dst, (uint32_t *)c->d_overflow);
+    HIPCHK(c, hipEventRecord(c->ev_end, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    *h_out_len = *c->h_overflow;
+    float t = 0;
+    if (hipEventElapsedTime(&t, c->ev_begin, c->ev_end) == hipSuccess) c->ms[3] = t;
+    return QZD_OK;
+}
+
 /* decode nsegs LZ4 frames {u64 in_off, u64 out_off, u32 in_len, u32 out_cap} -> {i32 status, u32 in_used, u32 out_len, u32 pad};
  * content checksums are verified on the GPU (XXH32) */
 extern "C" int qzd_lz4_decompress_frames(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const void *h_segs,

@@ -116,9 +116,9 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
                                                ts_d, lit_d, seq_d, ch_d)
         const char *oe = getenv("QATZIP_AMD_INFLATE_OCC");
         const int occ = oe ? atoi(oe) : 0;
-        if (lpw == 8) { if (occ == 3) QZD_TOK_LAUNCH(8, 3); else if (occ == 2) QZD_TOK_LAUNCH(8, 2); else QZD_TOK_LAUNCH(8, 4); }
+        if (lpw == 8) { if (occ == 2) QZD_TOK_LAUNCH(8, 2); else QZD_TOK_LAUNCH(8, 4); }
         else if (lpw == 32) QZD_TOK_LAUNCH(32, 1); else if (lpw == 64) QZD_TOK_LAUNCH(64, 1);
-        else { if (occ == 3) QZD_TOK_LAUNCH(16, 3); else QZD_TOK_LAUNCH(16, 2); }
+        else QZD_TOK_LAUNCH(16, 2);
 #undef QZD_TOK_LAUNCH
     } else {
         const uint32_t spw = 64 / K;

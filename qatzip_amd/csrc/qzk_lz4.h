@@ -4,9 +4,10 @@
  *
  * Replaces LZ4F_compressFrame / LZ4F_decompress on the reference's software path
  * (src/qatzip_sw.c:443-533) for frames of at most one 64 KB block — the
- * "64 KB blocks + xxhash32" configuration of BASELINE.json.  Frames whose content
- * exceeds 64 KB use liblz4's linked-block mode (a dictionary carried across
- * blocks); that mode is not produced here (decode handles it).
+ * "64 KB blocks + xxhash32" configuration of BASELINE.json.  A call above 64 KB is
+ * what liblz4 makes of it: ONE frame whose blocks are linked (qzk_lz4c_linked_kernel:
+ * LZ4_compress_fast_continue over the blocks, one parse state for the frame - a
+ * serial chain, so one wave per call).
  * CPU restatement: oracle/qzo_lz4.c.
  *
  * Compress: the parse is greedy and serial (every probed position is inserted in
@@ -80,20 +81,36 @@ QZ_DEV uint32_t qzk_lz4_count(const uint8_t *a, const uint8_t *b, uint32_t maxle
 
 #define QZK_LZ4HASH(v) (((v) * 2654435761u) >> 19)
 
-/* LZ4 block compress of in[0..n) into out (capacity cap); returns size or 0 when it does not fit.
- * table: QZK_LZ4_HASHSZ u32 in LDS (zeroed here). */
-QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap, uint32_t *table,
-                              uint32_t *slot, int lane)
+/* lz4's LZ4_hash5 of the 64-bit little-endian builds: the five bytes at p, 12 bits (the table of the linked mode) */
+QZ_DEV uint32_t qzk_lz4_hash5(const uint8_t *p)
 {
-    for (int i = lane; i < QZK_LZ4_HASHSZ; i += 64) table[i] = 0;
+    const uint64_t seq = (uint64_t)qz_ld32(p) | (uint64_t)p[4] << 32;
+    return (uint32_t)(((seq << 24) * 889523592379ull) >> 52);
+}
+
+/* LZ4 block compress of in[bs..bs+n) into out (capacity cap); returns size or 0 when it does not fit.
+ * LINKED = false: an independent block (bs = 0; LZ4_compress_fast, 13-bit hash of 4 bytes; table: QZK_LZ4_HASHSZ u32
+ * in LDS, zeroed here).  LINKED = true: one block of a linked frame that starts at in[0] (LZ4_compress_fast_continue:
+ * the frame's table - 4096 u32, 12-bit hash of 5 bytes - comes in and goes out with everything earlier blocks and this
+ * one inserted, also when this block does not fit; candidates up to 65535 bytes back, across block borders). */
+template <bool LINKED>
+QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint8_t *out, uint32_t cap, uint32_t *table,
+                                uint32_t *slot, int lane)
+{
+#define QZK_LZ4H(pos, v4) (LINKED ? qzk_lz4_hash5(in + (pos)) : QZK_LZ4HASH(v4))
+#define QZK_LZ4NEAR(cand, cur) (!LINKED || (cand) + 65535u >= (cur))
+    if (!LINKED) { for (int i = lane; i < QZK_LZ4_HASHSZ; i += 64) table[i] = 0; }
     qz_wave_sync();
-    uint32_t op = 0, anchor = 0, ip;
-    const int32_t mfl1 = (int32_t)n - QZK_LZ4_MFLIMIT + 1;      /* mflimitPlusOne */
-    const uint32_t matchlimit = n - QZK_LZ4_LASTLIT;
+    const uint32_t be = bs + n;
+    uint32_t op = 0, anchor = bs, ip;
+    const int32_t mfl1 = (int32_t)be - QZK_LZ4_MFLIMIT + 1;     /* mflimitPlusOne */
+    const uint32_t matchlimit = be - QZK_LZ4_LASTLIT;
     bool ended = false;
     if (n >= QZK_LZ4_MFLIMIT + 1) {
-        /* first byte: position 0 goes into the table (it is 0 already), search starts at 1 */
-        ip = 1;
+        /* first byte: the block's first position goes into the table unsearched (an independent block's is 0 - already
+         * there), the search starts behind it */
+        if (LINKED) { if (lane == 0) table[qzk_lz4_hash5(in + bs)] = bs; qz_wave_sync(); }
+        ip = bs + 1;
         for (;;) {
             /* ---------------- search streak from ip ---------------- */
             uint32_t j0 = 0, mpos = 0, mcand = 0; bool found = false;
@@ -104,7 +121,7 @@ QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint3
                 const uint32_t f = ip + (j ? 1 + 32 * b * (b + 1) + (b + 1) * r : 0), step = j ? (63 + j) >> 6 : 1;
                 const bool live = (int32_t)(f + step) <= mfl1;       /* else this probe is the `goto _last_literals` */
                 uint32_t v = 0, h = 0, cand = 0;
-                if (live) { v = qz_ld32(in + f); h = QZK_LZ4HASH(v); cand = table[h]; }
+                if (live) { v = qz_ld32(in + f); h = QZK_LZ4H(f, v); cand = table[h]; }
                 const uint32_t key = h & 1023;
                 if (live) slot[key] = 64;
                 qz_wave_sync();
@@ -112,7 +129,7 @@ QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint3
                 qz_wave_sync();
                 const bool suspect = live && slot[key] != (uint32_t)lane;
                 bool hit = false;
-                if (live && !suspect) hit = qz_ld32(in + cand) == v;
+                if (live && !suspect) hit = QZK_LZ4NEAR(cand, f) && qz_ld32(in + cand) == v;
                 const uint64_t LIVE = qz_ballot(live);
                 uint64_t HIT = qz_ballot(hit);
                 const uint64_t SUS = qz_ballot(suspect);
@@ -127,10 +144,10 @@ QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint3
                     todo &= todo - 1;
                     uint32_t hs = qz_readlane(h, s), vs = qz_readlane(v, s);
                     uint64_t same = qz_ballot(live && h == hs) & qz_below(s);
-                    uint32_t cs, cv;
+                    uint32_t cs, cv; bool near = true;
                     if (same) { int m = qz_msb64(same); cs = qz_readlane(f, m); cv = qz_readlane(v, m); }
-                    else { cs = qz_readlane(cand, s); cv = qz_ld32(in + cs); }
-                    if (cv == vs) { fl = s; fcand = cs; break; }
+                    else { cs = qz_readlane(cand, s); cv = qz_ld32(in + cs); near = QZK_LZ4NEAR(cs, qz_readlane(f, s)); }
+                    if (near && cv == vs) { fl = s; fcand = cs; break; }
                 }
                 if (fl == bound && bound < first_dead && HIT) fcand = qz_readlane(cand, bound);
                 const bool got = fl < first_dead && (fl < bound || (HIT && bound < 64 && fl == bound));
@@ -185,14 +202,14 @@ QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint3
                 if ((int32_t)mip >= mfl1) { ended = true; break; }
                 /* fill table with ip-2, then test the next position right away */
                 uint32_t v2 = qz_ld32(in + mip - 2), v0 = qz_ld32(in + mip);
-                uint32_t h2 = QZK_LZ4HASH(v2), h0 = QZK_LZ4HASH(v0);
+                uint32_t h2 = QZK_LZ4H(mip - 2, v2), h0 = QZK_LZ4H(mip, v0);
                 if (lane == 0) table[h2] = mip - 2;
                 qz_wave_sync();
                 uint32_t mi = table[h0];
                 qz_wave_sync();
                 if (lane == 0) table[h0] = mip;
                 qz_wave_sync();
-                if (qz_ld32(in + mi) == v0) { token_at = op++; tok = 0; match = mi; continue; }
+                if (QZK_LZ4NEAR(mi, mip) && qz_ld32(in + mi) == v0) { token_at = op++; tok = 0; match = mi; continue; }
                 break;
             }
             if (ended) break;
@@ -201,7 +218,7 @@ QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint3
     }
     /* last literals */
     {
-        uint32_t lr = n - anchor;
+        uint32_t lr = be - anchor;
         if (op + lr + 1 + (lr + 255 - 15) / 255 > cap) return 0;
         if (lr >= 15) {
             uint32_t acc = lr - 15;
@@ -214,7 +231,11 @@ QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint3
         qzk_wave_copy(out + op, in + anchor, lr, lane); op += lr;
     }
     return op;
+#undef QZK_LZ4H
+#undef QZK_LZ4NEAR
 }
+QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap, uint32_t *table, uint32_t *slot, int lane)
+{ return qzk_lz4_block_t<false>(in, 0, n, out, cap, table, slot, lane); }
 
 /* K4: one LZ4 frame (<= 64 KB of content, one independent block) per wave, written to its slot:
  * LZ4F_compressFrame with {contentChecksum, contentSize, autoFlush, level < 3}. */
@@ -257,6 +278,48 @@ QZ_KERNEL qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_s
         o[pos] = o[pos + 1] = o[pos + 2] = o[pos + 3] = 0;
         o[pos + 4] = (uint8_t)xx; o[pos + 5] = (uint8_t)(xx >> 8); o[pos + 6] = (uint8_t)(xx >> 16); o[pos + 7] = (uint8_t)(xx >> 24);
         out_len[fr] = pos + 8;
+    }
+}
+
+/* K4 for one call above 64 KB: the frame LZ4F_compressFrame writes for it (src/qatzip_sw.c:451-456) - FLG 0x4C (blocks
+ * linked, content size, content checksum), then per 64 KB: block header + block (or the bytes themselves when the block
+ * does not shrink), end mark, XXH32 of the content.  The blocks share one parse state, so this is one wave's serial work
+ * from the first byte to the last; it is what keeps a QZ_LZ4 session's bytes equal to the software path's for every call
+ * size, not a fast path (calls of at most 64 KB, and the 64 KB-frame bench configuration, go through qzk_lz4c_kernel). */
+QZ_KERNEL_MAX(64) qzk_lz4c_linked_kernel(const uint8_t *src, uint32_t n, uint8_t *out, uint32_t *out_len)
+{
+    QZ_LDS uint32_t table[4096];
+    QZ_LDS uint32_t slot[1024];
+    const int lane = qz_lane();
+    for (int i = lane; i < 4096; i += 64) table[i] = 0;
+    if (lane == 0) {
+        out[0] = 0x04; out[1] = 0x22; out[2] = 0x4d; out[3] = 0x18;
+        out[4] = (uint8_t)((1u << 6) | (1u << 3) | (1u << 2));
+        out[5] = 4u << 4;
+        out[6] = (uint8_t)n; out[7] = (uint8_t)(n >> 8); out[8] = (uint8_t)(n >> 16); out[9] = (uint8_t)(n >> 24);
+        out[10] = out[11] = out[12] = out[13] = 0;
+    }
+    qz_wave_sync();
+    uint32_t pos = 14;
+    {
+        uint32_t hc = qzk_wave_xxh32(out + 4, pos - 4, lane);
+        if (lane == 0) out[pos] = (uint8_t)(hc >> 8);
+        pos++;
+    }
+    for (uint32_t bs = 0; bs < n; bs += QZK_LZ4_MAXBLK) {
+        const uint32_t bn = n - bs < QZK_LZ4_MAXBLK ? n - bs : QZK_LZ4_MAXBLK;
+        uint32_t c = qzk_lz4_block_t<true>(src, bs, bn, out + pos + 4, bn - 1, table, slot, lane);
+        const uint32_t bh = c ? c : (bn | 0x80000000u);
+        if (c == 0) { qz_wave_sync(); qzk_wave_copy(out + pos + 4, src + bs, bn, lane); c = bn; }
+        if (lane == 0) { out[pos] = (uint8_t)bh; out[pos + 1] = (uint8_t)(bh >> 8); out[pos + 2] = (uint8_t)(bh >> 16); out[pos + 3] = (uint8_t)(bh >> 24); }
+        pos += 4 + c;
+        qz_wave_sync();
+    }
+    const uint32_t xx = qzk_wave_xxh32(src, n, lane);
+    if (lane == 0) {
+        out[pos] = out[pos + 1] = out[pos + 2] = out[pos + 3] = 0;
+        out[pos + 4] = (uint8_t)xx; out[pos + 5] = (uint8_t)(xx >> 8); out[pos + 6] = (uint8_t)(xx >> 16); out[pos + 7] = (uint8_t)(xx >> 24);
+        *out_len = pos + 8;
     }
 }
 

@@ -223,6 +223,13 @@ int sim_lz4c(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, 
     return (int)nframes;
 }
 
+/* K4, linked mode: ONE frame for a call above 64 KB */
+int sim_lz4c_linked(const uint8_t *src, uint32_t n, uint8_t *out, uint32_t *out_len)
+{
+    sim::launch(1, 64, 0, [&] { qzk_lz4c_linked_kernel(src, n, out, out_len); });
+    return 0;
+}
+
 /* K5: decode nsegs frames */
 int sim_lz4d(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *segs, qzk_lz4res *res, uint32_t nsegs)
 {

@@ -74,6 +74,26 @@ def test_oracle_pin_holds_on_this_box():
     assert n > 300
 
 
+def test_calls_above_64k_are_liblz4s_linked_frames():
+    """compress side: a QZ_LZ4 call above 64 KB gives the bytes liblz4 1.9.3 gives (FLG 0x4C, linked blocks)"""
+    import oracle_lib as O
+    s = A.Session(lz4=True)
+    for fr in LZ4L["frames"]:
+        with open(os.path.join(HERE, "golden", "lz4_linked", fr["file"]), "rb") as f:
+            exp = f.read()
+        src = datagen.gen_bytes(fr["kind"], fr["n"], fr["seed"])
+        rc, used, out, _ = s.compress(src, 1)
+        assert rc == A.QZ_OK and used == len(src) and out == exp, (fr["file"], rc, len(out), len(exp))
+    for kind, n, seed in (("silesia", 1 << 20, 3), ("text", 65536 + 12, 4), ("records", 5 * 65536 + 13, 5), ("rand", 200000, 6)):
+        src = datagen.gen_bytes(kind, n, seed)
+        rc, used, out, _ = s.compress(src, 1)
+        exp = O.sw_compress("LZ4", src, 65536, 1, cap=n + n // 255 + 4096)[2]
+        assert rc == A.QZ_OK and out == exp and out[4] == 0x4c, (kind, n, rc)
+        rc, cused, back = s.decompress(out, n + 64)
+        assert rc == A.QZ_OK and back == src and cused == len(out)
+    s.close()
+
+
 def test_linked_block_lz4_frames_decode():
     """what LZ4F_compressFrame writes for src_len > 64 KB (src/qatzip_sw.c:451-456): one frame, linked blocks (a block
     may reach 64 KB back into the blocks before it), content size + content checksum - liblz4 1.9.3's own bytes"""

@@ -287,3 +287,25 @@ def test_speculative_inflate_matches_serial(sim):
                 assert (res[f] == ref_res[f]).all(), (kind, chunk, K, f, res[f], ref_res[f])
             taken += len(segs) - redone
     assert taken > 50            # the speculative kernel really decoded most of the ordinary segments itself
+
+
+def test_lz4_linked_frames_match_liblz4_goldens(sim):
+    """a QZ_LZ4 call above 64 KB: ONE frame with linked blocks (LZ4F_compressFrame, src/qatzip_sw.c:451-456) - the kernel
+    against liblz4 1.9.3's own frames (tests/golden/lz4_linked) and the oracle on a few more shapes"""
+    import json
+    sim.sim_lz4c_linked.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+    d = os.path.join(HERE, "golden", "lz4_linked")
+    with open(os.path.join(d, "index.json")) as f:
+        idx = json.load(f)
+    cases = [(fr["kind"], fr["n"], fr["seed"], open(os.path.join(d, fr["file"]), "rb").read()) for fr in idx["frames"]]
+    for kind, n, seed in (("text", 65536 + 12, 3), ("text", 65536 + 13, 4), ("silesia", 3 * 65536, 5), ("records", 131072 + 5, 6)):
+        src = datagen.gen_bytes(kind, n, seed)
+        cases.append((kind, n, seed, O.sw_compress("LZ4", src, 65536, 1, cap=n + n // 255 + 1000)[2]))
+    # an incompressible block between compressible ones: stored, and the table keeps what the attempt inserted
+    mix = datagen.gen_bytes("text", 70000, 8) + datagen.gen_bytes("rand", 66000, 9) + datagen.gen_bytes("text", 70000, 8)
+    cases.append(("mix", len(mix), -1, O.sw_compress("LZ4", mix, 65536, 1, cap=len(mix) + 4000)[2]))
+    for kind, n, seed, exp in cases:
+        src = mix if kind == "mix" else datagen.gen_bytes(kind, n, seed)
+        out = C.create_string_buffer(n + n // 255 + 4096); ol = C.c_uint32(0)
+        sim.sim_lz4c_linked(src, n, out, C.byref(ol))
+        assert out.raw[:ol.value] == exp, (kind, n, seed, ol.value, len(exp))
