@@ -27,6 +27,11 @@ while time.time() - t0 < budget:
     s = (A.Session(hw_buff_sz=hw, comp_lvl=lvl, zlib_format=True) if fmt == "ZLIB" else
          A.Session(hw_buff_sz=hw, lz4=True) if fmt == "LZ4" else A.Session(FMT[fmt], hw, comp_lvl=lvl))
     ok = s.rc_setup == A.QZ_OK
+    hwf = fmt in ("GZIP_EXT", "GZIP") and lvl == 1 and rng.random() < 0.25
+    if hwf:
+        import ctypes as C
+        s.L.qzamd_set_hw_framing.argtypes = [C.c_void_p, C.c_int]
+        ok &= s.L.qzamd_set_hw_framing(C.byref(s.s), 1) == A.QZ_OK
     members, plain = [], []
     for m in range(rng.choice([1, 1, 2, 4]) if fmt not in ("RAW", "4B") else 1):
         kind = rng.choice(datagen.KINDS)
@@ -34,9 +39,20 @@ while time.time() - t0 < budget:
         if kind == "lzmix":
             n = min(n, 100000)
         src = datagen.gen_bytes(kind, n, 20000 + seed * 7 + m)
-        if fmt == "LZ4":                                        # one frame per 64 KB, each what a call of its own writes
+        if fmt == "LZ4":                                        # one frame per call: one block, or liblz4's linked blocks above 64 KB
             rc, used, out, _ = s.compress(src, 1, cap=n + 64 * (n // 65536 + 2))
-            exp = b"".join(O.sw_compress("LZ4", src[i:i + 65536], 65536, 1, cap=70000)[2] for i in range(0, max(n, 1), 65536))
+            exp = O.sw_compress("LZ4", src, 65536, 1, cap=n + 64 * (n // 65536 + 2))[2]
+            ok &= rc == A.QZ_OK and used == n and out == exp
+        elif hwf and n:                                         # the hardware path's framing: a complete member per chunk
+            import zlib
+            rc, used, out, _ = s.compress(src, 1)
+            exp = b""
+            for off in range(0, n, hw):
+                ch = src[off:off + hw]
+                body = O.sw_compress("RAW", ch, hw, lvl, last=1)[2]
+                hdr = (bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 255, 12, 0]) + b"QZ" + (8).to_bytes(2, "little") +
+                       len(ch).to_bytes(4, "little") + len(body).to_bytes(4, "little")) if fmt == "GZIP_EXT" else bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255])
+                exp += hdr + body + (zlib.crc32(ch) & 0xffffffff).to_bytes(4, "little") + len(ch).to_bytes(4, "little")
             ok &= rc == A.QZ_OK and used == n and out == exp
         elif rng.random() < 0.3 and n > hw and fmt != "4B":     # the member written by two calls: last = 0, then last = 1
             # (not for the 4-byte header: a stream opened with last = 0 keeps a zero length there, src/qatzip_sw.c:166)
