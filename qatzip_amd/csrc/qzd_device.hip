@@ -80,6 +80,13 @@ __global__ void __launch_bounds__(256) qzk_copy16_kernel(const uint4 *__restrict
 }
 
 /* ------------------------------------------------------------------ context (qzd_internal.h) */
+static qzd_k1pool g_k1pool[QZD_MAX_DEVICES];
+static pthread_once_t g_k1pool_once = PTHREAD_ONCE_INIT;
+static void k1pool_init(void)
+{
+    for (int i = 0; i < QZD_MAX_DEVICES; i++) { memset(&g_k1pool[i], 0, sizeof(g_k1pool[i])); pthread_mutex_init(&g_k1pool[i].lock, NULL); g_k1pool[i].epoch = 1; }
+}
+
 int qzd_aux_reserve(qzd_ctx *c, size_t n)
 {
     if (n <= c->aux_cap) return QZD_OK;
@@ -157,10 +164,9 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         unsigned a = 0;
         if (e && sscanf(e, "%u", &a) == 1 && a > 0 && a <= 65536) c->k1_wgs = a;
         c->batch_chunks = QZD_BATCH_ROUNDS * c->k1_wgs;
-        /* the tables (16 MiB per workgroup, 4 GiB for a full device) are allocated by the first call that needs them and
-         * only as many as its chunks can occupy: a session that decompresses, or only ever sees small calls, holds none
-         * or few */
-        c->k1_tables = NULL; c->k1_tab_wgs = 0; c->k1_epoch = 1;
+        /* the tables (16 MiB per workgroup, 4 GiB for a full device) belong to the device (g_k1pool): allocated by the
+         * first call that needs them and only as many as its chunks can occupy, shared by every context on the GPU */
+        c->k1_held = false;
         if (hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) QZD_CREATE_FAIL;
     }
     if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) QZD_CREATE_FAIL;
@@ -177,7 +183,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (int i = 0; i < QZD_NBUF; i++) {
-        hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
+        hipFree(c->slots[i]);
         /* handles may be missing: qzd_create comes here from its failure paths */
         if (c->st[i]) hipStreamDestroy(c->st[i]);
         if (c->done[i]) hipEventDestroy(c->done[i]);
@@ -192,7 +198,8 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);
     for (int i = 0; i < QZD_K1EV; i++) { if (c->k1ev[i][0]) hipEventDestroy(c->k1ev[i][0]); if (c->k1ev[i][1]) hipEventDestroy(c->k1ev[i][1]); }
-    hipFree(c->k1_tables); hipFree(c->k1_counter);
+    if (c->k1_held) { c->k1_held = false; pthread_mutex_unlock(&g_k1pool[c->device % QZD_MAX_DEVICES].lock); }
+    hipFree(c->k1_counter);
     hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
     hipHostFree(c->h_running); hipHostFree(c->h_overflow);
     if (c->d_aux) hipFree(c->d_aux);
@@ -273,24 +280,26 @@ extern "C" void qzd_host_free_pinned(void *p) { if (p) hipHostFree(p); }
 
 static uint32_t slot_stride_for(uint32_t chunk_sz) { return (chunk_sz / 8u * 9u + 1024u + 15u) & ~15u; }
 
-static int ensure_scratch(qzd_ctx *c, uint32_t chunk_sz, uint32_t nchunks)
+/* the device pool's batch scratch (called with the pool's lock held) and this context's per-call arrays */
+static int ensure_scratch(qzd_ctx *c, qzd_k1pool *pool, uint32_t chunk_sz, uint32_t nchunks)
 {
     uint32_t batch = nchunks < c->batch_chunks ? nchunks : c->batch_chunks;
     size_t sym = (size_t)batch * chunk_sz + 256, slot = (size_t)batch * slot_stride_for(chunk_sz);
-    if (sym > c->sym_cap || slot > c->slot_cap || batch > c->meta_cap) {
+    if (sym > pool->sym_cap || slot > pool->slot_cap || batch > pool->meta_cap) {
         hipDeviceSynchronize();
-        c->sym_cap = 0; c->slot_cap = 0; c->meta_cap = 0;      /* set again only when every allocation below succeeded */
+        sym = std::max(sym, pool->sym_cap); slot = std::max(slot, pool->slot_cap); batch = std::max(batch, pool->meta_cap);
+        pool->sym_cap = 0; pool->slot_cap = 0; pool->meta_cap = 0;      /* set again only when every allocation below succeeded */
         for (int i = 0; i < QZD_NBUF; i++) {
-            hipFree(c->sym_lc[i]); hipFree(c->sym_dist[i]); hipFree(c->slots[i]); hipFree(c->meta[i]);
-            c->sym_lc[i] = NULL; c->sym_dist[i] = NULL; c->slots[i] = NULL; c->meta[i] = NULL;
+            hipFree(pool->sym_lc[i]); hipFree(pool->sym_dist[i]); hipFree(pool->slots[i]); hipFree(pool->meta[i]);
+            pool->sym_lc[i] = NULL; pool->sym_dist[i] = NULL; pool->slots[i] = NULL; pool->meta[i] = NULL;
         }
         for (int i = 0; i < QZD_NBUF; i++) {
-            HIPCHK(c, hipMalloc(&c->sym_lc[i], sym));
-            HIPCHK(c, hipMalloc(&c->sym_dist[i], sym * 2));
-            HIPCHK(c, hipMalloc(&c->slots[i], slot));
-            HIPCHK(c, hipMalloc(&c->meta[i], (size_t)batch * sizeof(qzk_lzmeta)));
+            HIPCHK(c, hipMalloc(&pool->sym_lc[i], sym));
+            HIPCHK(c, hipMalloc(&pool->sym_dist[i], sym * 2));
+            HIPCHK(c, hipMalloc(&pool->slots[i], slot));
+            HIPCHK(c, hipMalloc(&pool->meta[i], (size_t)batch * sizeof(qzk_lzmeta)));
         }
-        c->sym_cap = sym; c->slot_cap = slot; c->meta_cap = batch;
+        pool->sym_cap = sym; pool->slot_cap = slot; pool->meta_cap = batch;
     }
     if (nchunks > c->call_cap) {
         hipDeviceSynchronize();
@@ -375,8 +384,20 @@ static int deflate_lazy_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
                              uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks, const uint32_t *cdesc);
 
 /* cdesc (device memory, or NULL): per-chunk length / closes-its-stream flag of a coalesced launch (qzk_chunk_len) */
+static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
+                                int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc, const uint8_t *h_src);
 static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
                            int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc, const uint8_t *h_src = NULL)
+{
+    const int rc = deflate_enqueue_impl(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, cdesc, h_src);
+    if (rc != QZD_OK && c && c->k1_held) {          /* an enqueue that failed half way gives the device's tables back */
+        hipStreamSynchronize(c->st[0]); hipStreamSynchronize(c->st[1]); hipStreamSynchronize(c->st_copy);
+        c->k1_held = false; pthread_mutex_unlock(&g_k1pool[c->device % QZD_MAX_DEVICES].lock);
+    }
+    return rc;
+}
+static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
+                                int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc, const uint8_t *h_src)
 {
     if (!c || !d_dst || (n && !d_src)) return QZD_ERR_PARAM;
     if (chunk_sz < 1024 || chunk_sz > 512 * 1024 || (chunk_sz & (chunk_sz - 1))) return QZD_ERR_PARAM;
@@ -394,29 +415,39 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
         if (level >= 4 && !(lz && lz[0] == '0')) return deflate_lazy_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
         if (level != 1 || (force && force[0] == 'l')) return deflate_lane_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
     }
-    int rc = ensure_scratch(c, chunk_sz, nchunks);
-    if (rc) return rc;
     const uint32_t max_wgs = (c->k1_wgs + QZK_K1_WAVES - 1) / QZK_K1_WAVES;      /* workgroups of a full launch (one per CU) */
+    qzd_k1pool *const pool = &g_k1pool[c->device % QZD_MAX_DEVICES];
     {
         /* a launch of few chunks spreads them over workgroups (CUs) before it stacks them on the waves of one */
         const uint32_t want = nchunks < max_wgs ? nchunks : max_wgs;
-        if (want > c->k1_tab_wgs) {
+        /* the device's tables and batch scratch: taken for the whole call (released by qzd_sync, or by the caller of
+         * this function when it fails) */
+        pthread_once(&g_k1pool_once, k1pool_init);
+        if (!c->k1_held) { pthread_mutex_lock(&pool->lock); c->k1_held = true; }
+        const int rc = ensure_scratch(c, pool, chunk_sz, nchunks);
+        if (rc) return rc;
+        if (want > pool->tab_wgs) {
             hipDeviceSynchronize();
-            if (c->k1_tables) hipFree(c->k1_tables);
-            c->k1_tables = NULL; c->k1_tab_wgs = 0;
+            if (pool->tables) hipFree(pool->tables);
+            pool->tables = NULL; pool->tab_wgs = 0;
             const uint32_t get = want > max_wgs / 4 ? max_wgs : want;     /* a big call: take the whole set at once */
             const size_t tb = (size_t)get * QZK_HSIZE * QZK_K1_WAVES * sizeof(qzk_bkt);
-            HIPCHK(c, hipMalloc(&c->k1_tables, tb));
-            HIPCHK(c, hipMemset(c->k1_tables, 0, tb));                    /* epoch 0 = never valid */
-            HIPCHK(c, hipDeviceSynchronize());                            /* hipMemset of device memory returns early, and the
+            if (hipMalloc(&pool->tables, tb) != hipSuccess || hipMemset(pool->tables, 0, tb) != hipSuccess ||   /* epoch 0 = never valid */
+                hipDeviceSynchronize() != hipSuccess) {                   /* hipMemset of device memory returns early, and the
                                                                            * (non-blocking) work streams do not wait for it */
-            c->k1_tab_wgs = get;
+                if (pool->tables) hipFree(pool->tables);
+                pool->tables = NULL;
+                c->k1_held = false; pthread_mutex_unlock(&pool->lock);
+                snprintf(c->err, sizeof(c->err), "K1 tables: out of device memory");
+                return QZD_ERR_HIP;
+            }
+            pool->tab_wgs = get;
         }
-        if ((uint64_t)c->k1_epoch + nchunks + 1 >= 0xffffffffull) {        /* epochs wrapped: forget everything once */
+        if ((uint64_t)pool->epoch + nchunks + 1 >= 0xffffffffull) {        /* epochs wrapped: forget everything once */
             hipDeviceSynchronize();
-            HIPCHK(c, hipMemset(c->k1_tables, 0, (size_t)c->k1_tab_wgs * QZK_HSIZE * QZK_K1_WAVES * sizeof(qzk_bkt)));
-            HIPCHK(c, hipDeviceSynchronize());
-            c->k1_epoch = 1;
+            hipMemset(pool->tables, 0, (size_t)pool->tab_wgs * QZK_HSIZE * QZK_K1_WAVES * sizeof(qzk_bkt));
+            hipDeviceSynchronize();
+            pool->epoch = 1;
         }
     }
     const uint32_t stride = slot_stride_for(chunk_sz);
@@ -434,7 +465,7 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
     /* with the input still on the host the first batch is one round of the persistent workgroups instead of three:
      * nothing can overlap its copy, so it is kept short */
     const uint32_t FIRST = h_src && nchunks > BATCH ? std::max<uint32_t>(c->k1_wgs, 1024u) : BATCH;
-    const uint32_t tab_wgs = c->k1_tab_wgs;
+    const uint32_t tab_wgs = pool->tab_wgs;
     if (FIRST != BATCH) c->nbatches = 1 + (nchunks - FIRST + BATCH - 1) / BATCH;
     for (uint32_t b = 0, k = 0, bnext = 0; b < nchunks; b = bnext, k++) {
         const int s = (int)(k % QZD_NBUF), so = (int)((k + 1) % QZD_NBUF);
@@ -469,14 +500,14 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
         if (k < QZD_K1EV) HIPCHK(c, hipEventRecord(c->k1ev[k][0], st));
         hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64 * wpw), 0, st, d_src + boff, blen, chunk_sz, bn,
-                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->k1_tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
-                           c->k1_epoch);
-        c->k1_epoch += bn;
+                           pool->sym_lc[s], pool->sym_dist[s], pool->meta[s], pool->tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
+                           pool->epoch);
+        pool->epoch += bn;
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
         hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HW), 0, st, d_src + boff, blen, chunk_sz, bn,
-                           c->sym_lc[s], c->sym_dist[s], c->meta[s], c->slots[s], stride, final_chunk,
+                           pool->sym_lc[s], pool->sym_dist[s], pool->meta[s], pool->slots[s], stride, final_chunk,
                            c->d_len + b, cdesc ? cdesc + b : NULL);
         hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn, c->d_crc + b,
                            cdesc ? cdesc + b : NULL);
@@ -484,7 +515,7 @@ static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_
         /* the running total serialises scan/gather of consecutive batches across the two streams */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->done[so], 0));
         hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);
-        hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, c->slots[s], stride, c->d_len + b,
+        hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, pool->slots[s], stride, c->d_len + b,
                            c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][3], st));
         HIPCHK(c, hipEventRecord(c->done[s], st));
@@ -626,9 +657,9 @@ extern "C" int qzd_sync(qzd_ctx *c)
 {
     if (!c) return QZD_ERR_PARAM;
     hipSetDevice(c->device);
-    HIPCHK(c, hipStreamSynchronize(c->st[0]));
-    HIPCHK(c, hipStreamSynchronize(c->st[1]));
-    HIPCHK(c, hipStreamSynchronize(c->st_copy));
+    const hipError_t e0 = hipStreamSynchronize(c->st[0]), e1 = hipStreamSynchronize(c->st[1]), e2 = hipStreamSynchronize(c->st_copy);
+    if (c->k1_held) { c->k1_held = false; pthread_mutex_unlock(&g_k1pool[c->device % QZD_MAX_DEVICES].lock); }   /* the call's K1 launches are done */
+    HIPCHK(c, e0); HIPCHK(c, e1); HIPCHK(c, e2);
     for (uint32_t k = 0; k < c->k1ev_n; k++) {      /* harvest the K1 launch timings of the call that just finished */
         float t = 0;
         if (hipEventElapsedTime(&t, c->k1ev[k][0], c->k1ev[k][1]) == hipSuccess) {
@@ -803,7 +834,7 @@ extern "C" int qzd_lz4_decompress_frames(qzd_ctx *c, const uint8_t *d_comp, uint
 extern "C" int qzd_debug_meta(qzd_ctx *c, int s, void *h_out, uint32_t nchunks)
 {
     hipSetDevice(c->device);
-    HIPCHK(c, hipMemcpy(h_out, c->meta[s], (size_t)nchunks * sizeof(qzk_lzmeta), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h_out, g_k1pool[c->device % QZD_MAX_DEVICES].meta[s], (size_t)nchunks * sizeof(qzk_lzmeta), hipMemcpyDeviceToHost));
     return (int)sizeof(qzk_lzmeta);
 }
 #endif

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <pthread.h>
 #include "../../include/qzamd_device.h"
 #include "qzk_deflate_lz77.h"
 
@@ -19,20 +20,20 @@ struct qzd_ctx {
     hipStream_t st[QZD_NBUF];
     hipStream_t st_copy; hipEvent_t cp_ev[QZD_NBUF + 1];   /* host input arrives batch by batch while the previous batch is parsed */
     hipEvent_t done[QZD_NBUF], k1done[QZD_NBUF];
-    /* scratch per buffer set */
-    uint8_t *sym_lc[QZD_NBUF]; uint16_t *sym_dist[QZD_NBUF]; uint8_t *slots[QZD_NBUF];
-    qzk_lzmeta *meta[QZD_NBUF];
+    /* output slots of the LZ4 frame kernel (the deflate pipeline's scratch lives in the device's pool, qzd_k1pool) */
+    uint8_t *slots[QZD_NBUF];
     /* K1 (persistent pull kernel): one candidate table (65536 x QZK_K1_WAVES entries of 16 bytes = 16 MiB) per resident
      * workgroup, one chunk counter per buffer set */
-    qzk_bkt *k1_tables; uint32_t *k1_counter;
-    uint32_t k1_tab_wgs;                            /* workgroups k1_tables has room for (grown on demand) */
+    /* The tables belong to the DEVICE, not to the context (qzd_k1pool): every session of a process on one GPU parses
+     * with the same 4 GiB - a context borrows them from its first K1 launch of a call until qzd_sync(). */
+    uint32_t *k1_counter;
+    bool k1_held;                                   /* this context holds its device's table pool */
     uint32_t k1_wgs;                                /* resident pulling WAVES (QZK_K1_WAVES per workgroup, one workgroup per CU) */
-    uint32_t k1_epoch;                              /* next unused chunk epoch (entries of the tables are tagged with it; never 0) */
     uint32_t batch_chunks;
     /* K1 launch durations (HIP events around every K1 launch, harvested at qzd_sync): bench.py's roofline input */
     hipEvent_t k1ev[QZD_K1EV][2]; uint32_t k1ev_chunks[QZD_K1EV]; uint32_t k1ev_n;
     double k1_ms_acc; uint64_t k1_launch_acc, k1_chunk_acc;
-    size_t sym_cap, slot_cap; uint32_t meta_cap;
+    size_t slot_cap;
     /* per-call arrays */
     uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;
     uint64_t *d_running; uint32_t *d_overflow;
@@ -58,6 +59,18 @@ struct qzd_ctx {
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
     return QZD_ERR_HIP; } } while (0)
+
+/* K1's candidate tables, one set per device and process: 65536 x QZK_K1_WAVES entries of 16 bytes per workgroup, grown
+ * on demand; `epoch` = next unused chunk epoch (entries are tagged with it; never 0).  lock serialises the K1 launches of
+ * different contexts (one big call fills the chip anyway; small calls meet in the coalescing queue, not here). */
+struct qzd_k1pool {
+    pthread_mutex_t lock; qzk_bkt *tables; uint32_t tab_wgs; uint32_t epoch;
+    /* K1 -> K2 hand-over of a batch (symbols, block marks) and K2's output slots, two sets: the same lifetime as the
+     * tables' loan, so they are the device's as well (6.3 GiB at 64 KB chunks, once instead of per session) */
+    uint8_t *sym_lc[2]; uint16_t *sym_dist[2]; uint8_t *slots[2]; qzk_lzmeta *meta[2];
+    size_t sym_cap, slot_cap; uint32_t meta_cap;
+};
+#define QZD_MAX_DEVICES 64
 
 /* grow the aux scratch pair to at least n bytes */
 int qzd_aux_reserve(qzd_ctx *c, size_t n);

@@ -64,6 +64,7 @@ typedef struct __attribute__((aligned(16))) { uint32_t w0, w1, w2, ep; } qzk_bkt
 /* moved as ONE 16-byte access (a struct load lets the compiler fetch ep first and the rest behind a branch: two dependent
  * round trips to HBM) */
 typedef uint32_t qzk_u32x4 __attribute__((vector_size(16)));
+typedef uint32_t qz_u32nt __attribute__((aligned(1)));      /* a dword at any byte address, for the non-temporal builtin */
 
 /* The gather of a table entry is served by the L2 (agent-scope `sc1` load), never by this CU's vector L1: the sixteen
  * waves of a workgroup keep their entries of one bucket in one cache line, and the L1 (write-through, no write-allocate,
@@ -226,7 +227,11 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 do {
                     const uint32_t a = rhi + 4 * (uint32_t)lane;
                     const uint64_t g = coff + a;
+#if defined(QZK_NT) && !defined(QZ_SIM)      /* streamed once: keep it from displacing table lines in L2 */
+                    ring[(a >> 2) & (QZK_RINGW - 1)] = g + 4 <= src_len ? __builtin_nontemporal_load((const qz_u32nt *)(src + g)) : qzk_ld32g(src, g, src_len);
+#else
                     ring[(a >> 2) & (QZK_RINGW - 1)] = g + 4 <= src_len ? qz_ld32(src + g) : qzk_ld32g(src, g, src_len);
+#endif
                     rhi += 256;
                 } while (rhi < pos + 64 + 2 * QZK_CAP);
                 qz_lds_sync();
@@ -440,8 +445,13 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         const uint32_t idx = nsym + rank;
         const uint32_t step = mlen ? mlen : 1;
         if (isP) {
+#if defined(QZK_NT) && !defined(QZ_SIM)
+            __builtin_nontemporal_store((uint8_t)(mlen ? mlen - 3 : (w0 & 0xff)), &olc[idx]);
+            __builtin_nontemporal_store((uint16_t)mdist, &odist[idx]);
+#else
             olc[idx] = (uint8_t)(mlen ? mlen - 3 : (w0 & 0xff));
             odist[idx] = (uint16_t)mdist;
+#endif
         }
         {   /* a symbol that completes a 32767-symbol block (at most one per window) */
             const bool closes = isP && ((idx + 1) % QZK_LITBUF == 0);

@@ -411,6 +411,34 @@ def test_synchronous_calls_of_many_threads_share_launches():
     assert r1.value - r0.value >= NT                         # calls did share launches
 
 
+def test_large_calls_of_several_threads_share_the_device_tables():
+    """one session per thread, every thread making calls far above the coalescing limit at the same time: the LZ77
+    candidate tables belong to the device, a context borrows them for the duration of a call"""
+    import threading
+    errs, start = [], threading.Barrier(3)
+
+    def body(t):
+        try:
+            s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+            src = datagen.gen_bytes(("silesia", "text", "records")[t], (24 << 20) + 4099 * t, 70 + t)
+            exp = O.sw_compress("GZIP_EXT", src, 65536, 1, cap=len(src) * 9 // 8 + 65536)[2]
+            start.wait()
+            for _ in range(3):
+                rc, used, out, _ = s.compress(src, 1)
+                assert rc == A.QZ_OK and used == len(src) and out == exp, (t, rc)
+                rc, cused, back = s.decompress(out, len(src) + 64)
+                assert rc == A.QZ_OK and back == src, (t, rc)
+            s.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append((t, repr(e)[:300]))
+    th = [threading.Thread(target=body, args=(t,)) for t in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(900)
+    assert not errs, errs
+
+
 def test_crc_known_answer_like_reference_test():
     # test/main.c:4283-4337: qzCompressCrc's crc == zlib crc32(src) for 64 KB and 1023 B
     s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
