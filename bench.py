@@ -272,7 +272,7 @@ def one_stream_leg(ctx, qz, pg, rank, world, d_src, shard_mb):
     as peer copies (xGMI between GPUs), rank 0 folds the CRCs and closes the gzip-ext member (qzd_shard_*)."""
     from qatzip_amd import shard
     n = shard_mb << 20
-    return shard.one_stream(ctx, pg, rank, world, view(qz, d_src, 0, n), n, CHUNK)
+    return shard.one_stream(ctx, pg, rank, world, view(qz, d_src, 0, n), n, CHUNK, verify="sample")
 
 
 def main():

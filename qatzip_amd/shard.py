@@ -85,11 +85,23 @@ def broadcast_bytes(pg, data: bytes, nbytes: int, src: int = 0) -> bytes:
     return bytes(t.tolist())
 
 
-def one_stream(ctx, pg, rank, world, d_src, n, chunk, level=1, timeout_s=60.0, seq=1, verify=None):
+def _all_ok(pg, ok: bool) -> bool:
+    """every rank learns whether every rank is fine (so that nobody waits for a rank that gave up)"""
+    if pg is None:
+        return ok
+    import torch
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    pg.all_reduce(t, op=pg.ReduceOp.MIN)
+    return bool(t[0])
+
+
+def one_stream(ctx, pg, rank, world, d_src, n, chunk, level=1, timeout_s=30.0, seq=1, verify=None):
     """ONE gzip-ext member out of `world` shards of n bytes each (rank r holds shard r in d_src): every rank deflates its
     shard on its GPU, the compressed shards travel to rank 0's HBM as peer copies (qzd_shard_*), rank 0 closes the member.
     Returns a dict (rank 0: sizes, time, the member's bytes under "stream" if verify == "full"); other ranks: {}.
-    verify: None | "sample" (rank 0's own shard prefix against the oracle + trailer against the ranks' CPU CRCs) | "full"."""
+    verify: None | "sample" (rank 0's own shard prefix against the oracle + trailer against the ranks' CPU CRCs) | "full".
+    Every step that can fail on one rank only (IPC mapping, peer copy) is followed by an agreement among the ranks, so a
+    failure ends the leg everywhere with {"error": ...} instead of leaving ranks waiting for each other."""
     import ctypes as C
     import time
     import zlib
@@ -99,32 +111,48 @@ def one_stream(ctx, pg, rank, world, d_src, n, chunk, level=1, timeout_s=60.0, s
     cap = world * (_lib.max_deflate_len(n, chunk) + 64)
     hbuf = C.create_string_buffer(64)
     win = C.c_void_p()
+    err = None
     if rank == 0:
-        ctx._chk(L.qzd_shard_root_create(ctx.h, world, cap, hbuf, C.byref(win)))
+        if L.qzd_shard_root_create(ctx.h, world, cap, hbuf, C.byref(win)) != 0:
+            err = "root window: " + L.qzd_last_error(ctx.h).decode()
     handle = broadcast_bytes(pg, hbuf.raw if rank == 0 else None, 64, 0) if world > 1 else hbuf.raw
-    if rank != 0:
-        ctx._chk(L.qzd_shard_attach(ctx.h, rank, world, handle, cap, C.byref(win)))
+    if rank != 0 and err is None:
+        if L.qzd_shard_attach(ctx.h, rank, world, handle, cap, C.byref(win)) != 0:
+            err = "attach: " + L.qzd_last_error(ctx.h).decode()
+    if not _all_ok(pg, err is None):
+        if win:
+            L.qzd_shard_close(win)
+        return {"error": err or "another rank could not map the window"}
     d_comp = ctx.alloc(_lib.max_deflate_len(n, chunk))
     if pg is not None:
         pg.barrier()
     t0 = time.perf_counter()
-    clen, crcs = ctx.deflate_raw(d_src, n, chunk, level, 1 if rank == world - 1 else 0, d_comp)
-    crc = 0
-    for i, c in enumerate(crcs):                                # the shard's CRC-32 from its chunks' (crc32_combine algebra)
-        cl = min(chunk, n - i * chunk)
-        crc = int(c) if i == 0 else L.qzd_crc32_combine(crc, int(c), cl)
-    off = C.c_uint64(0)
-    ctx._chk(L.qzd_shard_put(win, d_comp.ptr, clen, n, crc, seq, timeout_s, C.byref(off)))
+    clen, crc = 0, 0
+    try:
+        clen, crcs = ctx.deflate_raw(d_src, n, chunk, level, 1 if rank == world - 1 else 0, d_comp)
+        for i, c in enumerate(crcs):                            # the shard's CRC-32 from its chunks' (crc32_combine algebra)
+            cl = min(chunk, n - i * chunk)
+            crc = int(c) if i == 0 else L.qzd_crc32_combine(crc, int(c), cl)
+        off = C.c_uint64(0)
+        if L.qzd_shard_put(win, d_comp.ptr, clen, n, crc, seq, timeout_s, C.byref(off)) != 0:
+            err = "put: " + L.qzd_last_error(ctx.h).decode()
+    except Exception as e:   # noqa: BLE001
+        err = "deflate: " + str(e)[:150]
     out = {}
-    if rank == 0:
-        dptr, slen, fcrc, raw = C.c_void_p(), C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
-        ctx._chk(L.qzd_shard_finish(win, seq, timeout_s, C.byref(dptr), C.byref(slen), C.byref(fcrc), C.byref(raw)))
-        dt = time.perf_counter() - t0
-        out = {"ranks": world, "raw_bytes": raw.value, "member_bytes": slen.value, "ms": round(dt * 1e3, 2),
-               "GBps": round(raw.value / dt / 1e9, 2), "crc32": "%08x" % fcrc.value,
-               "transport": "peer copies into an IPC window in rank 0's HBM (xGMI between GPUs)"}
-    if pg is not None:
-        pg.barrier()
+    dptr = C.c_void_p()
+    if rank == 0 and err is None:
+        slen, fcrc, raw = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+        if L.qzd_shard_finish(win, seq, timeout_s, C.byref(dptr), C.byref(slen), C.byref(fcrc), C.byref(raw)) != 0:
+            err = "finish: " + L.qzd_last_error(ctx.h).decode()
+        else:
+            dt = time.perf_counter() - t0
+            out = {"ranks": world, "raw_bytes": raw.value, "member_bytes": slen.value, "ms": round(dt * 1e3, 2),
+                   "GBps": round(raw.value / dt / 1e9, 2), "crc32": "%08x" % fcrc.value,
+                   "transport": "peer copies into an IPC window in rank 0's HBM (xGMI between GPUs)"}
+    if not _all_ok(pg, err is None):
+        L.qzd_shard_close(win)
+        d_comp.free()
+        return {"error": err or "another rank failed"}
     if verify:
         host = d_src.download(n)
         my_crc = zlib.crc32(host.tobytes()) & 0xffffffff
@@ -136,7 +164,7 @@ def one_stream(ctx, pg, rank, world, d_src, n, chunk, level=1, timeout_s=60.0, s
             mb = member.tobytes()
             ok = mb[:4] == b"\x1f\x8b\x08\x04" and int.from_bytes(mb[16:20], "little") == raw_t and \
                 int.from_bytes(mb[20:24], "little") == comp_t and int.from_bytes(mb[-8:-4], "little") == crc_t and \
-                int.from_bytes(mb[-4:], "little") == (raw_t & 0xffffffff) and fcrc.value == crc_t
+                int.from_bytes(mb[-4:], "little") == (raw_t & 0xffffffff) and int(out["crc32"], 16) == crc_t
             if ok:
                 import sys
                 import os
@@ -149,7 +177,8 @@ def one_stream(ctx, pg, rank, world, d_src, n, chunk, level=1, timeout_s=60.0, s
             out["verified"] = bool(ok)
             if verify == "full":
                 out["stream"] = mb
-    ctx._chk(0)
+    if pg is not None:
+        pg.barrier()                                            # nobody unmaps the window before rank 0 has read it
     L.qzd_shard_close(win)
     d_comp.free()
     return out
