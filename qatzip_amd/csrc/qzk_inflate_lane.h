@@ -162,30 +162,42 @@ QZ_DEV int qzk_ldecode_long(qzk_lbits *b, int rootbits, const uint16_t *sorted, 
  * segment's sorted list.  (The ranges in the per-segment HBM record cost a lane two dependent loads per length tried -
  * and the fifteen other lanes of its wave wait with it: with rare long codes in every segment nearly every trip of a
  * wave had one.) */
-#define QZK_LR_WORDS 9
-QZ_DEV void qzk_longtab_load(uint32_t *LR, const qzk_inf_tab *T, int lmax)
+/* ROOT = bits of the root table; lengths ROOT+1 .. 15 => N = 15 - ROOT ranges in N + (N + 1) / 2 words */
+#define QZK_LT_WORDS(ROOT) ((15 - (ROOT)) + (16 - (ROOT)) / 2)
+#define QZK_LR_WORDS QZK_LT_WORDS(QZK_LLROOT)
+#define QZK_DR_WORDS QZK_LT_WORDS(QZK_LDROOT)
+template <int ROOT>
+QZ_DEV void qzk_longtab_load_t(uint32_t *LR, const uint16_t *first_, const uint16_t *count_, const uint16_t *index_, int maxlen)
 {
-    for (int k = 0; k < 6; k++) {
-        const int l = QZK_LLROOT + 1 + k;
+    constexpr int N = 15 - ROOT;
+    for (int k = 0; k < N; k++) {
+        const int l = ROOT + 1 + k;
         uint32_t first = 0, limit = 0, d = 0;
-        if (l <= lmax) { first = T->lfirst[l]; limit = first + T->lcount[l]; d = ((uint32_t)T->lindex[l] - first) & 0xffffu; }
+        if (l <= maxlen) { first = first_[l]; limit = first + count_[l]; d = ((uint32_t)index_[l] - first) & 0xffffu; }
         LR[k] = first | (limit << 15);
-        if (k & 1) LR[6 + (k >> 1)] |= d << 16; else LR[6 + (k >> 1)] = d;
+        if (k & 1) LR[N + (k >> 1)] |= d << 16; else LR[N + (k >> 1)] = d;
     }
 }
-QZ_DEV int qzk_ldecode_long_reg(qzk_lbits *b, const uint32_t *LR, const uint16_t *sorted, int maxlen)
+template <int ROOT>
+QZ_DEV int qzk_ldecode_long_reg_t(qzk_lbits *b, const uint32_t *LR, const uint16_t *sorted, int maxlen)
 {
+    constexpr int N = 15 - ROOT;
     const uint32_t V = qzk_rev((uint32_t)b->bb & 0x7fffu, 15);
     uint32_t sel_l = 0, sel_i = 0;
-    for (int k = 5; k >= 0; k--) {                              /* longest first: the shortest hit is kept */
-        const int l = QZK_LLROOT + 1 + k;
+    for (int k = N - 1; k >= 0; k--) {                          /* longest first: the shortest hit is kept */
+        const int l = ROOT + 1 + k;
         const uint32_t first = LR[k] & 0x7fffu, limit = LR[k] >> 15, c = V >> (15 - l);
-        const uint32_t d = (LR[6 + (k >> 1)] >> (16 * (k & 1))) & 0xffffu;
+        const uint32_t d = (LR[N + (k >> 1)] >> (16 * (k & 1))) & 0xffffu;
         if (l <= maxlen && l <= b->bc && c >= first && c < limit) { sel_l = (uint32_t)l; sel_i = (c + d) & 0xffffu; }
     }
     int sym = -1;
     if (sel_l) { QZK_DROP(b, sel_l); sym = sorted[sel_i]; }
     return sym;
+}
+QZ_DEV void qzk_longtab_load(uint32_t *LR, uint32_t *DR, const qzk_inf_tab *T, int lmax, int dmax)
+{
+    qzk_longtab_load_t<QZK_LLROOT>(LR, T->lfirst, T->lcount, T->lindex, lmax);
+    qzk_longtab_load_t<QZK_LDROOT>(DR, T->dfirst, T->dcount, T->dindex, dmax);
 }
 
 /* per-lane decode state that the cold paths (block header, stored run) share with the kernel */
@@ -393,14 +405,14 @@ QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
  * straight-line code.  MIDREFILL: the caller's reader guarantees < 48 valid bits, refill before the distance code. */
 template <bool MIDREFILL, bool PAIR>
 QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, const uint16_t *lroot,
-                            const uint16_t *droot, uint64_t hist, const uint32_t *LR = 0)
+                            const uint16_t *droot, uint64_t hist, const uint32_t *LR = 0, const uint32_t *DR = 0)
 {
     qzk_lbits *b = &S->b;
     const uint32_t e = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
     int sym;
     if (e != 0 && (int)(e & 15) <= b->bc) { QZK_DROP(b, e & 15); sym = (int)(e >> 4); }
     else if (e) sym = -1;
-    else if (LR) sym = qzk_ldecode_long_reg(b, LR, T->lsorted, S->lmax);
+    else if (LR) sym = qzk_ldecode_long_reg_t<QZK_LLROOT>(b, LR, T->lsorted, S->lmax);
     else sym = qzk_ldecode_long(b, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, S->lmax);
     if (sym < 256) {
         if (sym < 0) { S->status = b->pos >= b->end && b->bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA; S->state = QZK_LS_DONE; }
@@ -435,7 +447,9 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
         const uint32_t de = droot[(uint32_t)b->bb & ((1u << QZK_LDROOT) - 1)];
         int ds;
         if (de != 0 && (int)(de & 15) <= b->bc) { QZK_DROP(b, de & 15); ds = (int)(de >> 4); }
-        else ds = de ? -1 : qzk_ldecode_long(b, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, S->dmax);
+        else if (de) ds = -1;
+        else if (DR) ds = qzk_ldecode_long_reg_t<QZK_LDROOT>(b, DR, T->dsorted, S->dmax);
+        else ds = qzk_ldecode_long(b, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, S->dmax);
         if (!err && (ds < 0 || ds >= 30)) err = b->pos >= b->end && b->bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA;
         if (ds < 0 || ds >= 30) ds = 0;
         xb = ds < 4 ? 0u : (uint32_t)(ds - 2) >> 1;
@@ -478,8 +492,9 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
 #ifdef QZK_INF_PROF
     uint32_t prof_trips = 0; const uint64_t prof_t0 = __builtin_readcyclecounter();
 #endif
-    uint32_t LR[QZK_LR_WORDS];                  /* the long literal/length codes of the current block (registers) */
+    uint32_t LR[QZK_LR_WORDS], DR[QZK_DR_WORDS];    /* the long literal/length and distance codes of the current block (registers) */
     for (int i = 0; i < QZK_LR_WORDS; i++) LR[i] = 0;
+    for (int i = 0; i < QZK_DR_WORDS; i++) DR[i] = 0;
 
     while (S.state != QZK_LS_DONE) {
         qzk_lbits *b = &S.b;
@@ -491,12 +506,26 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
              * that lanes parked in a cold state get their turn. ---- */
             b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;     /* hand whole bytes back */
             uint64_t pw = qzk_ld64u(b->p + b->pos);
+#if !defined(QZ_SIM) && defined(QZK_PREFETCH)
+            uint32_t pf1 = 0, pf2 = 0;                  /* lines requested one / two trips ago */
+#endif
             for (int round = 0; round < 32 && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; round++) {
                 for (int trip = 0; trip < QZK_TOK_ROUND && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
                     b->bb |= pw << b->bc;
                     b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
                     pw = qzk_ld64u(b->p + b->pos);
-                    qzk_lane_symbol<false, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0, LR);
+#if !defined(QZ_SIM) && defined(QZK_PREFETCH)
+                    {
+                        /* experiment (measured on MI355X, no gain: the compiler waits with vmcnt(0) at the loop head, so
+                         * the request is not left in flight - DESIGN.md section 7): every lane also asks for the line three
+                         * ahead of its read position and claims the value two trips later */
+                        const uint32_t ahead = b->pos + 192 < b->end - 8 ? b->pos + 192 : b->end - 8;
+                        const uint32_t pf0 = qz_ld32(b->p + (ahead & ~63u));
+                        asm volatile("" :: "v"(pf2));
+                        pf2 = pf1; pf1 = pf0;
+                    }
+#endif
+                    qzk_lane_symbol<false, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0, LR, DR);
 #ifdef QZK_INF_PROF
                     prof_trips++;
 #endif
@@ -512,13 +541,13 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
             for (int round = 0; round < 8 && S.state == QZK_LS_SYM; round++) {
                 for (int trip = 0; trip < QZK_TOK_ROUND && S.state == QZK_LS_SYM; trip++) {
                     qzk_lrefill(b);
-                    qzk_lane_symbol<true, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0, LR);
+                    qzk_lane_symbol<true, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0, LR, DR);
                 }
                 qzk_tok_round_flush(&O);
             }
         } else if (S.state == QZK_LS_HDR) {
             qzk_lane_header(&S, T, lroot, droot);
-            if (S.state == QZK_LS_SYM) qzk_longtab_load(LR, T, S.lmax);
+            if (S.state == QZK_LS_SYM) qzk_longtab_load(LR, DR, T, S.lmax, S.dmax);
         }
         else if (S.state == QZK_LS_RAW) {
             if (O.count_only) { S.op += S.clen; S.rpos += S.clen; S.clen = 0; }         /* nothing to move */
@@ -576,6 +605,28 @@ QZ_DEV uint32_t qzk_wave_scan_incl(uint32_t v, int lane)
     return v;
 }
 
+/* Phase B reads back bytes its own wave stored a moment ago (a match's source is earlier output).  With the plain
+ * variant the stores are made visible by a workgroup-scope fence (s_waitcnt vmcnt(0): the wave waits for its stores to
+ * reach the L2 at every dependency step); QZK_RES_L2 serves those loads from the L2 instead (non-temporal loads bypass
+ * the CU's vector L1, the only place a stale copy could sit; a wave's requests reach an L2 channel in issue order), so
+ * a wave-local fence is enough and nothing waits. */
+#if defined(QZK_RES_L2) && !defined(QZ_SIM)
+typedef uint64_t qz_u64ntu __attribute__((aligned(1)));
+typedef uint32_t qz_u32ntu __attribute__((aligned(1)));
+typedef uint16_t qz_u16ntu __attribute__((aligned(1)));
+#define QZK_RLD64(p) __builtin_nontemporal_load((const qz_u64ntu *)(p))
+#define QZK_RLD32(p) __builtin_nontemporal_load((const qz_u32ntu *)(p))
+#define QZK_RLD16(p) __builtin_nontemporal_load((const qz_u16ntu *)(p))
+#define QZK_RLD8(p) __builtin_nontemporal_load((const uint8_t *)(p))
+#define QZK_RSYNC() qz_lds_sync()
+#else
+#define QZK_RLD64(p) qzk_ld64u(p)
+#define QZK_RLD32(p) qz_ld32(p)
+#define QZK_RLD16(p) qz_ld16(p)
+#define QZK_RLD8(p) (*(const uint8_t *)(p))
+#define QZK_RSYNC() qz_wave_sync()
+#endif
+
 /* copy one match inside the output: len bytes from d - dist to d (the classic overlapping LZ77 copy) */
 QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
 {
@@ -583,18 +634,18 @@ QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
     if (dist >= 8) {
         if (len >= 8) {
             uint32_t i = 0;
-            for (; i + 8 <= len; i += 8) qzk_st64u(d + i, qzk_ld64u(s + i));
-            if (i < len) qzk_st64u(d + len - 8, qzk_ld64u(s + len - 8));     /* overlapping tail, same bytes again */
+            for (; i + 8 <= len; i += 8) qzk_st64u(d + i, QZK_RLD64(s + i));
+            if (i < len) qzk_st64u(d + len - 8, QZK_RLD64(s + len - 8));     /* overlapping tail, same bytes again */
         } else {
-            if (len & 4) { ((qz_u32u *)d)->v = qz_ld32(s); d += 4; s += 4; }
-            if (len & 2) { ((qz_u16u *)d)->v = (uint16_t)qz_ld16(s); d += 2; s += 2; }
-            if (len & 1) *d = *s;
+            if (len & 4) { ((qz_u32u *)d)->v = QZK_RLD32(s); d += 4; s += 4; }
+            if (len & 2) { ((qz_u16u *)d)->v = (uint16_t)QZK_RLD16(s); d += 2; s += 2; }
+            if (len & 1) *d = QZK_RLD8(s);
         }
         return;
     }
     /* period < 8: build 16 bytes of the periodic pattern in registers, then every 8-byte step is a funnel shift */
     uint64_t P = 0;
-    for (uint32_t i = 0; i < dist; i++) P |= (uint64_t)s[i] << (8 * i);
+    for (uint32_t i = 0; i < dist; i++) P |= (uint64_t)QZK_RLD8(s + i) << (8 * i);
     uint64_t q0 = 0, q1 = 0;
     for (uint32_t t = 0, ph = 0; t < 16; t++) {
         const uint64_t byte = (P >> (8 * ph)) & 0xff;
@@ -641,7 +692,7 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, 6) qzk_lz_resolve_kernel(const uint8_t *comp, 
             if ((uint64_t)obase + ce.seq_count > sg.out_cap) { err = QZK_INF_EOUT; break; }
             const uint8_t *s = comp + sg.in_off + ce.seq_first;
             for (uint32_t i = (uint32_t)lane; i < ce.seq_count; i += 64) o[obase + i] = s[i];
-            qz_wave_sync();
+            QZK_RSYNC();
             obase += ce.seq_count;
             continue;
         }
@@ -671,7 +722,7 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, 6) qzk_lz_resolve_kernel(const uint8_t *comp, 
                 const uint32_t oj = qz_shfl(my_o, j), lj = qz_shfl(my_l0, j);
                 if (k < Lb) o[oj + (k - lj)] = lp[lbase + k];
             }
-            qz_wave_sync();                                             /* matches may read these literals */
+            QZK_RSYNC();                                                /* matches may read these literals */
             const uint32_t src_end = my_m - dist + (mlen < dist ? mlen : dist);
             uint64_t pending = qz_ballot(mlen != 0);
             while (pending) {
@@ -692,12 +743,12 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, 6) qzk_lz_resolve_kernel(const uint8_t *comp, 
                     uint32_t r = (uint32_t)lane % D;
                     const uint8_t *sp = o + ((int64_t)M - (int64_t)D);
                     for (uint32_t i = (uint32_t)lane; i < L; i += 64) {
-                        o[M + i] = sp[r];
+                        o[M + i] = QZK_RLD8(sp + r);
                         r += stp; if (r >= D) r -= D;
                     }
                 }
                 pending &= ~qz_ballot(ready);
-                qz_wave_sync();
+                QZK_RSYNC();
             }
             obase += Tb; lbase += Lb;
         }
