@@ -280,11 +280,24 @@ extern "C" void qzd_host_free_pinned(void *p) { if (p) hipHostFree(p); }
 
 static uint32_t slot_stride_for(uint32_t chunk_sz) { return (chunk_sz / 8u * 9u + 1024u + 15u) & ~15u; }
 
-/* the device pool's batch scratch (called with the pool's lock held) and this context's per-call arrays */
+/* K2 inside the K1 waves (the default) or as a launch of its own (QATZIP_AMD_FUSE=0, round 1's pipeline, kept for
+ * comparison): decides the launch shape AND the layout of the device pool's scratch, so it is fixed per process */
+static bool k1_fused(void)
+{
+    static const bool fuse = !(getenv("QATZIP_AMD_FUSE") && getenv("QATZIP_AMD_FUSE")[0] == '0');
+    return fuse;
+}
+
+/* the device pool's scratch (called with the pool's lock held) and this context's per-call arrays.
+ *   fused:    symbols per WAVE (a wave codes the chunk it parsed before it pulls the next: 3 bytes per input byte for the
+ *             4096 resident waves, whatever the call's size), slots and meta per chunk of the CALL, one set;
+ *   separate: symbols, slots and meta per chunk of a BATCH, double-buffered (K2 of batch b beside K1 of batch b+1). */
 static int ensure_scratch(qzd_ctx *c, qzd_k1pool *pool, uint32_t chunk_sz, uint32_t nchunks)
 {
-    uint32_t batch = nchunks < c->batch_chunks ? nchunks : c->batch_chunks;
-    size_t sym = (size_t)batch * chunk_sz + 256, slot = (size_t)batch * slot_stride_for(chunk_sz);
+    const bool fuse = k1_fused();
+    uint32_t batch = fuse ? nchunks : (nchunks < c->batch_chunks ? nchunks : c->batch_chunks);
+    const uint32_t waves = ((c->k1_wgs + QZK_K1_WAVES - 1) / QZK_K1_WAVES) * QZK_K1_WAVES;
+    size_t sym = (size_t)(fuse ? waves : batch) * chunk_sz + 256, slot = (size_t)batch * slot_stride_for(chunk_sz);
     if (sym > pool->sym_cap || slot > pool->slot_cap || batch > pool->meta_cap) {
         hipDeviceSynchronize();
         sym = std::max(sym, pool->sym_cap); slot = std::max(slot, pool->slot_cap); batch = std::max(batch, pool->meta_cap);
@@ -293,7 +306,7 @@ static int ensure_scratch(qzd_ctx *c, qzd_k1pool *pool, uint32_t chunk_sz, uint3
             hipFree(pool->sym_lc[i]); hipFree(pool->sym_dist[i]); hipFree(pool->slots[i]); hipFree(pool->meta[i]);
             pool->sym_lc[i] = NULL; pool->sym_dist[i] = NULL; pool->slots[i] = NULL; pool->meta[i] = NULL;
         }
-        for (int i = 0; i < QZD_NBUF; i++) {
+        for (int i = 0; i < (fuse ? 1 : QZD_NBUF); i++) {
             HIPCHK(c, hipMalloc(&pool->sym_lc[i], sym));
             HIPCHK(c, hipMalloc(&pool->sym_dist[i], sym * 2));
             HIPCHK(c, hipMalloc(&pool->slots[i], slot));
@@ -452,7 +465,12 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
     }
     const uint32_t stride = slot_stride_for(chunk_sz);
     c->last_nchunks = nchunks;
-    const uint32_t BATCH = c->batch_chunks;
+    /* input already in HBM and K2 inside K1: the whole call is ONE launch - every launch ends with a tail (the waves
+     * finish their last chunks, ~8 ms each, at different times; on the bench data ~3 ms of a 12288-chunk launch) and there
+     * is nothing left to overlap it with.  Input still on the host: batches, so that the copy of the next one runs beside
+     * the kernels of this one. */
+    const bool fuse = k1_fused();
+    const uint32_t BATCH = fuse && !h_src ? std::max<uint32_t>(nchunks, 1u) : c->batch_chunks;
     c->k1ev_n = 0;
     c->nbatches = (nchunks + BATCH - 1) / BATCH;
 
@@ -499,23 +517,28 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         HIPCHK(c, hipMemsetAsync(c->k1_counter + s, 0, 4, st));
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][0], st));
         if (k < QZD_K1EV) HIPCHK(c, hipEventRecord(c->k1ev[k][0], st));
+        /* K2 rides in the K1 waves (qzk_lz77_pull_kernel): symbols per wave, slots / meta by the chunk's number in the call */
+        uint8_t *const slots_b = fuse ? pool->slots[0] + (size_t)b * stride : pool->slots[s];
+        qzk_lzmeta *const meta_b = fuse ? pool->meta[0] + b : pool->meta[s];
+        const int sb = fuse ? 0 : s;
         hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64 * wpw), 0, st, d_src + boff, blen, chunk_sz, bn,
-                           pool->sym_lc[s], pool->sym_dist[s], pool->meta[s], pool->tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
-                           pool->epoch);
+                           pool->sym_lc[sb], pool->sym_dist[sb], meta_b, pool->tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
+                           pool->epoch, fuse ? slots_b : (uint8_t *)NULL, stride, final_chunk, c->d_len + b);
         pool->epoch += bn;
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][1], st));
-        hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HW), 0, st, d_src + boff, blen, chunk_sz, bn,
-                           pool->sym_lc[s], pool->sym_dist[s], pool->meta[s], pool->slots[s], stride, final_chunk,
-                           c->d_len + b, cdesc ? cdesc + b : NULL);
+        if (!fuse)
+            hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HW), 0, st, d_src + boff, blen, chunk_sz, bn,
+                               pool->sym_lc[s], pool->sym_dist[s], pool->meta[s], pool->slots[s], stride, final_chunk,
+                               c->d_len + b, cdesc ? cdesc + b : NULL);
         hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn, c->d_crc + b,
                            cdesc ? cdesc + b : NULL);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][2], st));
         /* the running total serialises scan/gather of consecutive batches across the two streams */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->done[so], 0));
         hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);
-        hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, pool->slots[s], stride, c->d_len + b,
+        hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, slots_b, stride, c->d_len + b,
                            c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][3], st));
         HIPCHK(c, hipEventRecord(c->done[s], st));

@@ -32,20 +32,26 @@
 
 typedef struct { uint32_t tab[4][256]; uint32_t ktab[4][256]; uint32_t x2n[32]; uint32_t red[16]; } qzk_crc_lds;
 
+/* One wave's K2 state, 8.1 KiB: small enough that the sixteen waves of a K1 workgroup can each run K2 on the chunk they
+ * just parsed, in the LDS their parse no longer needs (qzk_lz77_pull_kernel below).  Arrays whose lifetimes do not
+ * overlap share storage: a tree's codes replace its frequencies (build_tree has copied them to nfreq[] by then), the
+ * dynamic header is assembled where the heap stood. */
 typedef struct {
-    /* frequencies (u32 for LDS atomics) */
-    uint32_t fl[288], fd[32], fbl[20];
-    /* tree-build scratch (lane 0) */
-    uint32_t heap[QZK_HEAP + 3];       /* freq<<15 | depth<<10 | node */
-    uint16_t order[QZK_HEAP + 3];
+    /* frequencies (u32 for LDS atomics) -> code tables: code | len<<16 */
+    union { uint32_t fl[288]; uint32_t code_l[288]; };
+    union { uint32_t fd[32]; uint32_t code_d[32]; };
+    union { uint32_t fbl[20]; uint32_t code_bl[20]; };
+    union {
+        struct {                            /* tree-build scratch (lane 0) */
+            uint32_t heap[QZK_HEAP + 3];    /* freq<<15 | depth<<10 | node */
+            uint16_t order[QZK_HEAP + 3];
+        };
+        struct { uint32_t hdr[320]; uint32_t hbits; };      /* dynamic header bits */
+    };
     uint16_t dad[QZK_HEAP + 3];
     uint16_t nfreq[QZK_HEAP + 3];
     uint8_t len_l[QZK_HEAP + 3], len_d[64], len_bl[40];
     uint16_t bl_count[16];
-    /* code tables: code | len<<16 */
-    uint32_t code_l[288], code_d[32], code_bl[20];
-    /* dynamic header bits */
-    uint32_t hdr[320]; uint32_t hbits;
     /* decisions */
     uint32_t btype, max_l, max_d;
     /* output staging */
@@ -434,27 +440,34 @@ QZ_DEV uint32_t qzk_block_crc32(qzk_crc_lds *S, const uint8_t *src, uint32_t n)
 
 /* ------------------------------------------------------------------ the kernel */
 #define QZK_HW 64                  /* threads per workgroup of K2: one wave per chunk, no workgroup barriers */
-QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
-                          const uint8_t *sym_lc, const uint16_t *sym_dist, const qzk_lzmeta *meta,
-                          uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk /* index or ~0u */,
-                          uint32_t *out_len, const uint32_t *cdesc)
+
+/* symbols written to HBM by the SAME wave a moment ago (K1 and K2 fused): read them at the L2 (no copy of these lines
+ * can be in this CU's L1 - they were never read before in this launch - but the load then does not depend on that) */
+template <bool L2> QZ_DEV uint32_t qzk_sym_ld8(const uint8_t *p)
 {
-    QZ_LDS qzk_huff_lds S;
-    const int lane = qz_lane();
-    const uint32_t chunk = blockIdx.x;
-    if (chunk >= nchunks) return;
-    const uint64_t coff = (uint64_t)chunk * chunk_sz;
-    const uint8_t *in = src + coff;
-    const uint8_t *lcs = sym_lc + coff;
-    const uint16_t *dists = sym_dist + coff;
-    const qzk_lzmeta *mt = meta + chunk;
+#ifndef QZ_SIM
+    if (L2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    return *p;
+}
+template <bool L2> QZ_DEV uint32_t qzk_sym_ld16(const uint16_t *p)
+{
+#ifndef QZ_SIM
+    if (L2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    return *p;
+}
+
+/* K2 for one chunk by one wave: `in` = the chunk's input, lcs/dists/mt = what K1 left for it, `out` = the chunk's slot */
+template <bool L2>
+QZ_DEV void qzk_huff_chunk(qzk_huff_lds *Sp, const int lane, const uint8_t *in, const uint8_t *lcs, const uint16_t *dists,
+                           const qzk_lzmeta *mt, uint8_t *out, const bool is_final, uint32_t *out_len)
+{
+    qzk_huff_lds &S = *Sp;
     const uint32_t n = mt->n, nsym = mt->nsym, nfull = mt->nfull, cs = mt->can_store;
-    const bool is_final = cdesc ? (cdesc[chunk] & QZK_CDESC_FINAL) != 0 : chunk == final_chunk;
-    (void)src_len;
 
     qzk_bitout bo;
-    bo.out = slots + (uint64_t)chunk * slot_stride; bo.nbytes = 0; bo.cbits = 0; bo.carry = 0;
-
+    bo.out = out; bo.nbytes = 0; bo.cbits = 0; bo.carry = 0;
     /* blocks 0..nfull-1 are full; block nfull is the remainder (possibly empty) */
     const uint32_t nblocks = nfull + ((is_final || nsym > nfull * QZK_LITBUF) ? 1 : 0);
     for (uint32_t b = 0; b < nblocks; b++) {
@@ -468,7 +481,7 @@ QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t
         if (lane < 32) S.fd[lane] = 0;
         qz_lds_sync();
         for (uint32_t i = s0 + (uint32_t)lane; i < s1; i += QZK_HW) {
-            uint32_t lc = lcs[i], dist = dists[i];
+            uint32_t lc = qzk_sym_ld8<L2>(lcs + i), dist = qzk_sym_ld16<L2>(dists + i);
             if (dist == 0) atomicAdd(&S.fl[lc], 1u);
             else {
                 uint32_t lcode, D = dist - 1, dcode;
@@ -510,7 +523,7 @@ QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t
             }
             for (uint32_t i0 = s0; i0 < s1; i0 += QZK_HW) {
                 uint32_t i = i0 + (uint32_t)lane, nb = 0; uint64_t v = 0;
-                if (i < s1) qzk_sym_bits(&S, lcs[i], dists[i], &v, &nb);
+                if (i < s1) qzk_sym_bits(&S, qzk_sym_ld8<L2>(lcs + i), qzk_sym_ld16<L2>(dists + i), &v, &nb);
                 qzk_emit_wave(&S, &bo, v, nb, lane);
             }
             {   /* END_BLOCK */
@@ -528,7 +541,69 @@ QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t
         if (lane < 4) bo.out[bo.nbytes + (uint32_t)lane] = lane < 2 ? 0x00 : 0xff;
         bo.nbytes += 4;
     }
-    if (lane == 0) out_len[chunk] = bo.nbytes;
+    *out_len = bo.nbytes;          /* wave-uniform: every lane stores the same word (no lane-0-only block at the end of a
+                                    * pull-loop iteration, see qzk_lz77_pull_kernel) */
+}
+
+QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
+                          const uint8_t *sym_lc, const uint16_t *sym_dist, const qzk_lzmeta *meta,
+                          uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk /* index or ~0u */,
+                          uint32_t *out_len, const uint32_t *cdesc)
+{
+    QZ_LDS qzk_huff_lds S;
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= nchunks) return;
+    const uint64_t coff = (uint64_t)chunk * chunk_sz;
+    const bool is_final = cdesc ? (cdesc[chunk] & QZK_CDESC_FINAL) != 0 : chunk == final_chunk;
+    (void)src_len;
+    qzk_huff_chunk<false>(&S, qz_lane(), src + coff, sym_lc + coff, sym_dist + coff, meta + chunk,
+                          slots + (uint64_t)chunk * slot_stride, is_final, out_len + chunk);
+}
+
+/* ------------------------------------------------------------------ K1 (+ K2) launch shape
+ * Persistent workgroups of QZK_K1_WAVES waves, one per CU; every WAVE pulls chunk numbers from a counter (uneven chunks
+ * balance themselves) and owns one column of its workgroup's table: entry h of wave w at
+ * tables[(blockIdx.x * 65536 + h) * QZK_K1_WAVES + w].  The waves never talk to each other - what they share is cache
+ * lines.  epoch_base + chunk number = the chunk's epoch (host: unique per chunk across launches, never 0).
+ *
+ * With `slots` the wave that parsed a chunk also codes it (K2, qzk_huff_chunk) before it pulls the next one, in the LDS
+ * its parse no longer needs.  K2's serial tree build is one lane following a chain of LDS round trips, the parse a wave
+ * following a chain of HBM round trips: as a separate launch beside the next batch's K1, K2 (two waves per CU in the LDS
+ * K1 leaves) stretched that K1 launch by 7 of its 23 ms; inside the K1 waves it fills issue slots the parse leaves
+ * empty, and a chunk's symbols are read back while they are still on their way through the L2. */
+#define QZK_K1_LDSW (QZK_K1_PARSEW > (sizeof(qzk_huff_lds) + 3) / 4 ? QZK_K1_PARSEW : (sizeof(qzk_huff_lds) + 3) / 4)
+QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
+                                                     uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tables,
+                                                     uint32_t *counter, const uint32_t *cdesc, uint32_t epoch_base,
+                                                     uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk, uint32_t *out_len)
+{
+    QZ_LDS uint32_t lds_all[QZK_K1_WAVES][QZK_K1_LDSW];
+    const int wv = (int)(threadIdx.x >> 6);
+    uint32_t *const lds = lds_all[wv];
+    qzk_bkt *tab = tables + (size_t)blockIdx.x * QZK_HSIZE * QZK_K1_WAVES + wv;
+    for (;;) {
+        /* no `if (lane == 0)` block at the start or the end of this loop's body: the compiler threads lane-0-only blocks
+         * of consecutive iterations together, after which the other 63 lanes would run readfirstlane without lane 0 (seen
+         * on gfx950: the wave re-parses chunk 0 forever).  Every lane takes part; only lane 0 adds. */
+        uint32_t chunk = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);
+        chunk = qz_readfirstlane(chunk);
+        if (chunk >= nchunks) break;
+        /* symbols: with K2 in the wave they only live until the wave has coded them - one chunk's worth per WAVE (read
+         * back at the L2: the same addresses carried the previous chunk's symbols); without, one per chunk of the launch */
+        const uint64_t soff = slots ? (uint64_t)(blockIdx.x * QZK_K1_WAVES + (uint32_t)wv) * chunk_sz : (uint64_t)chunk * chunk_sz;
+        uint8_t *const wlc = sym_lc + soff;
+        uint16_t *const wdist = sym_dist + soff;
+        qzk_lz77_chunk(src, src_len, chunk_sz, chunk, wlc, wdist, meta, tab, epoch_base + chunk, cdesc, lds);
+        if (slots) {
+            /* every lane stored the chunk's meta words itself; the symbols were stored by other lanes of this wave:
+             * memory operations of one wave reach the L2 in issue order */
+            qz_lds_sync();
+            const bool is_final = cdesc ? (cdesc[chunk] & QZK_CDESC_FINAL) != 0 : chunk == final_chunk;
+            qzk_huff_chunk<true>((qzk_huff_lds *)lds, qz_lane(), src + (uint64_t)chunk * chunk_sz, wlc, wdist, meta + chunk,
+                                 slots + (uint64_t)chunk * slot_stride, is_final, out_len + chunk);
+            qz_lds_sync();
+        }
+    }
 }
 
 #endif

@@ -54,6 +54,7 @@
 #define QZK_K1_OCC 1               /* workgroups per CU the register budget is cut for */
 #endif
 #define QZK_RINGW (QZK_RING / 4)
+#define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW)   /* words of LDS one wave's parse needs */
 #ifndef QZK_K1_WAVES
 #define QZK_K1_WAVES 16            /* waves per K1 workgroup, one chunk each; they share the lines of the candidate table */
 #endif
@@ -156,15 +157,15 @@ QZ_DEV int qzk_wave_matchlen(const uint8_t *src, uint64_t src_len, uint64_t a, u
  * h at tab[h * QZK_K1_WAVES]); LDS holds, per wave, a ring of the most recent input and the per-window slot tables. */
 QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t chunk,
                            uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tab, uint32_t epoch,
-                           const uint32_t *cdesc, int wv)
+                           const uint32_t *cdesc, uint32_t *lds)
 {
-    QZ_LDS uint32_t slot_all[QZK_K1_WAVES][QZK_NSLOT];    /* per-window: min(lane<<16 | hash) over the lanes on a hash key */
-    QZ_LDS uint32_t scnt_all[QZK_K1_WAVES][QZK_NSLOT];    /* per-window: number of lanes on the key */
-    /* the last QZK_RING bytes of input (and ~100 ahead of the parse point) sit in LDS.  Every candidate compare
-     * drags a 128-byte line through L2 for 16 bytes, three quarters of them less than 4 KiB back; with a dozen
-     * waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
-    QZ_LDS uint32_t ring_all[QZK_K1_WAVES][QZK_RINGW];
-    uint32_t *const slot = slot_all[wv], *const scnt = scnt_all[wv], *const ring = ring_all[wv];
+    /* this wave's QZK_K1_LDSW words of LDS:
+     *   slot[QZK_NSLOT]  per-window: min(lane<<16 | hash) over the lanes on a hash key
+     *   scnt[QZK_NSLOT]  per-window: number of lanes on the key
+     *   ring[QZK_RINGW]  the last QZK_RING bytes of input (and ~100 ahead of the parse point).  Every candidate compare
+     *     drags a 128-byte line through L2 for 16 bytes, three quarters of them less than 4 KiB back; with a dozen
+     *     waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
+    uint32_t *const slot = lds, *const scnt = lds + QZK_NSLOT, *const ring = lds + 2 * QZK_NSLOT;
     uint32_t rhi = 0;                      /* chunk offset the ring is filled up to (multiple of 256) */
 #define QZK_RING16(dst, ca) do { const uint32_t r_ = (ca) & (QZK_RING - 1), i_ = r_ >> 2, s_ = r_ & 3; \
         const uint32_t d0_ = ring[i_ & (QZK_RINGW - 1)], d1_ = ring[(i_ + 1) & (QZK_RINGW - 1)], d2_ = ring[(i_ + 2) & (QZK_RINGW - 1)], \
@@ -175,8 +176,8 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     const int lane = qz_lane();
     const uint64_t coff = (uint64_t)chunk * chunk_sz;
     const uint32_t n = qzk_chunk_len(cdesc, chunk, src_len, chunk_sz);
-    uint8_t *olc = sym_lc + coff;
-    uint16_t *odist = sym_dist + coff;
+    uint8_t *olc = sym_lc;                          /* this chunk's symbol arrays (the caller placed them) */
+    uint16_t *odist = sym_dist;
     qzk_lzmeta *mt = meta + chunk;
 
     /* nothing to clear: the entries of earlier chunks carry other epochs.  (All cross-lane ordering in here is
@@ -520,27 +521,6 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     for (int k = 0; k < 16; k++) mt->prof[k] = prof[k];
 #endif
 #undef QZK_RING16
-}
-
-/* K1 launch shape: persistent workgroups of QZK_K1_WAVES waves, one per CU; every WAVE pulls chunk numbers from a
- * counter (uneven chunks balance themselves) and owns one column of its workgroup's table: entry h of wave w at
- * tables[(blockIdx.x * 65536 + h) * QZK_K1_WAVES + w].  The waves never talk to each other - what they share is cache
- * lines.  epoch_base + chunk number = the chunk's epoch (host: unique per chunk across launches, never 0). */
-QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
-                                                     uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tables,
-                                                     uint32_t *counter, const uint32_t *cdesc, uint32_t epoch_base)
-{
-    const int wv = (int)(threadIdx.x >> 6);
-    qzk_bkt *tab = tables + (size_t)blockIdx.x * QZK_HSIZE * QZK_K1_WAVES + wv;
-    for (;;) {
-        /* no `if (lane == 0)` anywhere on this loop's path: the compiler threads lane-0-only blocks of consecutive
-         * iterations together, after which the other 63 lanes would run readfirstlane without lane 0 (seen on
-         * gfx950: the wave re-parses chunk 0 forever).  Every lane takes part; only lane 0 adds. */
-        uint32_t chunk = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);
-        chunk = qz_readfirstlane(chunk);
-        if (chunk >= nchunks) break;
-        qzk_lz77_chunk(src, src_len, chunk_sz, chunk, sym_lc, sym_dist, meta, tab, epoch_base + chunk, cdesc, wv);
-    }
 }
 
 #endif

@@ -25,7 +25,8 @@ extern "C" {
  * interesting case.  The table starts out as garbage with a foreign epoch, and the epochs continue from run to run. */
 static uint32_t g_k1_epoch = 1;
 static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint32_t nchunks,
-                   uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta, const uint32_t *cdesc = nullptr, uint32_t waves = 3)
+                   uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta, const uint32_t *cdesc = nullptr, uint32_t waves = 3,
+                   uint8_t *slots = nullptr, uint32_t stride = 0, uint32_t final_chunk = ~0u, uint32_t *olen = nullptr)
 {
     static std::vector<qzk_bkt> tables;
     const size_t need = (size_t)wgs * QZK_HSIZE * QZK_K1_WAVES;
@@ -34,7 +35,8 @@ static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_
         tables.assign(need, junk);
     }
     uint32_t counter = 0;
-    sim::launch(wgs, 64 * waves, 0, [&] { qzk_lz77_pull_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, tables.data(), &counter, cdesc, g_k1_epoch); });
+    sim::launch(wgs, 64 * waves, 0, [&] { qzk_lz77_pull_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, tables.data(), &counter, cdesc, g_k1_epoch,
+                                                                slots, stride, final_chunk, olen); });
     g_k1_epoch += nchunks;
 }
 
@@ -51,17 +53,24 @@ static int deflate_variant(int variant, const uint8_t *src, uint64_t n, uint32_t
                            uint64_t *out_len, uint32_t *crcs)
 {
     uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
-    std::vector<uint8_t> lc(n + 64);
-    std::vector<uint16_t> dist(n + 64);
+    /* fused: one chunk's worth of symbols per wave of the two workgroups, whatever the number of chunks */
+    const size_t symn = variant == 1 ? (size_t)2 * QZK_K1_WAVES * chunk_sz + 64 : n + 64;
+    std::vector<uint8_t> lc(symn);
+    std::vector<uint16_t> dist(symn);
     std::vector<qzk_lzmeta> meta(nchunks);
     uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
     std::vector<uint8_t> slots((size_t)nchunks * stride);
     std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
-    (void)variant; run_k1(2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data());
-    sim::launch(nchunks, QZK_HW, 0, [&] {
-        qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
-                        last ? nchunks - 1 : ~0u, olen.data(), nullptr);
-    });
+    if (variant == 1)           /* the product's shape: the wave that parsed a chunk codes it too, in the same LDS */
+        run_k1(2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), nullptr, 3, slots.data(), stride,
+               last ? nchunks - 1 : ~0u, olen.data());
+    else {
+        run_k1(2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data());
+        sim::launch(nchunks, QZK_HW, 0, [&] {
+            qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
+                            last ? nchunks - 1 : ~0u, olen.data(), nullptr);
+        });
+    }
     sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data(), nullptr); });
     uint64_t pos = 0;
     for (uint32_t c = 0; c < nchunks; c++) {
@@ -78,7 +87,7 @@ int sim_deflate(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uin
     return deflate_variant(0, src, n, chunk_sz, last, out, out_len, crcs);
 }
 
-int sim_deflate_hbm(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len, uint32_t *crcs)
+int sim_deflate_fused(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len, uint32_t *crcs)
 {
     return deflate_variant(1, src, n, chunk_sz, last, out, out_len, crcs);
 }

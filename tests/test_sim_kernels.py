@@ -30,17 +30,17 @@ def sim():
     S.sim_lz77.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     S.sim_deflate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint64),
                               C.c_void_p]
-    S.sim_deflate_hbm.argtypes = S.sim_deflate.argtypes
+    S.sim_deflate_fused.argtypes = S.sim_deflate.argtypes
     return S
 
 
-def _sim_deflate(S, src, chunk, last=1, hbm=False):
+def _sim_deflate(S, src, chunk, last=1, fused=False):
     n = len(src)
     nch = max(1, (n + chunk - 1) // chunk)
     cap = n * 9 // 8 + 4096 * (nch + 1)
     out = C.create_string_buffer(cap); ol = C.c_uint64(0)
     crcs = np.zeros(nch, np.uint32)
-    (S.sim_deflate_hbm if hbm else S.sim_deflate)(src, n, chunk, last, out, C.byref(ol), crcs.ctypes.data)
+    (S.sim_deflate_fused if fused else S.sim_deflate)(src, n, chunk, last, out, C.byref(ol), crcs.ctypes.data)
     return out.raw[:ol.value], crcs
 
 
@@ -70,14 +70,16 @@ def test_deflate_stream_matches_oracle(sim, kind):
             assert crcs[i] == (zlib.crc32(src[i * chunk:(i + 1) * chunk]) & 0xffffffff)
 
 
-def test_deflate_prev_in_hbm_variant(sim):
-    """K1's second residency variant (prev[] in a global slice instead of LDS) parses identically; the persistent
-    workgroup reuses its table slices across chunks without clearing prev[]."""
+def test_deflate_fused_k1_k2(sim):
+    """The product's launch shape: the wave that parsed a chunk also codes it (K2 inside K1's pull loop, in the LDS the
+    parse no longer needs), chunk after chunk on the same wave."""
     for kind, n, chunk in (("silesia", 200000, 65536), ("lzmix", 66000, 16384), ("runs", 140000, 131072),
-                           ("text", 9000, 1024), ("allA", 70000, 65536), ("rand", 0, 65536)):
+                           ("text", 9000, 1024), ("allA", 70000, 65536), ("rand", 0, 65536), ("rand", 70000, 16384),
+                           ("mod200", 300000, 65536), ("text", 100000, 4096)):
         src = datagen.gen_bytes(kind, n, 77)
-        out, _ = _sim_deflate(sim, src, chunk, hbm=True)
-        assert out == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 8192)[2], (kind, n, chunk)
+        for last in (1, 0):
+            out, _ = _sim_deflate(sim, src, chunk, last=last, fused=True)
+            assert out == O.sw_compress("RAW", src, chunk, 1, last=last, cap=n * 9 // 8 + 8192)[2], (kind, n, chunk, last)
 
 
 def test_deflate_not_last(sim):
