@@ -523,7 +523,8 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         const int sb = fuse ? 0 : s;
         hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64 * wpw), 0, st, d_src + boff, blen, chunk_sz, bn,
                            pool->sym_lc[sb], pool->sym_dist[sb], meta_b, pool->tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
-                           pool->epoch, fuse ? slots_b : (uint8_t *)NULL, stride, final_chunk, c->d_len + b);
+                           pool->epoch, fuse ? slots_b : (uint8_t *)NULL, stride, final_chunk, c->d_len + b,
+                           fuse ? c->d_crc + b : (uint32_t *)NULL);
         pool->epoch += bn;
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
@@ -532,8 +533,9 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
             hipLaunchKernelGGL(qzk_huff_kernel, dim3(bn), dim3(QZK_HW), 0, st, d_src + boff, blen, chunk_sz, bn,
                                pool->sym_lc[s], pool->sym_dist[s], pool->meta[s], pool->slots[s], stride, final_chunk,
                                c->d_len + b, cdesc ? cdesc + b : NULL);
-        hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn, c->d_crc + b,
-                           cdesc ? cdesc + b : NULL);
+        if (!fuse)          /* fused: the chunk CRCs ride along K1's input reads */
+            hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(bn), dim3(QZK_HT), 0, st, d_src + boff, blen, chunk_sz, bn, c->d_crc + b,
+                               cdesc ? cdesc + b : NULL);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][2], st));
         /* the running total serialises scan/gather of consecutive batches across the two streams */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->done[so], 0));

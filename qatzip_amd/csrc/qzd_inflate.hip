@@ -358,8 +358,21 @@ static int find_markers(qzd_ctx *c, const uint8_t *d_src, uint64_t n, std::vecto
     if (cnt > cap - 8) return 1;       /* too many candidates: caller falls back to the serial walk */
     if (cnt) {
         HIPCHK(c, hipMemcpy(c->h_aux, d_list, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-        pos.assign((uint32_t *)c->h_aux, (uint32_t *)c->h_aux + cnt);
-        std::sort(pos.begin(), pos.end());
+        /* the kernel's atomics hand the positions out in no order: three 11-bit counting passes (a 2 GiB call has 32768
+         * of them; std::sort took over a millisecond between two kernels) */
+        const uint32_t *in = (const uint32_t *)c->h_aux;
+        std::vector<uint32_t> tmp(cnt);
+        pos.resize(cnt);
+        for (int pass = 0; pass < 3; pass++) {
+            const int sh = 11 * pass;
+            uint32_t hist[2049] = {0};
+            const uint32_t *src = pass == 0 ? in : pass == 1 ? tmp.data() : pos.data();
+            uint32_t *dst = pass == 1 ? pos.data() : tmp.data();
+            for (uint32_t i = 0; i < cnt; i++) hist[((src[i] >> sh) & 2047u) + 1]++;
+            for (int k = 0; k < 2048; k++) hist[k + 1] += hist[k];
+            for (uint32_t i = 0; i < cnt; i++) dst[hist[(src[i] >> sh) & 2047u]++] = src[i];
+        }
+        pos.swap(tmp);              /* pass 0: in -> tmp, 1: tmp -> pos, 2: pos -> tmp */
     }
     return QZD_OK;
 }

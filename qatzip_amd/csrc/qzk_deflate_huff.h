@@ -23,6 +23,7 @@
 #define QZK_DEFLATE_HUFF_H
 #include "qzk_common.h"
 #include "qzk_deflate_lz77.h"
+#include "qzk_crcmath.h"
 
 #define QZK_HT 256                 /* threads per workgroup */
 #define QZK_LCODES 286
@@ -346,25 +347,6 @@ QZ_DEV void qzk_align(qzk_bitout *bo, int lane)
 }
 
 /* ------------------------------------------------------------------ CRC32 (K6) */
-#define QZK_POLY 0xEDB88320u
-QZ_DEV uint32_t qzk_multmodp(uint32_t a, uint32_t b)
-{
-    uint32_t m = 1u << 31, p = 0;
-    for (;;) {
-        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
-        m >>= 1;
-        b = (b & 1) ? (b >> 1) ^ QZK_POLY : b >> 1;
-    }
-    return p;
-}
-/* x^(n * 2^k) mod P, using S->x2n[i] = x^(2^i) */
-QZ_DEV uint32_t qzk_x2nmodp(const uint32_t *x2n, uint64_t n, unsigned k)
-{
-    uint32_t p = 1u << 31;
-    while (n) { if (n & 1) p = qzk_multmodp(x2n[k & 31], p); n >>= 1; k++; }
-    return p;
-}
-
 /* crc32 of src[0..n) by the whole workgroup (finalised, zlib convention).
  * Layout: the 256 threads sweep the data in rows of 4 KiB, thread t owning the 16 bytes at row*4096 + 16*t, so
  * every wave load is one coalesced 1 KiB request.  A thread folds its pieces Horner-style:
@@ -575,9 +557,12 @@ QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t
 QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                                                      uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tables,
                                                      uint32_t *counter, const uint32_t *cdesc, uint32_t epoch_base,
-                                                     uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk, uint32_t *out_len)
+                                                     uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk, uint32_t *out_len,
+                                                     uint32_t *crc_out /* per chunk, or NULL */)
 {
     QZ_LDS uint32_t lds_all[QZK_K1_WAVES][QZK_K1_LDSW];
+    QZ_LDS qzk_k1crc_lds crcT;
+    if (crc_out) qzk_k1crc_init(&crcT);             /* kernel argument: the whole workgroup takes the same way */
     const int wv = (int)(threadIdx.x >> 6);
     uint32_t *const lds = lds_all[wv];
     qzk_bkt *tab = tables + (size_t)blockIdx.x * QZK_HSIZE * QZK_K1_WAVES + wv;
@@ -593,7 +578,8 @@ QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_p
         const uint64_t soff = slots ? (uint64_t)(blockIdx.x * QZK_K1_WAVES + (uint32_t)wv) * chunk_sz : (uint64_t)chunk * chunk_sz;
         uint8_t *const wlc = sym_lc + soff;
         uint16_t *const wdist = sym_dist + soff;
-        qzk_lz77_chunk(src, src_len, chunk_sz, chunk, wlc, wdist, meta, tab, epoch_base + chunk, cdesc, lds);
+        qzk_lz77_chunk(src, src_len, chunk_sz, chunk, wlc, wdist, meta, tab, epoch_base + chunk, cdesc, lds,
+                       crc_out ? &crcT : (const qzk_k1crc_lds *)0, crc_out ? crc_out + chunk : (uint32_t *)0);
         if (slots) {
             /* every lane stored the chunk's meta words itself; the symbols were stored by other lanes of this wave:
              * memory operations of one wave reach the L2 in issue order */

@@ -33,6 +33,7 @@
 #ifndef QZK_DEFLATE_LZ77_H
 #define QZK_DEFLATE_LZ77_H
 #include "qzk_common.h"
+#include "qzk_crcmath.h"
 
 #define QZK_WSIZE 32768
 #define QZK_MAXDIST 32506          /* w_size - MIN_LOOKAHEAD */
@@ -157,7 +158,7 @@ QZ_DEV int qzk_wave_matchlen(const uint8_t *src, uint64_t src_len, uint64_t a, u
  * h at tab[h * QZK_K1_WAVES]); LDS holds, per wave, a ring of the most recent input and the per-window slot tables. */
 QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t chunk,
                            uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tab, uint32_t epoch,
-                           const uint32_t *cdesc, uint32_t *lds)
+                           const uint32_t *cdesc, uint32_t *lds, const qzk_k1crc_lds *crcT, uint32_t *crc_slot)
 {
     /* this wave's QZK_K1_LDSW words of LDS:
      *   slot[QZK_NSLOT]  per-window: min(lane<<16 | hash) over the lanes on a hash key
@@ -167,6 +168,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
      *     waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
     uint32_t *const slot = lds, *const scnt = lds + QZK_NSLOT, *const ring = lds + 2 * QZK_NSLOT;
     uint32_t rhi = 0;                      /* chunk offset the ring is filled up to (multiple of 256) */
+    uint32_t crc_acc = 0;                  /* this lane's share of the chunk's CRC-32 (crcT != NULL) */
 #define QZK_RING16(dst, ca) do { const uint32_t r_ = (ca) & (QZK_RING - 1), i_ = r_ >> 2, s_ = r_ & 3; \
         const uint32_t d0_ = ring[i_ & (QZK_RINGW - 1)], d1_ = ring[(i_ + 1) & (QZK_RINGW - 1)], d2_ = ring[(i_ + 2) & (QZK_RINGW - 1)], \
                        d3_ = ring[(i_ + 3) & (QZK_RINGW - 1)], d4_ = ring[(i_ + 4) & (QZK_RINGW - 1)]; \
@@ -228,10 +230,14 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 do {
                     const uint32_t a = rhi + 4 * (uint32_t)lane;
                     const uint64_t g = coff + a;
-#if defined(QZK_NT) && !defined(QZ_SIM)      /* streamed once: keep it from displacing table lines in L2 */
+#if defined(QZK_NT) && !defined(QZ_SIM)      /* experiment: streamed once, keep it from displacing table lines in L2 (no CRC) */
                     ring[(a >> 2) & (QZK_RINGW - 1)] = g + 4 <= src_len ? __builtin_nontemporal_load((const qz_u32nt *)(src + g)) : qzk_ld32g(src, g, src_len);
 #else
-                    ring[(a >> 2) & (QZK_RINGW - 1)] = g + 4 <= src_len ? qz_ld32(src + g) : qzk_ld32g(src, g, src_len);
+                    const uint32_t wd = g + 4 <= src_len ? qz_ld32(src + g) : qzk_ld32g(src, g, src_len);
+                    ring[(a >> 2) & (QZK_RINGW - 1)] = wd;
+                    /* the chunk's CRC-32 rides along: every byte of the chunk passes here exactly once, lane l seeing the
+                     * dwords at 256 r + 4 l; it folds them Horner-style (crc32_combine algebra, 8 LDS lookups a step) */
+                    if (crcT && a + 4 <= n) crc_acc = qzk_k1crc_step(crcT, crc_acc, wd);
 #endif
                     rhi += 256;
                 } while (rhi < pos + 64 + 2 * QZK_CAP);
@@ -514,6 +520,26 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         QZK_T(12);
     }
 
+    if (crcT) {
+        /* a last match may have carried the parse to the end of the chunk past rows the ring never asked for */
+        for (; rhi < n; rhi += 256) {
+            const uint32_t a = rhi + 4 * (uint32_t)lane;
+            if (a + 4 <= n) crc_acc = qzk_k1crc_step(crcT, crc_acc, qz_ld32(src + coff + a));
+        }
+        /* a lane's dwords end at 4 l + 4 + 256 (rows - 1); shift its share over the dword-covered bytes that follow, XOR the shares, and
+         * append the n & 3 bytes no dword covered (crc32_combine with the CRC of that tail) */
+        const uint32_t n4 = n & ~3u;
+        const uint32_t mine = n4 > 4u * (uint32_t)lane ? (n4 - 4u * (uint32_t)lane + 252u) >> 8 : 0;   /* dwords this lane folded */
+        uint32_t part = 0;
+        if (mine) part = qzk_multmodp(qzk_x2nmodp(crcT->x2n, n4 - (4u * (uint32_t)lane + 4u + 256u * (mine - 1)), 3), crc_acc);
+        for (int d = 32; d >= 1; d >>= 1) part ^= qz_shfl(part, lane ^ d);
+        if (n & 3u) {
+            uint32_t c = 0xffffffffu;
+            for (uint32_t i = n4; i < n; i++) c = crcT->tab[0][(c ^ src[coff + i]) & 0xff] ^ (c >> 8);
+            part = qzk_multmodp(qzk_x2nmodp(crcT->x2n, n & 3u, 3), part) ^ ~c;
+        }
+        *crc_slot = part;                   /* wave-uniform: every lane stores the same word */
+    }
     /* zlib's final loop top (lookahead == 0) may still slide before the last flush */
     if (cur_bstart >= base) can_store |= 1u << nfull;
     mt->nsym = nsym; mt->nfull = nfull; mt->can_store = can_store; mt->n = n;      /* uniform, all lanes */

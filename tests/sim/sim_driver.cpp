@@ -26,7 +26,8 @@ extern "C" {
 static uint32_t g_k1_epoch = 1;
 static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint32_t nchunks,
                    uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta, const uint32_t *cdesc = nullptr, uint32_t waves = 3,
-                   uint8_t *slots = nullptr, uint32_t stride = 0, uint32_t final_chunk = ~0u, uint32_t *olen = nullptr)
+                   uint8_t *slots = nullptr, uint32_t stride = 0, uint32_t final_chunk = ~0u, uint32_t *olen = nullptr,
+                   uint32_t *ocrc = nullptr)
 {
     static std::vector<qzk_bkt> tables;
     const size_t need = (size_t)wgs * QZK_HSIZE * QZK_K1_WAVES;
@@ -36,7 +37,7 @@ static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_
     }
     uint32_t counter = 0;
     sim::launch(wgs, 64 * waves, 0, [&] { qzk_lz77_pull_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, tables.data(), &counter, cdesc, g_k1_epoch,
-                                                                slots, stride, final_chunk, olen); });
+                                                                slots, stride, final_chunk, olen, ocrc); });
     g_k1_epoch += nchunks;
 }
 
@@ -63,7 +64,7 @@ static int deflate_variant(int variant, const uint8_t *src, uint64_t n, uint32_t
     std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
     if (variant == 1)           /* the product's shape: the wave that parsed a chunk codes it too, in the same LDS */
         run_k1(2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), nullptr, 3, slots.data(), stride,
-               last ? nchunks - 1 : ~0u, olen.data());
+               last ? nchunks - 1 : ~0u, olen.data(), ocrc.data());
     else {
         run_k1(2, src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data());
         sim::launch(nchunks, QZK_HW, 0, [&] {
@@ -71,7 +72,7 @@ static int deflate_variant(int variant, const uint8_t *src, uint64_t n, uint32_t
                             last ? nchunks - 1 : ~0u, olen.data(), nullptr);
         });
     }
-    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data(), nullptr); });
+    if (variant != 1) sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data(), nullptr); });
     uint64_t pos = 0;
     for (uint32_t c = 0; c < nchunks; c++) {
         memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);

@@ -75,11 +75,14 @@ def test_deflate_fused_k1_k2(sim):
     parse no longer needs), chunk after chunk on the same wave."""
     for kind, n, chunk in (("silesia", 200000, 65536), ("lzmix", 66000, 16384), ("runs", 140000, 131072),
                            ("text", 9000, 1024), ("allA", 70000, 65536), ("rand", 0, 65536), ("rand", 70000, 16384),
-                           ("mod200", 300000, 65536), ("text", 100000, 4096)):
+                           ("mod200", 300000, 65536), ("text", 100000, 4096), ("text", 70001, 65536), ("silesia", 65539, 65536),
+                           ("records", 131074, 65536), ("text", 1027, 1024), ("text", 3, 65536), ("text", 259, 65536)):
         src = datagen.gen_bytes(kind, n, 77)
         for last in (1, 0):
-            out, _ = _sim_deflate(sim, src, chunk, last=last, fused=True)
+            out, crcs = _sim_deflate(sim, src, chunk, last=last, fused=True)
             assert out == O.sw_compress("RAW", src, chunk, 1, last=last, cap=n * 9 // 8 + 8192)[2], (kind, n, chunk, last)
+            for i in range(len(crcs) if n else 0):      # the CRC that rides along K1's input reads
+                assert crcs[i] == (zlib.crc32(src[i * chunk:(i + 1) * chunk]) & 0xffffffff), (kind, n, chunk, i)
 
 
 def test_deflate_not_last(sim):

@@ -1,0 +1,10 @@
+#!/bin/bash
+# CRC inside K1 + marker radix sort: parity, bench, host-step trace of one decompress call
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout 900 python -m pytest tests/test_gpu_deflate.py tests/test_gpu_golden.py tests/test_gpu_api.py tests/test_gpu_inflate.py -x -q 2>&1 | tail -3
+timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu --no-extra 2>&1 | grep '^{' | python -c "
+import sys,json
+r=json.loads(sys.stdin.read()); print(r['value'], r['config']['compress_GBps'], r['config']['decompress_GBps'], r['roofline']['launch_ms'], r['roofline']['other_kernels_ms'])" | tee gpurun_out/s_crc.log
+QATZIP_AMD_TRACE=1 timeout 200 python bench.py --steps 1 --warmup 1 --no-cpu --no-extra 2>&1 | grep qzd_inflate_stream | tail -12 | tee -a gpurun_out/s_crc.log
