@@ -59,11 +59,15 @@ typedef struct {
     uint32_t stage[104];               /* 64 lanes x 48 bits + the pending partial byte */
 } qzk_huff_lds;
 
-QZ_DEV uint32_t qzk_bitrev(uint32_t code, int len)
+QZ_DEV uint32_t qzk_bitrev(uint32_t code, int len)         /* len 1..15 */
 {
+#ifdef QZ_SIM
     uint32_t r = 0;
     for (int i = 0; i < len; i++) { r = (r << 1) | (code & 1); code >>= 1; }
     return r;
+#else
+    return __builtin_bitreverse32(code) >> (32 - len);
+#endif
 }
 
 /* ------------------------------------------------------------------ lane-0 tree code */
@@ -443,9 +447,10 @@ template <bool L2> QZ_DEV uint32_t qzk_sym_ld16(const uint16_t *p)
 /* K2 for one chunk by one wave: `in` = the chunk's input, lcs/dists/mt = what K1 left for it, `out` = the chunk's slot */
 template <bool L2>
 QZ_DEV void qzk_huff_chunk(qzk_huff_lds *Sp, const int lane, const uint8_t *in, const uint8_t *lcs, const uint16_t *dists,
-                           const qzk_lzmeta *mt, uint8_t *out, const bool is_final, uint32_t *out_len)
+                           const qzk_lzmeta *mt, uint8_t *out, const bool is_final, uint32_t *out_len, uint64_t *prof_plan = 0)
 {
     qzk_huff_lds &S = *Sp;
+    (void)prof_plan;
     const uint32_t n = mt->n, nsym = mt->nsym, nfull = mt->nfull, cs = mt->can_store;
 
     qzk_bitout bo;
@@ -475,11 +480,26 @@ QZ_DEV void qzk_huff_chunk(qzk_huff_lds *Sp, const int lane, const uint8_t *in, 
             }
         }
         qz_lds_sync();
-        if (lane == 0) {                                /* zlib's trees are built serially; other waves fill the CU meanwhile */
+#if defined(QZK_PROF) && !defined(QZ_SIM)
+        const uint64_t tp_ = __builtin_readcyclecounter();
+#endif
+        /* zlib's trees are built serially: one lane following a chain of LDS round trips while the CU's other waves parse.
+         * At raised priority its (few) instructions go out as soon as their operands are there instead of waiting for a
+         * turn among the other waves of the SIMD (QZK_NO_SETPRIO: measured without) */
+#if !defined(QZ_SIM) && !defined(QZK_NO_SETPRIO)
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        if (lane == 0) {
             S.fl[256] = 1;
             qzk_plan_block(&S, be - bs, (cs >> b) & 1);
         }
         qz_lds_sync();
+#if !defined(QZ_SIM) && !defined(QZK_NO_SETPRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#if defined(QZK_PROF) && !defined(QZ_SIM)
+        if (prof_plan) *prof_plan += __builtin_readcyclecounter() - tp_;
+#endif
         const uint32_t btype = S.btype;
 
         /* 3-bit block header */
@@ -585,8 +605,16 @@ QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_p
              * memory operations of one wave reach the L2 in issue order */
             qz_lds_sync();
             const bool is_final = cdesc ? (cdesc[chunk] & QZK_CDESC_FINAL) != 0 : chunk == final_chunk;
+#if defined(QZK_PROF) && !defined(QZ_SIM)
+            const uint64_t tk_ = __builtin_readcyclecounter();
+            uint64_t plan_ = 0;
+            qzk_huff_chunk<true>((qzk_huff_lds *)lds, qz_lane(), src + (uint64_t)chunk * chunk_sz, wlc, wdist, meta + chunk,
+                                 slots + (uint64_t)chunk * slot_stride, is_final, out_len + chunk, &plan_);
+            meta[chunk].prof[13] = __builtin_readcyclecounter() - tk_; meta[chunk].prof[14] = plan_;
+#else
             qzk_huff_chunk<true>((qzk_huff_lds *)lds, qz_lane(), src + (uint64_t)chunk * chunk_sz, wlc, wdist, meta + chunk,
                                  slots + (uint64_t)chunk * slot_stride, is_final, out_len + chunk);
+#endif
             qz_lds_sync();
         }
     }

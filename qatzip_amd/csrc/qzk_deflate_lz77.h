@@ -66,7 +66,6 @@ typedef struct __attribute__((aligned(16))) { uint32_t w0, w1, w2, ep; } qzk_bkt
 /* moved as ONE 16-byte access (a struct load lets the compiler fetch ep first and the rest behind a branch: two dependent
  * round trips to HBM) */
 typedef uint32_t qzk_u32x4 __attribute__((vector_size(16)));
-typedef uint32_t qz_u32nt __attribute__((aligned(1)));      /* a dword at any byte address, for the non-temporal builtin */
 
 /* The gather of a table entry is served by the L2 (agent-scope `sc1` load), never by this CU's vector L1: the sixteen
  * waves of a workgroup keep their entries of one bucket in one cache line, and the L1 (write-through, no write-allocate,
@@ -122,6 +121,12 @@ QZ_DEV uint32_t qzk_ld32g(const uint8_t *src, uint64_t off, uint64_t src_len)
     return v;
 }
 
+/* the same with one test on the common path */
+QZ_DEV uint32_t qzk_ld32g_fast(const uint8_t *src, uint64_t off, uint64_t src_len)
+{
+    return off + 4 <= src_len ? qz_ld32(src + off) : qzk_ld32g(src, off, src_len);
+}
+
 /* low dword of {hi,lo} >> 8*s, s in 0..3 (v_alignbyte_b32) */
 QZ_DEV uint32_t qzk_alignbyte(uint32_t hi, uint32_t lo, uint32_t s)
 {
@@ -169,11 +174,15 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     uint32_t *const slot = lds, *const scnt = lds + QZK_NSLOT, *const ring = lds + 2 * QZK_NSLOT;
     uint32_t rhi = 0;                      /* chunk offset the ring is filled up to (multiple of 256) */
     uint32_t crc_acc = 0;                  /* this lane's share of the chunk's CRC-32 (crcT != NULL) */
+    uint32_t rnext = qzk_ld32g_fast(src, (uint64_t)chunk * chunk_sz + 4 * (uint32_t)qz_lane(), src_len);   /* my dword of the row at rhi */
 #define QZK_RING16(dst, ca) do { const uint32_t r_ = (ca) & (QZK_RING - 1), i_ = r_ >> 2, s_ = r_ & 3; \
         const uint32_t d0_ = ring[i_ & (QZK_RINGW - 1)], d1_ = ring[(i_ + 1) & (QZK_RINGW - 1)], d2_ = ring[(i_ + 2) & (QZK_RINGW - 1)], \
                        d3_ = ring[(i_ + 3) & (QZK_RINGW - 1)], d4_ = ring[(i_ + 4) & (QZK_RINGW - 1)]; \
         (dst)[0] = qzk_alignbyte(d1_, d0_, s_); (dst)[1] = qzk_alignbyte(d2_, d1_, s_); \
         (dst)[2] = qzk_alignbyte(d3_, d2_, s_); (dst)[3] = qzk_alignbyte(d4_, d3_, s_); } while (0)
+#define QZK_RING4(ca) ({ const uint32_t r_ = (ca) & (QZK_RING - 1), i_ = r_ >> 2; \
+        qzk_alignbyte(ring[(i_ + 1) & (QZK_RINGW - 1)], ring[i_ & (QZK_RINGW - 1)], r_ & 3); })
+#define QZK_AHEAD (64 + 258 + 6)       /* bytes of input the ring holds beyond the window start */
 
     const int lane = qz_lane();
     const uint64_t coff = (uint64_t)chunk * chunk_sz;
@@ -181,6 +190,27 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     uint8_t *olc = sym_lc;                          /* this chunk's symbol arrays (the caller placed them) */
     uint16_t *odist = sym_dist;
     qzk_lzmeta *mt = meta + chunk;
+    /* common-prefix length of the strings at chunk offsets ca (a lane of the current window) and cb < ca, at most maxlen:
+     * the whole wave compares, four bytes a lane.  ca's side always comes out of the ring (it reaches QZK_AHEAD past the
+     * window), cb's side too unless the candidate is more than ~3.7 KiB back - a match that outgrows the 16 speculative
+     * bytes used to cost the parse a round trip to HBM per string */
+    auto wave_matchlen = [&](uint32_t ca, uint32_t cb, int maxlen) -> int {
+        const bool near = (int64_t)cb >= (int64_t)rhi - QZK_RING;
+        for (int off = 0; off < maxlen; off += 256) {
+            const int o = off + 4 * lane;
+            const bool act = o < maxlen;
+            uint32_t x = 0;
+            if (act) x = QZK_RING4(ca + (uint32_t)o) ^ (near ? QZK_RING4(cb + (uint32_t)o) : qzk_ld32g(src, coff + cb + (uint32_t)o, src_len));
+            const uint64_t mm = qz_ballot(act && x != 0);
+            if (mm) {
+                const int f = qz_ctz64(mm);
+                const uint32_t xf = qz_readlane(x, f);
+                const int len = off + 4 * f + (qz_ctz32(xf) >> 3);
+                return len < maxlen ? len : maxlen;
+            }
+        }
+        return maxlen;
+    };
 
     /* nothing to clear: the entries of earlier chunks carry other epochs.  (All cross-lane ordering in here is
      * wave-local - the waves of a workgroup never exchange anything - so the syncs are wavefront-scope: no vmcnt(0).) */
@@ -225,22 +255,21 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         const bool guard = coff + pos + 64 + 2 * QZK_CAP > src_len;
         uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
         {
-            /* top the ring up to 96 bytes past the window start: one coalesced 256-byte load every few windows */
-            if (rhi < pos + 64 + 2 * QZK_CAP) {
+            /* top the ring up to QZK_AHEAD bytes past the window start (the longest match of the last lane ends before
+             * that: extensions beyond the 16 speculative bytes read it from here): one coalesced 256-byte row every few windows.  The row
+             * at rhi is always already in a register (rnext, asked for when the row before it was stored): by the time it
+             * is needed its load has long landed behind a table gather of an earlier window (loads return in order), so
+             * the input stream costs the window no round trip of its own */
+            if (rhi < pos + QZK_AHEAD) {
                 do {
                     const uint32_t a = rhi + 4 * (uint32_t)lane;
-                    const uint64_t g = coff + a;
-#if defined(QZK_NT) && !defined(QZ_SIM)      /* experiment: streamed once, keep it from displacing table lines in L2 (no CRC) */
-                    ring[(a >> 2) & (QZK_RINGW - 1)] = g + 4 <= src_len ? __builtin_nontemporal_load((const qz_u32nt *)(src + g)) : qzk_ld32g(src, g, src_len);
-#else
-                    const uint32_t wd = g + 4 <= src_len ? qz_ld32(src + g) : qzk_ld32g(src, g, src_len);
-                    ring[(a >> 2) & (QZK_RINGW - 1)] = wd;
+                    ring[(a >> 2) & (QZK_RINGW - 1)] = rnext;
                     /* the chunk's CRC-32 rides along: every byte of the chunk passes here exactly once, lane l seeing the
                      * dwords at 256 r + 4 l; it folds them Horner-style (crc32_combine algebra, 8 LDS lookups a step) */
-                    if (crcT && a + 4 <= n) crc_acc = qzk_k1crc_step(crcT, crc_acc, wd);
-#endif
+                    if (crcT && a + 4 <= n) crc_acc = qzk_k1crc_step(crcT, crc_acc, rnext);
                     rhi += 256;
-                } while (rhi < pos + 64 + 2 * QZK_CAP);
+                    rnext = qzk_ld32g_fast(src, coff + a + 256, src_len);
+                } while (rhi < pos + QZK_AHEAD);
                 qz_lds_sync();
             }
             uint32_t w[4];
@@ -414,7 +443,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                     }
                     if (len > maxlen_l) len = maxlen_l;
                     if (len == QZK_CAP && maxlen_l > QZK_CAP)
-                        len = qzk_wave_matchlen(src, src_len, coff + pos + (uint32_t)l, coff + pos + (uint32_t)j, maxlen_l, lane);
+                        len = wave_matchlen(pos + (uint32_t)l, pos + (uint32_t)j, maxlen_l);
                     cnt++;
                     if (len > bl) { bl = len; bd = (uint32_t)(l - j); }
                     if (len >= nice_l) fin = true;
@@ -426,7 +455,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                         const uint32_t ck = qz_readlane(k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3, l);
                         int len = (int)qz_readlane((uint32_t)(k == 0 ? l0 : k == 1 ? l1 : k == 2 ? l2 : l3), l);
                         if (len == QZK_CAP && maxlen_l > QZK_CAP)
-                            len = qzk_wave_matchlen(src, src_len, coff + pos + (uint32_t)l, coff + ck, maxlen_l, lane);
+                            len = wave_matchlen(pos + (uint32_t)l, ck, maxlen_l);
                         cnt++;
                         if (len > bl) { bl = len; bd = (pos + (uint32_t)l) - ck; }
                         if (len >= nice_l) fin = true;
@@ -452,13 +481,8 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         const uint32_t idx = nsym + rank;
         const uint32_t step = mlen ? mlen : 1;
         if (isP) {
-#if defined(QZK_NT) && !defined(QZ_SIM)
-            __builtin_nontemporal_store((uint8_t)(mlen ? mlen - 3 : (w0 & 0xff)), &olc[idx]);
-            __builtin_nontemporal_store((uint16_t)mdist, &odist[idx]);
-#else
             olc[idx] = (uint8_t)(mlen ? mlen - 3 : (w0 & 0xff));
             odist[idx] = (uint16_t)mdist;
-#endif
         }
         {   /* a symbol that completes a 32767-symbol block (at most one per window) */
             const bool closes = isP && ((idx + 1) % QZK_LITBUF == 0);
@@ -524,7 +548,8 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         /* a last match may have carried the parse to the end of the chunk past rows the ring never asked for */
         for (; rhi < n; rhi += 256) {
             const uint32_t a = rhi + 4 * (uint32_t)lane;
-            if (a + 4 <= n) crc_acc = qzk_k1crc_step(crcT, crc_acc, qz_ld32(src + coff + a));
+            if (a + 4 <= n) crc_acc = qzk_k1crc_step(crcT, crc_acc, rnext);
+            rnext = qzk_ld32g_fast(src, coff + a + 256, src_len);
         }
         /* a lane's dwords end at 4 l + 4 + 256 (rows - 1); shift its share over the dword-covered bytes that follow, XOR the shares, and
          * append the n & 3 bytes no dword covered (crc32_combine with the CRC of that tail) */
@@ -547,6 +572,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     for (int k = 0; k < 16; k++) mt->prof[k] = prof[k];
 #endif
 #undef QZK_RING16
+#undef QZK_RING4
 }
 
 #endif

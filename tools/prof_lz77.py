@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import datagen  # noqa: E402
 
-SO = os.path.join(ROOT, "gpurun_out", "libqatzip_amd_prof.so")
+SO = os.path.join(ROOT, "build", "var", "lib_k1prof.so")       # built here (python tools/prof_lz77.py build), travels with the snapshot
 
 
 def build():
@@ -58,6 +58,8 @@ def main():
         print("  %-16s %12.0f ticks/chunk  %5.1f %%  %8.1f /window" % (names[k], tot[k], 100 * tot[k] / cyc, tot[k] / tot[8]))
     print("  windows/chunk %.0f  complex lanes/window %.2f  suspect commits/window %.2f  symbols/window %.1f"
           % (tot[8], tot[9] / tot[8], tot[10] / tot[8], tot[11] / tot[8]))
+    print("  K2 in the wave: %.0f ticks/chunk (%.1f %% on top of the parse), of which the serial tree build %.0f"
+          % (tot[13], 100 * tot[13] / cyc, tot[14]))
     per = prof[:, [0, 1, 2, 3, 4, 5, 6, 7, 12]].sum(1)
     print("  total ticks/chunk %.0f  (min %.0f  max %.0f)  => ideal %.2f ms at 256 CUs, 2.3 GHz"
           % (cyc, per.min(), per.max(), per.sum() / 256 / 2.3e6))

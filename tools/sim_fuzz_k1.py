@@ -23,7 +23,7 @@ if not os.path.exists(so):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-I", SIMDIR, "-Wno-unused-function", "-o", so,
                            os.path.join(SIMDIR, "sim_driver.cpp")])
 S = C.CDLL(so)
-S.sim_deflate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+S.sim_deflate_fused.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t0 = time.time(); n_ok = 0; bad = []
@@ -47,9 +47,11 @@ while time.time() - t0 < budget:
     nch = max(1, (n + chunk - 1) // chunk)
     cap = n * 9 // 8 + 4096 * (nch + 1)
     out = C.create_string_buffer(cap); ol = C.c_uint64(0); crcs = np.zeros(nch, np.uint32)
-    S.sim_deflate(src, n, chunk, last, out, C.byref(ol), crcs.ctypes.data)
+    S.sim_deflate_fused(src, n, chunk, last, out, C.byref(ol), crcs.ctypes.data)      # the product's shape: K2 and the CRC inside the K1 waves
     exp = O.sw_compress("RAW", src, chunk, 1, last=last, cap=cap)[2]
-    if out.raw[:ol.value] != exp:
+    import zlib
+    crc_ok = all(int(crcs[i]) == (zlib.crc32(src[i * chunk:(i + 1) * chunk]) & 0xffffffff) for i in range(nch))
+    if out.raw[:ol.value] != exp or not crc_ok:
         bad.append((seed, kind, n, chunk, last)); print("MISMATCH", bad[-1], flush=True)
     else:
         n_ok += 1
