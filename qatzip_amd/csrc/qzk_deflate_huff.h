@@ -75,28 +75,48 @@ QZ_DEV uint32_t qzk_bitrev(uint32_t code, int len)         /* len 1..15 */
 
 QZ_DEV void qzk_pqdown(uint32_t *heap, int heap_len, int k)
 {
-    uint32_t v = heap[k];
+    /* one LDS round trip per level: both children come in one access (j is even, the slot after the heap's end exists
+     * and is never chosen) and the smaller one is picked in registers */
+    const uint32_t v = heap[k];
     int j = k << 1;
     while (j <= heap_len) {
-        if (j < heap_len && QZK_SMALLER(heap[j + 1], heap[j])) j++;
-        if (QZK_SMALLER(v, heap[j])) break;
-        heap[k] = heap[j]; k = j; j <<= 1;
+        const uint32_t c0 = heap[j], c1 = heap[j + 1];
+        uint32_t c = c0;
+        if (j < heap_len && QZK_SMALLER(c1, c0)) { j++; c = c1; }
+        if (QZK_SMALLER(v, c)) break;
+        heap[k] = c; k = j; j <<= 1;
     }
     heap[k] = v;
 }
 
-/* zlib build_tree(): freq[] -> len[] (and codes).  Returns max_code.  Adds to *opt / *stat. */
-QZ_DEV int qzk_build_tree(qzk_huff_lds *S, uint32_t *freq, uint8_t *len, uint32_t *codes, int elems,
-                          int max_length, int stype /*0 l,1 d,2 bl*/, uint32_t *opt, uint32_t *stat)
+/* zlib build_tree(), taken apart: what is a loop over independent elements runs on the wave, what is the heap stays on
+ * lane 0.
+ *   qzk_tree_init  (wave)   nfreq[] copies, len = 0 for unused symbols, the symbols in use into heap[1..] in symbol order
+ *   qzk_tree_core  (lane 0) forced nodes, heap order, the tree itself, gen_bitlen with the overflow repair, opt / stat
+ *   qzk_tree_codes (wave)   gen_codes: a symbol's code is next_code[len] + the number of earlier symbols of that length */
+QZ_DEV void qzk_tree_init(qzk_huff_lds *S, const uint32_t *freq, uint8_t *len, int elems, int lane, int *heap_len_out, int *max_code_out)
+{
+    int heap_len = 0, max_code = -1;
+    for (int n0 = 0; n0 < elems; n0 += 64) {
+        const int n = n0 + lane;
+        const bool in = n < elems;
+        const uint32_t f = in ? freq[n] : 0;
+        if (in) { S->nfreq[n] = (uint16_t)f; if (!f) len[n] = 0; }
+        const uint64_t nz = qz_ballot(f != 0);
+        if (f) S->heap[heap_len + 1 + qz_popc64(nz & qz_below(lane))] = (f << 15) | (uint32_t)n;
+        if (nz) max_code = n0 + qz_msb64(nz);
+        heap_len += qz_popc64(nz);
+    }
+    *heap_len_out = heap_len; *max_code_out = max_code;
+}
+
+/* lane 0.  Returns max_code.  Adds to *opt / *stat. */
+QZ_DEV int qzk_tree_core(qzk_huff_lds *S, uint32_t *freq, uint8_t *len, int elems, int heap_len, int max_code,
+                         int max_length, int stype /*0 l,1 d,2 bl*/, uint32_t *opt, uint32_t *stat)
 {
     uint32_t *heap = S->heap; uint16_t *order = S->order, *dad = S->dad, *nf = S->nfreq;
-    int heap_len = 0, heap_max = QZK_HEAP, max_code = -1, n, m, node;
+    int heap_max = QZK_HEAP, n, m, node;
 
-    for (n = 0; n < elems; n++) {
-        nf[n] = (uint16_t)freq[n];
-        if (freq[n] != 0) { heap[++heap_len] = (freq[n] << 15) | (uint32_t)n; max_code = n; }
-        else len[n] = 0;
-    }
     while (heap_len < 2) {
         node = max_code < 2 ? ++max_code : 0;
         heap[++heap_len] = (1u << 15) | (uint32_t)node;
@@ -165,16 +185,26 @@ QZ_DEV int qzk_build_tree(qzk_huff_lds *S, uint32_t *freq, uint8_t *len, uint32_
             }
         }
     }
-    /* gen_codes */
-    {
-        uint32_t next_code[16], code = 0;
-        for (int bits = 1; bits <= 15; bits++) { code = (code + S->bl_count[bits - 1]) << 1; next_code[bits] = code; }
-        for (n = 0; n <= max_code; n++) {
-            int l = len[n];
-            codes[n] = l ? (qzk_bitrev(next_code[l]++, l) | ((uint32_t)l << 16)) : 0;
-        }
-    }
     return max_code;
+}
+
+/* gen_codes on the wave: sixty-four symbols a step; `codes` may be the storage the frequencies were in */
+QZ_DEV void qzk_tree_codes(const qzk_huff_lds *S, const uint8_t *len, uint32_t *codes, int max_code, int lane)
+{
+    uint32_t next_code[16], code = 0;
+    for (int bits = 1; bits <= 15; bits++) { code = (code + S->bl_count[bits - 1]) << 1; next_code[bits] = code; }
+    for (int n0 = 0; n0 <= max_code; n0 += 64) {
+        const int n = n0 + lane;
+        const int l = n <= max_code ? len[n] : 0;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int b = 1; b <= 15; b++) {
+            const uint64_t m = qz_ballot(l == b);
+            if (l == b) mine = next_code[b] + (uint32_t)qz_popc64(m & qz_below(lane));
+            next_code[b] += (uint32_t)qz_popc64(m);
+        }
+        if (n <= max_code) codes[n] = l ? (qzk_bitrev(mine, l) | ((uint32_t)l << 16)) : 0;
+    }
 }
 
 QZ_DEV void qzk_scan_tree(qzk_huff_lds *S, uint8_t *len, int max_code)
@@ -224,49 +254,83 @@ QZ_DEV void qzk_send_tree(qzk_huff_lds *S, uint8_t *len, int max_code)
     }
 }
 
-/* lane 0: everything _tr_flush_block decides.  Leaves S->btype (0 stored,1 fixed,2 dynamic),
- * code tables and (dynamic) header bits, all AFTER the 3-bit block header. */
-QZ_DEV void qzk_plan_block(qzk_huff_lds *S, uint32_t stored_len, bool can_store)
+/* the whole wave: everything _tr_flush_block decides.  Leaves S->btype (0 stored,1 fixed,2 dynamic), code tables and
+ * (dynamic) header bits, all AFTER the 3-bit block header.  Ends with the wave in step (an LDS sync). */
+QZ_DEV void qzk_plan_block(qzk_huff_lds *S, uint32_t stored_len, bool can_store, int lane)
 {
     static const uint8_t bl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    uint32_t opt = 0, stat = 0, opt_lenb, static_lenb;
-    int max_l, max_d, max_blindex;
+    uint32_t opt = 0, stat = 0;             /* lane 0's are the ones that count */
+    int hl, mc;
 
-    max_l = qzk_build_tree(S, S->fl, S->len_l, S->code_l, QZK_LCODES, 15, 0, &opt, &stat);
-    max_d = qzk_build_tree(S, S->fd, S->len_d, S->code_d, QZK_DCODES, 15, 1, &opt, &stat);
-    for (int i = 0; i < 19; i++) S->fbl[i] = 0;
-    qzk_scan_tree(S, S->len_l, max_l);
-    qzk_scan_tree(S, S->len_d, max_d);
-    qzk_build_tree(S, S->fbl, S->len_bl, S->code_bl, QZK_BLCODES, 7, 2, &opt, &stat);
-    for (max_blindex = QZK_BLCODES - 1; max_blindex >= 3; max_blindex--)
-        if (S->len_bl[bl_order[max_blindex]] != 0) break;
-    opt += 3 * ((uint32_t)max_blindex + 1) + 5 + 5 + 4;
-    opt_lenb = (opt + 3 + 7) >> 3;
-    static_lenb = (stat + 3 + 7) >> 3;
-    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+    if (lane == 0) S->fl[256] = 1;
+    qz_lds_sync();
+    qzk_tree_init(S, S->fl, S->len_l, QZK_LCODES, lane, &hl, &mc);
+    qz_lds_sync();
+    if (lane == 0) S->max_l = (uint32_t)qzk_tree_core(S, S->fl, S->len_l, QZK_LCODES, hl, mc, 15, 0, &opt, &stat);
+    qz_lds_sync();
+    const int max_l = (int)S->max_l;
+    qzk_tree_codes(S, S->len_l, S->code_l, max_l, lane);
+    qz_lds_sync();
 
-    if (stored_len + 4 <= opt_lenb && can_store) { S->btype = 0; return; }
-    if (static_lenb == opt_lenb) {
-        S->btype = 1;
+    qzk_tree_init(S, S->fd, S->len_d, QZK_DCODES, lane, &hl, &mc);
+    qz_lds_sync();
+    if (lane == 0) S->max_d = (uint32_t)qzk_tree_core(S, S->fd, S->len_d, QZK_DCODES, hl, mc, 15, 1, &opt, &stat);
+    qz_lds_sync();
+    const int max_d = (int)S->max_d;
+    qzk_tree_codes(S, S->len_d, S->code_d, max_d, lane);
+    qz_lds_sync();
+
+    if (lane == 0) {
+        for (int i = 0; i < 19; i++) S->fbl[i] = 0;
+        qzk_scan_tree(S, S->len_l, max_l);
+        qzk_scan_tree(S, S->len_d, max_d);
+    }
+    qz_lds_sync();
+    qzk_tree_init(S, S->fbl, S->len_bl, QZK_BLCODES, lane, &hl, &mc);
+    qz_lds_sync();
+    if (lane == 0) {
+        int max_blindex;
+        uint32_t opt_lenb, static_lenb;
+        qzk_tree_core(S, S->fbl, S->len_bl, QZK_BLCODES, hl, mc, 7, 2, &opt, &stat);
+        for (max_blindex = QZK_BLCODES - 1; max_blindex >= 3; max_blindex--)
+            if (S->len_bl[bl_order[max_blindex]] != 0) break;
+        opt += 3 * ((uint32_t)max_blindex + 1) + 5 + 5 + 4;
+        opt_lenb = (opt + 3 + 7) >> 3;
+        static_lenb = (stat + 3 + 7) >> 3;
+        if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+        S->btype = (stored_len + 4 <= opt_lenb && can_store) ? 0u : static_lenb == opt_lenb ? 1u : 2u;
+        S->stage[0] = (uint32_t)max_blindex;        /* handed to the header below (the staging tile is idle here) */
+    }
+    qz_lds_sync();
+    const uint32_t btype = S->btype;
+    if (btype == 0) return;
+    if (btype == 1) {
         /* fixed codes: canonical, lengths 8/9/7/8 and 5 */
-        for (int n = 0; n < 288; n++) {
+        for (int n = lane; n < 288; n += 64) {
             int l = n < 144 ? 8 : n < 256 ? 9 : n < 280 ? 7 : 8;
             uint32_t c = n < 144 ? 0x30 + (uint32_t)n : n < 256 ? 0x190 + (uint32_t)(n - 144)
                          : n < 280 ? (uint32_t)(n - 256) : 0xC0 + (uint32_t)(n - 280);
             S->code_l[n] = qzk_bitrev(c, l) | ((uint32_t)l << 16);
         }
-        for (int n = 0; n < 30; n++) S->code_d[n] = qzk_bitrev((uint32_t)n, 5) | (5u << 16);
+        if (lane < 30) S->code_d[lane] = qzk_bitrev((uint32_t)lane, 5) | (5u << 16);
+        qz_lds_sync();
         return;
     }
-    S->btype = 2;
-    for (int i = 0; i < 320; i++) S->hdr[i] = 0;
-    S->hbits = 0;
-    qzk_hdr_bits(S, (uint32_t)(max_l + 1 - 257), 5);
-    qzk_hdr_bits(S, (uint32_t)(max_d + 1 - 1), 5);
-    qzk_hdr_bits(S, (uint32_t)(max_blindex + 1 - 4), 4);
-    for (int r = 0; r <= max_blindex; r++) qzk_hdr_bits(S, S->len_bl[bl_order[r]], 3);
-    qzk_send_tree(S, S->len_l, max_l);
-    qzk_send_tree(S, S->len_d, max_d);
+    const int max_blindex = (int)S->stage[0];
+    qz_lds_sync();                                  /* every lane has read it: code_bl may replace fbl, hdr the heap */
+    qzk_tree_codes(S, S->len_bl, S->code_bl, QZK_BLCODES - 1, lane);
+    for (int i = lane; i < 320; i += 64) S->hdr[i] = 0;
+    qz_lds_sync();
+    if (lane == 0) {
+        S->hbits = 0;
+        qzk_hdr_bits(S, (uint32_t)(max_l + 1 - 257), 5);
+        qzk_hdr_bits(S, (uint32_t)(max_d + 1 - 1), 5);
+        qzk_hdr_bits(S, (uint32_t)(max_blindex + 1 - 4), 4);
+        for (int r = 0; r <= max_blindex; r++) qzk_hdr_bits(S, S->len_bl[bl_order[r]], 3);
+        qzk_send_tree(S, S->len_l, max_l);
+        qzk_send_tree(S, S->len_d, max_d);
+    }
+    qz_lds_sync();
 }
 
 /* ------------------------------------------------------------------ wave helpers */
@@ -483,17 +547,13 @@ QZ_DEV void qzk_huff_chunk(qzk_huff_lds *Sp, const int lane, const uint8_t *in, 
 #if defined(QZK_PROF) && !defined(QZ_SIM)
         const uint64_t tp_ = __builtin_readcyclecounter();
 #endif
-        /* zlib's trees are built serially: one lane following a chain of LDS round trips while the CU's other waves parse.
-         * At raised priority its (few) instructions go out as soon as their operands are there instead of waiting for a
-         * turn among the other waves of the SIMD (QZK_NO_SETPRIO: measured without) */
+        /* zlib's trees: the heap is one lane following a chain of LDS round trips while the CU's other waves parse, the
+         * loops around it run on the wave.  At raised priority its instructions go out as soon as their operands are there
+         * instead of waiting for a turn among the other waves of the SIMD */
 #if !defined(QZ_SIM) && !defined(QZK_NO_SETPRIO)
         __builtin_amdgcn_s_setprio(3);
 #endif
-        if (lane == 0) {
-            S.fl[256] = 1;
-            qzk_plan_block(&S, be - bs, (cs >> b) & 1);
-        }
-        qz_lds_sync();
+        qzk_plan_block(&S, be - bs, (cs >> b) & 1, lane);
 #if !defined(QZ_SIM) && !defined(QZK_NO_SETPRIO)
         __builtin_amdgcn_s_setprio(0);
 #endif

@@ -383,6 +383,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             if (lim > lstop) lim = lstop;
         }
         uint64_t Pm = 0;
+        uint64_t SHm = qz_ballot(mlen >= 3 && mlen <= QZK_MAXINS && avail - (int)mlen >= 3), S4m = qz_ballot(mlen == 4);
         int l = 0;
         while (l < lim) {
             uint64_t cxr = CX >> l;
@@ -409,7 +410,8 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 const uint32_t h_l = qz_readlane(h, l);
                 /* early out: no earlier lane of this window carries the hash and nothing needs extending =>
                  * the speculative answer is already exact */
-                if ((qz_ballot(canh && h == h_l) & qz_below(l)) == 0 && !((CAPM >> l) & 1)) {
+                const uint64_t earlier = qz_ballot(canh && h == h_l) & qz_below(l);
+                if (earlier == 0 && !((CAPM >> l) & 1)) {
                     Pm |= 1ull << l;
                     uint32_t ml = qz_readlane(mlen, l);
                     l += ml ? (int)ml : 1;
@@ -419,34 +421,38 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 const int avail_l = (int)look - l;
                 const int maxlen_l = avail_l < 258 ? avail_l : 258;
                 const int nice_l = avail_l < QZK_NICE ? avail_l : QZK_NICE;
-                /* inserted lanes so far: parse points with >=3 bytes ahead + interiors of short matches */
-                const uint64_t SH = qz_ballot(mlen >= 3 && mlen <= QZK_MAXINS && avail - (int)mlen >= 3);
-                const uint64_t S4 = qz_ballot(mlen == 4);
-                const uint64_t ps = Pm & SH;
-                const uint64_t I = (Pm & CANH) | (ps << 1) | (ps << 2) | ((ps & S4) << 3);
-                uint64_t Sh = qz_ballot(canh && h == h_l) & I & qz_below(l);
-                if (B == 0) Sh &= ~1ull;               /* window position 0 is NIL */
                 int cnt = 0, bl = 2; uint32_t bd = 0; bool fin = false;
-                const bool had_intra = Sh != 0;
-                const uint32_t a0 = qz_readlane(w0, l), a1 = qz_readlane(w1, l), a2 = qz_readlane(w2, l), a3 = qz_readlane(w3, l);
-                while (Sh && cnt < 4 && !fin) {
-                    int j = qz_msb64(Sh);
-                    Sh &= ~(1ull << j);
-                    /* both strings start inside this window: their first 16 bytes are already in registers */
-                    int len = QZK_CAP;
-                    {
-                        uint32_t d;
-                        d = a3 ^ qz_readlane(w3, j); if (d) len = 12 + (qz_ctz32(d) >> 3);
-                        d = a2 ^ qz_readlane(w2, j); if (d) len = 8 + (qz_ctz32(d) >> 3);
-                        d = a1 ^ qz_readlane(w1, j); if (d) len = 4 + (qz_ctz32(d) >> 3);
-                        d = a0 ^ qz_readlane(w0, j); if (d) len = (qz_ctz32(d) >> 3);
+                bool had_intra = false;
+                if (earlier) {
+                    /* inserted lanes so far: parse points with >=3 bytes ahead + interiors of short matches (SHm / S4m: the
+                     * lanes whose match is short / exactly four long, kept up to date as exact lanes change theirs) */
+                    const uint64_t ps = Pm & SHm;
+                    const uint64_t I = (Pm & CANH) | (ps << 1) | (ps << 2) | ((ps & S4m) << 3);
+                    uint64_t Sh = earlier & I;
+                    if (B == 0) Sh &= ~1ull;               /* window position 0 is NIL */
+                    had_intra = Sh != 0;
+                    if (Sh) {
+                        const uint32_t a0 = qz_readlane(w0, l), a1 = qz_readlane(w1, l), a2 = qz_readlane(w2, l), a3 = qz_readlane(w3, l);
+                        while (Sh && cnt < 4 && !fin) {
+                            int j = qz_msb64(Sh);
+                            Sh &= ~(1ull << j);
+                            /* both strings start inside this window: their first 16 bytes are already in registers */
+                            int len = QZK_CAP;
+                            {
+                                uint32_t d;
+                                d = a3 ^ qz_readlane(w3, j); if (d) len = 12 + (qz_ctz32(d) >> 3);
+                                d = a2 ^ qz_readlane(w2, j); if (d) len = 8 + (qz_ctz32(d) >> 3);
+                                d = a1 ^ qz_readlane(w1, j); if (d) len = 4 + (qz_ctz32(d) >> 3);
+                                d = a0 ^ qz_readlane(w0, j); if (d) len = (qz_ctz32(d) >> 3);
+                            }
+                            if (len > maxlen_l) len = maxlen_l;
+                            if (len == QZK_CAP && maxlen_l > QZK_CAP)
+                                len = wave_matchlen(pos + (uint32_t)l, pos + (uint32_t)j, maxlen_l);
+                            cnt++;
+                            if (len > bl) { bl = len; bd = (uint32_t)(l - j); }
+                            if (len >= nice_l) fin = true;
+                        }
                     }
-                    if (len > maxlen_l) len = maxlen_l;
-                    if (len == QZK_CAP && maxlen_l > QZK_CAP)
-                        len = wave_matchlen(pos + (uint32_t)l, pos + (uint32_t)j, maxlen_l);
-                    cnt++;
-                    if (len > bl) { bl = len; bd = (uint32_t)(l - j); }
-                    if (len >= nice_l) fin = true;
                 }
                 const int nc_l = (int)qz_readlane((uint32_t)nc, l);
                 const bool ex_l = qz_readlane((uint32_t)exact0, l) != 0;
@@ -463,6 +469,11 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 }
                 uint32_t nl = bl >= 3 ? (uint32_t)bl : 0;
                 if (lane == l) { mlen = nl; mdist = nl ? bd : 0; }
+                {
+                    const uint64_t bit = 1ull << l;
+                    SHm = (nl >= 3 && nl <= QZK_MAXINS && avail_l - (int)nl >= 3) ? SHm | bit : SHm & ~bit;
+                    S4m = nl == 4 ? S4m | bit : S4m & ~bit;
+                }
                 Pm |= 1ull << l;
                 l += nl ? (int)nl : 1;
             }
@@ -471,10 +482,8 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 
         QZK_T(5);
         /* ---- vector epilogue: symbols, block marks, table commit ---- */
-        const uint64_t SH = qz_ballot(mlen >= 3 && mlen <= QZK_MAXINS && avail - (int)mlen >= 3);
-        const uint64_t S4 = qz_ballot(mlen == 4);
-        const uint64_t ps = Pm & SH;
-        const uint64_t I = (Pm & CANH) | (ps << 1) | (ps << 2) | ((ps & S4) << 3);
+        const uint64_t ps = Pm & SHm;
+        const uint64_t I = (Pm & CANH) | (ps << 1) | (ps << 2) | ((ps & S4m) << 3);
         const bool isP = (Pm >> lane) & 1, isI = (I >> lane) & 1;
 
         const uint32_t rank = (uint32_t)qz_popc64(Pm & qz_below(lane));
@@ -510,10 +519,10 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             uint64_t todo = I & qz_ballot(suspect);
             QZK_C(10, qz_popc64(todo)); QZK_C(11, qz_popc64(Pm));
             while (todo) {
-                int j = qz_ctz64(todo);
-                todo &= todo - 1;
+                const int j = qz_msb64(todo);               /* the last inserted lane of its bucket: it writes the entry ... */
                 uint32_t b_j = qz_readlane(bucket, j);
                 const uint64_t same = qz_ballot(canh && bucket == b_j) & I;
+                todo &= ~same;                              /* ... and stands for every earlier one */
                 uint64_t mates = same & qz_below(j);
                 uint32_t m1 = 0, m2 = 0, m3 = 0;            /* up to three most recent inserted lanes with lane j's hash */
                 int nf = 1;
