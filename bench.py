@@ -343,14 +343,15 @@ def main():
         step()
     ctx.sync(); barrier(pg)
     dt = allreduce(pg, time.perf_counter() - t0, "MAX")
-    # dominant kernel (K1, the LZ77 parse): HIP events around every launch of the timed region, on its own stream
+    # dominant kernel (K1: the LZ77 parse, with K2 and the CRC in its waves): HIP events around every launch of the timed
+    # region, on the stream it is launched on
     k1_ms, k1_launches, k1_chunks = ctx.k1_stats()
 
     # per-direction split (untimed by the contract, reported alongside) and one K1 launch alone on the chip
     ctx.sync(); t1 = time.perf_counter(); compress_all(); ctx.sync(); tc = time.perf_counter() - t1
     t1 = time.perf_counter(); decompress_all(); ctx.sync(); td = time.perf_counter() - t1
     inf_ms = ctx.inflate_timing()
-    batch_chunks = ctx.batch_chunks()         # chunks per full K1 launch (three rounds over the resident waves)
+    batch_chunks = ctx.batch_chunks()         # three rounds over the resident waves: the probe launch below
     probe_n = min(batch_chunks * CHUNK, call_n[0])
     ctx.deflate_raw_async(view(qatzip_amd, d_src, 0, probe_n), probe_n, CHUNK, 1, 1, d_comp[0]); ctx.sync()
     k_ms = ctx.timing()                      # single batch => K1 ran alone on the chip
@@ -381,13 +382,14 @@ def main():
         # HBM traffic per K1 launch: PMC counters cannot be read from inside this process; they come from the committed
         # rocprofv3 --pmc passes of this same command (profiles/r2_pmc.json, tools/pmc_summary.py): FETCH_SIZE and
         # WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note; quoted only when the
-        # profiled command had the same launch mix (same --mb, same chunks per launch) - null otherwise, never stale.
+        # profiled command had the same launch mix (same --mb, same chunks per launch: a device-resident call is ONE launch
+        # of the fused K1+K2+CRC kernel, 32768 chunks for 2 GiB) - null otherwise, never stale.
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "r2_pmc.json")) as f:
                 pj = json.load(f)
             pk = pj["kernels"].get(pj.get("k1_key", ""))
-            if pk and pj.get("bench_mb") == args.mb and pj.get("k1_launch_chunks") == batch_chunks:
+            if pk and pj.get("bench_mb") == args.mb and pj.get("k1_launch_chunks") == round(k1_chunks / max(k1_launches, 1)):
                 traffic = pk["hbm_bytes_fetch_x2"]
         except (OSError, KeyError, ValueError):
             pass
@@ -419,7 +421,8 @@ def main():
                          "launch_ms": round(launch_ms, 3), "launches": int(k1_launches),
                          "chunks_per_launch": round(k1_chunks / max(k1_launches, 1), 1),
                          "full_launch_alone_ms": round(k_ms[0], 3), "full_launch_chunks": probe_n // CHUNK,
-                         "other_kernels_ms": {"qzk_huff_kernel": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
+                         "fused": "K2 (Huffman coding) and the chunk CRC-32 run inside this kernel's waves",
+                         "other_kernels_ms": {"separate K2 / CRC launches": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
                                               "inflate kernels (last call)": round(inf_ms[0], 3),
                                               "of which qzk_lz_resolve_kernel": round(inf_ms[2], 3),
                                               "qzk_crc_kernel(last call)": round(inf_ms[1], 3)}},

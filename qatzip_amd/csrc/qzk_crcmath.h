@@ -26,19 +26,15 @@ QZ_DEV uint32_t qzk_x2nmodp(const uint32_t *x2n, uint64_t n, unsigned k)
     return p;
 }
 
-/* what a K1 workgroup keeps in LDS for the CRC of its waves' chunks: the four byte tables of CRC-32 over a dword, the
- * four byte tables of the multiplication by x^(8*256) (a lane's consecutive dwords are 256 bytes apart), x^(2^i) */
-typedef struct { uint32_t tab[4][256]; uint32_t ktab[4][256]; uint32_t x2n[32]; } qzk_k1crc_lds;
+/* what a K1 workgroup keeps in LDS for the CRC of its waves' chunks, 1.1 KiB (nibble tables: K1 spends its LDS on waves):
+ * adv[k][v] = the CRC register v << 4k advanced over four zero bytes (a dword's CRC is the XOR of eight of them),
+ * mul[k][v] = (v << 4k) * x^(8*256) (a lane's consecutive dwords are 256 bytes apart), x2n[i] = x^(2^i) */
+typedef struct { uint32_t adv[8][16]; uint32_t mul[8][16]; uint32_t x2n[32]; } qzk_k1crc_lds;
 
 /* filled by the whole workgroup (any size >= 64), ends with a barrier */
 QZ_DEV void qzk_k1crc_init(qzk_k1crc_lds *S)
 {
     const uint32_t t0 = threadIdx.x, nt = blockDim.x;
-    for (uint32_t t = t0; t < 256; t += nt) {
-        uint32_t c = t;
-        for (int k = 0; k < 8; k++) c = (c & 1) ? QZK_POLY ^ (c >> 1) : c >> 1;
-        S->tab[0][t] = c;
-    }
     if (t0 == 0) {
         uint32_t p = 1u << 30;
         S->x2n[0] = p;
@@ -46,13 +42,12 @@ QZ_DEV void qzk_k1crc_init(qzk_k1crc_lds *S)
     }
     qz_block_sync();
     const uint32_t K = qzk_x2nmodp(S->x2n, 256, 3);
-    for (uint32_t t = t0; t < 256; t += nt) {
-        const uint32_t c0 = S->tab[0][t];
-        const uint32_t c1 = (c0 >> 8) ^ S->tab[0][c0 & 0xff];
-        const uint32_t c2 = (c1 >> 8) ^ S->tab[0][c1 & 0xff];
-        const uint32_t c3 = (c2 >> 8) ^ S->tab[0][c2 & 0xff];
-        S->tab[1][t] = c1; S->tab[2][t] = c2; S->tab[3][t] = c3;
-        for (int k = 0; k < 4; k++) S->ktab[k][t] = qzk_multmodp(K, t << (8 * k));
+    for (uint32_t t = t0; t < 128; t += nt) {
+        const uint32_t k = t >> 4, v = t & 15;
+        uint32_t c = v << (4 * k);
+        for (int i = 0; i < 32; i++) c = (c & 1) ? QZK_POLY ^ (c >> 1) : c >> 1;
+        S->adv[k][v] = c;
+        S->mul[k][v] = v ? qzk_multmodp(K, v << (4 * k)) : 0;
     }
     qz_block_sync();
 }
@@ -60,9 +55,19 @@ QZ_DEV void qzk_k1crc_init(qzk_k1crc_lds *S)
 /* acc * x^(8*256) + crc32(the four bytes of w): one Horner step of a lane over its column of the input */
 QZ_DEV uint32_t qzk_k1crc_step(const qzk_k1crc_lds *S, uint32_t acc, uint32_t w)
 {
-    uint32_t c = 0xffffffffu ^ w;
-    c = S->tab[3][c & 0xff] ^ S->tab[2][(c >> 8) & 0xff] ^ S->tab[1][(c >> 16) & 0xff] ^ S->tab[0][c >> 24];
-    return S->ktab[0][acc & 0xff] ^ S->ktab[1][(acc >> 8) & 0xff] ^ S->ktab[2][(acc >> 16) & 0xff] ^ S->ktab[3][acc >> 24] ^ ~c;
+    const uint32_t c = 0xffffffffu ^ w;
+    uint32_t r = 0xffffffffu;               /* the final complement of crc32(w) */
+#pragma unroll
+    for (int k = 0; k < 8; k++) r ^= S->adv[k][(c >> (4 * k)) & 15] ^ S->mul[k][(acc >> (4 * k)) & 15];
+    return r;
+}
+
+/* CRC register after one more byte (the <= 3 bytes of a chunk no dword covers) */
+QZ_DEV uint32_t qzk_crc_byte(uint32_t c, uint32_t byte)
+{
+    c ^= byte;
+    for (int i = 0; i < 8; i++) c = (c & 1) ? QZK_POLY ^ (c >> 1) : c >> 1;
+    return c;
 }
 
 #endif

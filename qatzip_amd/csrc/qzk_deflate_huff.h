@@ -33,10 +33,11 @@
 
 typedef struct { uint32_t tab[4][256]; uint32_t ktab[4][256]; uint32_t x2n[32]; uint32_t red[16]; } qzk_crc_lds;
 
-/* One wave's K2 state, 8.1 KiB: small enough that the sixteen waves of a K1 workgroup can each run K2 on the chunk they
+/* One wave's K2 state, 5.8 KiB: small enough that the sixteen waves of a K1 workgroup can each run K2 on the chunk they
  * just parsed, in the LDS their parse no longer needs (qzk_lz77_pull_kernel below).  Arrays whose lifetimes do not
- * overlap share storage: a tree's codes replace its frequencies (build_tree has copied them to nfreq[] by then), the
- * dynamic header is assembled where the heap stood. */
+ * overlap share storage: a tree's codes replace its frequencies (gen_bitlen, their last reader, is done by then), the
+ * dynamic header is assembled where the heap stood.  zlib's copy of the frequencies into the tree nodes has no
+ * counterpart: a leaf's frequency is read where the histogram left it, an inner node's only ever from its heap entry. */
 typedef struct {
     /* frequencies (u32 for LDS atomics) -> code tables: code | len<<16 */
     union { uint32_t fl[288]; uint32_t code_l[288]; };
@@ -44,13 +45,12 @@ typedef struct {
     union { uint32_t fbl[20]; uint32_t code_bl[20]; };
     union {
         struct {                            /* tree-build scratch (lane 0) */
-            uint32_t heap[QZK_HEAP + 3];    /* freq<<15 | depth<<10 | node */
-            uint16_t order[QZK_HEAP + 3];
+            uint32_t heap[QZK_LCODES + 4];  /* freq<<15 | depth<<10 | node: at most one entry per symbol (+ the slot pqdown reads past the end) */
+            uint16_t order[QZK_HEAP + 3];   /* zlib keeps this in the back of its heap[] */
         };
         struct { uint32_t hdr[320]; uint32_t hbits; };      /* dynamic header bits */
     };
     uint16_t dad[QZK_HEAP + 3];
-    uint16_t nfreq[QZK_HEAP + 3];
     uint8_t len_l[QZK_HEAP + 3], len_d[64], len_bl[40];
     uint16_t bl_count[16];
     /* decisions */
@@ -91,7 +91,7 @@ QZ_DEV void qzk_pqdown(uint32_t *heap, int heap_len, int k)
 
 /* zlib build_tree(), taken apart: what is a loop over independent elements runs on the wave, what is the heap stays on
  * lane 0.
- *   qzk_tree_init  (wave)   nfreq[] copies, len = 0 for unused symbols, the symbols in use into heap[1..] in symbol order
+ *   qzk_tree_init  (wave)   len = 0 for unused symbols, the symbols in use into heap[1..] in symbol order
  *   qzk_tree_core  (lane 0) forced nodes, heap order, the tree itself, gen_bitlen with the overflow repair, opt / stat
  *   qzk_tree_codes (wave)   gen_codes: a symbol's code is next_code[len] + the number of earlier symbols of that length */
 QZ_DEV void qzk_tree_init(qzk_huff_lds *S, const uint32_t *freq, uint8_t *len, int elems, int lane, int *heap_len_out, int *max_code_out)
@@ -101,7 +101,7 @@ QZ_DEV void qzk_tree_init(qzk_huff_lds *S, const uint32_t *freq, uint8_t *len, i
         const int n = n0 + lane;
         const bool in = n < elems;
         const uint32_t f = in ? freq[n] : 0;
-        if (in) { S->nfreq[n] = (uint16_t)f; if (!f) len[n] = 0; }
+        if (in && !f) len[n] = 0;
         const uint64_t nz = qz_ballot(f != 0);
         if (f) S->heap[heap_len + 1 + qz_popc64(nz & qz_below(lane))] = (f << 15) | (uint32_t)n;
         if (nz) max_code = n0 + qz_msb64(nz);
@@ -114,13 +114,14 @@ QZ_DEV void qzk_tree_init(qzk_huff_lds *S, const uint32_t *freq, uint8_t *len, i
 QZ_DEV int qzk_tree_core(qzk_huff_lds *S, uint32_t *freq, uint8_t *len, int elems, int heap_len, int max_code,
                          int max_length, int stype /*0 l,1 d,2 bl*/, uint32_t *opt, uint32_t *stat)
 {
-    uint32_t *heap = S->heap; uint16_t *order = S->order, *dad = S->dad, *nf = S->nfreq;
+    uint32_t *heap = S->heap; uint16_t *order = S->order, *dad = S->dad;
+    const uint32_t *nf = freq;              /* leaves only (n <= max_code) */
     int heap_max = QZK_HEAP, n, m, node;
 
     while (heap_len < 2) {
         node = max_code < 2 ? ++max_code : 0;
         heap[++heap_len] = (1u << 15) | (uint32_t)node;
-        nf[node] = 1; freq[node] = 1;
+        freq[node] = 1;
         (*opt)--;
         if (stype == 0) *stat -= (node < 144 ? 8 : node < 256 ? 9 : node < 280 ? 7 : 8);
         else if (stype == 1) *stat -= 5;
@@ -137,7 +138,6 @@ QZ_DEV int qzk_tree_core(qzk_huff_lds *S, uint32_t *freq, uint8_t *len, int elem
         {
             uint32_t f = (a >> 15) + (b >> 15);
             uint32_t da = (a >> 10) & 31, db = (b >> 10) & 31, d = (da >= db ? da : db) + 1;
-            nf[node] = (uint16_t)f;
             dad[n] = dad[m] = (uint16_t)node;
             heap[1] = (f << 15) | (d << 10) | (uint32_t)node;
         }

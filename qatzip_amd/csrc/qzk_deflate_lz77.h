@@ -569,7 +569,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         for (int d = 32; d >= 1; d >>= 1) part ^= qz_shfl(part, lane ^ d);
         if (n & 3u) {
             uint32_t c = 0xffffffffu;
-            for (uint32_t i = n4; i < n; i++) c = crcT->tab[0][(c ^ src[coff + i]) & 0xff] ^ (c >> 8);
+            for (uint32_t i = n4; i < n; i++) c = qzk_crc_byte(c, src[coff + i]);
             part = qzk_multmodp(qzk_x2nmodp(crcT->x2n, n & 3u, 3), part) ^ ~c;
         }
         *crc_slot = part;                   /* wave-uniform: every lane stores the same word */

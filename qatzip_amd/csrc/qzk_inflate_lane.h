@@ -138,7 +138,7 @@ typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chai
 #define QZK_TOK_SEQCAP(out_cap) ((uint64_t)(out_cap) / 3 + 2)
 
 enum { QZK_LS_HDR = 0, QZK_LS_SYM, QZK_LS_RAW, QZK_LS_DONE };
-#define QZK_LIT_RUN 4              /* literals one trip of the serial phase A may take */
+#define QZK_LIT_RUN 4              /* literals one trip of the serial phase A may take (six, with the staging widened to match, measured 1.5 % slower) */
 
 /* slow half of a symbol decode: the root entry was empty (code longer than the root) */
 QZ_DEV int qzk_ldecode_long(qzk_lbits *b, int rootbits, const uint16_t *sorted, const uint16_t *count,
@@ -314,12 +314,12 @@ QZ_DEV void qzk_tok_init(qzk_tok_out *O, uint8_t *lp, qzk_seq *sq, bool count_on
     O->l0 = O->l1 = O->l2 = O->l3 = O->l4 = 0;
     O->s0 = O->s1 = O->s2 = O->s3 = O->s4 = O->s5 = O->s6 = O->s7 = 0;
 }
-/* append k (1..4) literals packed in v, lowest byte first */
-QZ_DEV void qzk_tok_lits(qzk_tok_out *O, uint32_t v, uint32_t k)
+/* append k (1..QZK_LIT_RUN) literals packed in v, lowest byte first, nothing above them */
+QZ_DEV void qzk_tok_lits(qzk_tok_out *O, uint64_t v, uint32_t k)
 {
     if (!O->count_only) {
         const uint32_t w = O->ln >> 3, sh = 8 * (O->ln & 7);
-        const uint64_t lo = (uint64_t)v << sh, hi = sh > 32 ? (uint64_t)v >> (64 - sh) : 0;     /* bytes that spill into the next word */
+        const uint64_t lo = v << sh, hi = sh ? v >> (64 - sh) : 0;       /* bytes that spill into the next word */
         O->l0 |= w == 0 ? lo : 0;
         O->l1 |= w == 1 ? lo : w == 0 ? hi : 0;
         O->l2 |= w == 2 ? lo : w == 1 ? hi : 0;
@@ -414,27 +414,12 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
     else if (e) sym = -1;
     else if (LR) sym = qzk_ldecode_long_reg_t<QZK_LLROOT>(b, LR, T->lsorted, S->lmax);
     else sym = qzk_ldecode_long(b, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, S->lmax);
+    uint64_t lv = 0; uint32_t lk = 0;       /* literals of this trip (packed), their number */
+    bool run = false;                       /* the trip may go on with literals out of the root table */
     if (sym < 256) {
         if (sym < 0) { S->status = b->pos >= b->end && b->bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA; S->state = QZK_LS_DONE; }
         else if (S->op >= S->out_cap) { S->status = QZK_INF_EOUT; S->state = QZK_LS_DONE; }
-        else {
-            uint32_t lv = (uint32_t)sym, lk = 1;
-            if (PAIR) {
-                /* literals come in runs: take up to QZK_LIT_RUN in one trip while their codes sit in the 9-bit root table
-                 * (15 + 3 * 9 bits fit the 56 a trip starts with).  Not for the speculative decoders, whose trips must
-                 * start at every symbol boundary their neighbour may have published. */
-                bool run = true;
-                for (int extra = 0; extra < QZK_LIT_RUN - 1; extra++) {
-                    const uint32_t e2 = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
-                    run = run && e2 != 0 && (e2 >> 4) < 256 && (int)(e2 & 15) <= b->bc && S->op + lk < S->out_cap;
-                    if (run) {
-                        QZK_DROP(b, e2 & 15);
-                        lv |= (e2 >> 4) << (8 * lk); lk++;
-                    }
-                }
-            }
-            qzk_tok_lits(O, lv, lk); S->op += lk;
-        }
+        else { lv = (uint64_t)sym; lk = 1; run = PAIR; }
     } else if (sym == 256) {
         if (S->last) { S->status = QZK_INF_FINAL; S->state = QZK_LS_DONE; } else S->state = QZK_LS_HDR;
     } else {
@@ -459,8 +444,24 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
         if (!err && (uint64_t)dist > hist + S->op) err = QZK_INF_EHIST;   /* hist: bytes before the segment a match may reach */
         if (!err && S->op + len > S->out_cap) err = QZK_INF_EOUT;
         if (err) { S->status = err; S->state = QZK_LS_DONE; }
-        else { qzk_tok_seq(O, len, dist - 1); S->op += len; }
+        else { qzk_tok_seq(O, len, dist - 1); S->op += len; run = PAIR; }
     }
+    if (PAIR) {
+        /* literals come in runs, and a match is usually followed by some: the trip goes on for up to QZK_LIT_RUN literals
+         * in all (three after a match) while their codes sit in the 9-bit root table and the bits the trip started with
+         * last (56; every step checks what is left).  Literal-heavy segments are phase A's critical path: the least
+         * compressible segments have the most symbols, and a lane decodes its segment alone.  Not for the speculative
+         * decoders, whose trips must start at every symbol boundary their neighbour may have published. */
+        for (int extra = 0; extra < QZK_LIT_RUN - 1; extra++) {
+            const uint32_t e2 = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
+            run = run && e2 != 0 && (e2 >> 4) < 256 && (int)(e2 & 15) <= b->bc && S->op + lk < S->out_cap;
+            if (run) {
+                QZK_DROP(b, e2 & 15);
+                lv |= (uint64_t)(e2 >> 4) << (8 * lk); lk++;
+            }
+        }
+    }
+    if (lk) { qzk_tok_lits(O, lv, lk); S->op += lk; }
 }
 
 /* LPW = segments (active lanes) per single-wave workgroup: LPW * 1.25 KiB of LDS (16 -> eight workgroups per CU) */
