@@ -2,18 +2,16 @@
  * qzd_device.hip — host side of the device-resident C ABI (include/qzamd_device.h)
  * and the small utility kernels (size scan, slot gather).  gfx950 only.
  *
- * A call is cut into batches of qzd_ctx::batch_chunks chunks (three rounds over the resident K1 workgroups).
- * Per batch, on one of two streams:
- *   K1 qzk_lz77_pull_kernel  (persistent 16-wave workgroups, one per CU, every wave pulling chunks; the waves of a
- *                             workgroup share the lines of one epoch-tagged candidate table)
- *   K2 qzk_huff_kernel       (one wave per chunk) -> per-chunk slot + length;  qzk_crc_chunks_kernel -> crc32
+ * Level 1, input already in HBM: ONE launch of qzk_lz77_pull_kernel over all chunks of the call (persistent 16-wave
+ * workgroups, one per CU, every wave pulling chunk numbers; the waves of a workgroup share the lines of one epoch-tagged
+ * candidate table).  The wave that parsed a chunk (K1) also codes it (K2, qzk_huff_chunk) into the chunk's slot and folds
+ * its CRC-32 along the input reads; then
  *   scan of the lengths (running total carried in HBM, no host round trip)
- *   gather of the slots into the contiguous destination
- * Scratch (symbols, slots) is double-buffered and batches alternate between the streams: K1 of batch b+1 (which
- * needs K1 of batch b to be done - they share the tables) overlaps K2/crc/scan/gather of batch b.
- * Variants of the same pipeline: input still on the host (copied in batch by batch on a third stream,
- * qzd_deflate_raw_from_host), many small requests in one launch (per-slot lengths, qzd_deflate_slots), and
- * comp_lvl 2-9 (K1b qzk_lz77_lane_kernel in place of K1, one batch).
+ *   gather of the slots into the contiguous destination.
+ * Input still on the host (qzd_deflate_raw_from_host): batches of qzd_ctx::batch_chunks chunks alternating over two
+ * streams, batch k+1's copy (third stream) beside batch k's kernels.  Many small requests in one launch: per-slot lengths
+ * (qzd_deflate_slots).  comp_lvl 2-9: K1b qzk_lz77_lane_kernel / the lazy kernels in place of K1, then qzk_huff_kernel and
+ * qzk_crc_chunks_kernel as launches of their own (also level 1 with QATZIP_AMD_FUSE=0, round 1's pipeline).
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -1,23 +1,18 @@
 /*
- * qzk_deflate_huff.h — K2: zlib-exact block coding (trees.c behaviour) of the
- * symbol stream K1 produced, ONE WAVE PER CHUNK (single-wave workgroups, no
- * workgroup barriers: the serial tree build of one chunk stalls only its own wave),
- * gfx950.  The workgroup CRC-32 routine (K6) also lives here; the chunk CRCs are a
- * separate launch (qzk_crc_chunks_kernel) so that this kernel's LDS stays below the
- * 16 KiB a CU has left beside twelve resident K1 workgroups.
+ * qzk_deflate_huff.h — K2: zlib-exact block coding (trees.c behaviour) of the symbol stream K1 produced, ONE WAVE PER
+ * CHUNK and no workgroup barriers (qzk_huff_chunk), gfx950 - and the kernels that run it: qzk_lz77_pull_kernel at the
+ * end of this file (level 1: the wave that parsed a chunk codes it too, in the same LDS) and qzk_huff_kernel (a launch
+ * of its own behind the parse kernels of comp_lvl 2-9).  The workgroup CRC-32 routine (K6) also lives here.
  *
- * Replaces, on the reference's software path, the _tr_flush_block() half of
- * zlib's deflate() (src/qatzip_sw.c:197) and the running crc32 zlib keeps for
- * the gzip trailer; CPU restatement: oracle/qzo_deflate.c (flush_block & co).
+ * Replaces, on the reference's software path, the _tr_flush_block() half of zlib's deflate() (src/qatzip_sw.c:197) and
+ * the running crc32 zlib keeps for the gzip trailer; CPU restatement: oracle/qzo_deflate.c (flush_block & co).
  *
- * Per block (<= 32767 symbols): parallel histogram (LDS atomics) -> lane 0
- * builds the three Huffman trees with zlib's exact heap order / tie-break /
- * overflow repair, RLE-codes the code lengths, and picks stored / fixed /
- * dynamic with zlib's byte-count rule -> 64 lanes at a time turn symbols into bit
- * strings, a wave prefix-sum gives every symbol its bit offset, and the bits are
- * OR-ed into an LDS staging tile that is flushed as whole bytes.
- * The chunk ends with the Z_FULL_FLUSH marker (000 + pad + 00 00 FF FF) or,
- * for the last chunk of a stream, BFINAL + byte padding.
+ * Per block (<= 32767 symbols): parallel histogram (LDS atomics) -> the three Huffman trees with zlib's exact heap
+ * order / tie-break / overflow repair (the heap on lane 0, the loops around it on the wave), the code lengths RLE-coded,
+ * stored / fixed / dynamic by zlib's byte-count rule -> 64 lanes at a time turn symbols into bit strings, a wave
+ * prefix-sum gives every symbol its bit offset, and the bits are OR-ed into an LDS staging tile that is flushed as whole
+ * bytes.  The chunk ends with the Z_FULL_FLUSH marker (000 + pad + 00 00 FF FF) or, for the last chunk of a stream,
+ * BFINAL + byte padding.
  */
 #ifndef QZK_DEFLATE_HUFF_H
 #define QZK_DEFLATE_HUFF_H

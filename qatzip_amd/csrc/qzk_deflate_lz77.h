@@ -1,6 +1,7 @@
 /*
- * qzk_deflate_lz77.h — K1: zlib-exact greedy LZ77 parse ("deflate_fast", level 1)
- * of one hw_buff_sz chunk per single-wave workgroup, gfx950.
+ * qzk_deflate_lz77.h — K1: zlib-exact greedy LZ77 parse ("deflate_fast", level 1) of one hw_buff_sz chunk per WAVE
+ * (qzk_lz77_chunk), gfx950.  The kernel that runs it - persistent sixteen-wave workgroups whose waves pull chunks, parse
+ * them, code them (K2) and fold their CRC-32 - is qzk_lz77_pull_kernel in qzk_deflate_huff.h.
  *
  * What it replaces: the deflate() hot loop the reference's software path spends
  * ~75 % of its time in (src/qatzip_sw.c:197, zlib deflate_fast + longest_match;
@@ -24,9 +25,10 @@
  *     bucket h of wave w+1 - so the buckets every chunk of a corpus keeps hitting (its
  *     common trigrams) are a few thousand fully used lines that stay in L2, instead of
  *     sixteen times as many lines with one live entry each.
- *   - LDS (8 KiB) holds a 4 KiB ring of the most recent input, from which the lanes'
- *     own bytes and three quarters of the candidates are compared, and the per-window
- *     slot tables; far candidates are gathered from HBM/L2.
+ *   - LDS (8 KiB per wave) holds a 4 KiB ring of the input - the last ~3.7 KiB and 328 bytes ahead of the window -
+ *     from which the lanes' own bytes, three quarters of the candidates and the extension of long matches are
+ *     compared, and the per-window slot tables; far candidates are gathered from HBM/L2.  The chunk's CRC-32 is
+ *     folded from the same dwords as they enter the ring.
  *   - zlib's window slide (strstart >= 65274 => rebase by 32768, NIL==0) is
  *     reproduced literally, so chunks up to 512 KiB and odd tail sizes match.
  */
