@@ -42,7 +42,18 @@ QZ_DEV uint32_t qzk_wave_xxh32(const uint8_t *p, uint32_t n, int lane)
     if (n >= 16) {
         uint32_t v = lane == 0 ? QZK_XP1 + QZK_XP2 : lane == 1 ? QZK_XP2 : lane == 2 ? 0u : 0u - QZK_XP1;
         const uint32_t stripes = n >> 4;
-        if (lane < 4) for (uint32_t s = 0; s < stripes; s++) v = qzk_rotl(v + qz_ld32(p + 16 * s + 4 * lane) * QZK_XP2, 13) * QZK_XP1;
+        if (lane < 4) {
+            /* the accumulator chain is serial, the loads are not: eight stripes' words are asked for before the first is used */
+            uint32_t s = 0;
+            for (; s + 8 <= stripes; s += 8) {
+                uint32_t w[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) w[k] = qz_ld32(p + 16 * (s + (uint32_t)k) + 4 * lane);
+#pragma unroll
+                for (int k = 0; k < 8; k++) v = qzk_rotl(v + w[k] * QZK_XP2, 13) * QZK_XP1;
+            }
+            for (; s < stripes; s++) v = qzk_rotl(v + qz_ld32(p + 16 * s + 4 * lane) * QZK_XP2, 13) * QZK_XP1;
+        }
         uint32_t v0 = qz_readlane(v, 0), v1 = qz_readlane(v, 1), v2 = qz_readlane(v, 2), v3 = qz_readlane(v, 3);
         h = qzk_rotl(v0, 1) + qzk_rotl(v1, 7) + qzk_rotl(v2, 12) + qzk_rotl(v3, 18);
         pos = stripes << 4;
@@ -89,12 +100,13 @@ QZ_DEV uint32_t qzk_lz4_hash5(const uint8_t *p)
 }
 
 /* LZ4 block compress of in[bs..bs+n) into out (capacity cap); returns size or 0 when it does not fit.
- * LINKED = false: an independent block (bs = 0; LZ4_compress_fast, 13-bit hash of 4 bytes; table: QZK_LZ4_HASHSZ u32
+ * LINKED = false: an independent block (bs = 0; LZ4_compress_fast, 13-bit hash of 4 bytes; table: QZK_LZ4_HASHSZ u16 -
+ * positions of a 64 KB block, lz4's own byU16 - so that eight of these waves fit a CU's LDS instead of four;
  * in LDS, zeroed here).  LINKED = true: one block of a linked frame that starts at in[0] (LZ4_compress_fast_continue:
  * the frame's table - 4096 u32, 12-bit hash of 5 bytes - comes in and goes out with everything earlier blocks and this
  * one inserted, also when this block does not fit; candidates up to 65535 bytes back, across block borders). */
-template <bool LINKED>
-QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint8_t *out, uint32_t cap, uint32_t *table,
+template <bool LINKED, typename TAB>
+QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint8_t *out, uint32_t cap, TAB *table,
                                 uint32_t *slot, int lane)
 {
 #define QZK_LZ4H(pos, v4) (LINKED ? qzk_lz4_hash5(in + (pos)) : QZK_LZ4HASH(v4))
@@ -109,7 +121,7 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
     if (n >= QZK_LZ4_MFLIMIT + 1) {
         /* first byte: the block's first position goes into the table unsearched (an independent block's is 0 - already
          * there), the search starts behind it */
-        if (LINKED) { if (lane == 0) table[qzk_lz4_hash5(in + bs)] = bs; qz_wave_sync(); }
+        if (LINKED) { if (lane == 0) table[qzk_lz4_hash5(in + bs)] = (TAB)bs; qz_wave_sync(); }
         ip = bs + 1;
         for (;;) {
             /* ---------------- search streak from ip ---------------- */
@@ -153,8 +165,26 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                 const bool got = fl < first_dead && (fl < bound || (HIT && bound < 64 && fl == bound));
                 /* insert every probed position up to and including the hit (or the whole window) */
                 const int last_ins = got ? fl : (first_dead < 64 ? first_dead - 1 : 63);
-                if (live && lane <= last_ins) atomicMax(&table[h], f);
-                qz_wave_sync();
+                if (sizeof(TAB) == 4) {
+                    if (live && lane <= last_ins) atomicMax((uint32_t *)&table[h], f);
+                    qz_wave_sync();
+                } else {
+                    /* 16-bit entries have no LDS atomic: the last probe of a hash is elected through the slot table - per
+                     * key the highest (rest of the hash, lane) wins, its hash is served, the other hashes on that key go
+                     * round again (eight hashes share a key, two of them in one window is already rare) */
+                    bool pend = live && lane <= last_ins;
+                    const uint32_t val = (((h >> 10) << 6) | (uint32_t)lane) + 1;
+                    while (qz_ballot(pend)) {
+                        if (pend) slot[key] = 0;
+                        qz_wave_sync();
+                        if (pend) atomicMax(&slot[key], val);
+                        qz_wave_sync();
+                        const uint32_t w = pend ? slot[key] : 0;
+                        if (pend && w == val) table[h] = (TAB)f;
+                        if (pend && ((w - 1) >> 6) == (h >> 10)) pend = false;      /* my hash was the one served */
+                        qz_wave_sync();
+                    }
+                }
                 if (got) { found = true; mpos = qz_readlane(f, fl); mcand = fcand; break; }
                 if (first_dead < 64) break;                          /* ran into the end: last literals */
                 j0 += 64;
@@ -203,11 +233,11 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                 /* fill table with ip-2, then test the next position right away */
                 uint32_t v2 = qz_ld32(in + mip - 2), v0 = qz_ld32(in + mip);
                 uint32_t h2 = QZK_LZ4H(mip - 2, v2), h0 = QZK_LZ4H(mip, v0);
-                if (lane == 0) table[h2] = mip - 2;
+                if (lane == 0) table[h2] = (TAB)(mip - 2);
                 qz_wave_sync();
                 uint32_t mi = table[h0];
                 qz_wave_sync();
-                if (lane == 0) table[h0] = mip;
+                if (lane == 0) table[h0] = (TAB)mip;
                 qz_wave_sync();
                 if (QZK_LZ4NEAR(mi, mip) && qz_ld32(in + mi) == v0) { token_at = op++; tok = 0; match = mi; continue; }
                 break;
@@ -234,15 +264,15 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
 #undef QZK_LZ4H
 #undef QZK_LZ4NEAR
 }
-QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap, uint32_t *table, uint32_t *slot, int lane)
-{ return qzk_lz4_block_t<false>(in, 0, n, out, cap, table, slot, lane); }
+QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap, uint16_t *table, uint32_t *slot, int lane)
+{ return qzk_lz4_block_t<false, uint16_t>(in, 0, n, out, cap, table, slot, lane); }
 
 /* K4: one LZ4 frame (<= 64 KB of content, one independent block) per wave, written to its slot:
  * LZ4F_compressFrame with {contentChecksum, contentSize, autoFlush, level < 3}. */
-QZ_KERNEL qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
+QZ_KERNEL_MAX(64) qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
                           uint8_t *slots, uint32_t stride, uint32_t *out_len)
 {
-    QZ_LDS uint32_t table[QZK_LZ4_HASHSZ];
+    QZ_LDS uint16_t table[QZK_LZ4_HASHSZ];
     QZ_LDS uint32_t slot[1024];
     const int lane = qz_lane();
     const uint32_t fr = blockIdx.x;
@@ -308,7 +338,7 @@ QZ_KERNEL_MAX(64) qzk_lz4c_linked_kernel(const uint8_t *src, uint32_t n, uint8_t
     }
     for (uint32_t bs = 0; bs < n; bs += QZK_LZ4_MAXBLK) {
         const uint32_t bn = n - bs < QZK_LZ4_MAXBLK ? n - bs : QZK_LZ4_MAXBLK;
-        uint32_t c = qzk_lz4_block_t<true>(src, bs, bn, out + pos + 4, bn - 1, table, slot, lane);
+        uint32_t c = qzk_lz4_block_t<true, uint32_t>(src, bs, bn, out + pos + 4, bn - 1, table, slot, lane);
         const uint32_t bh = c ? c : (bn | 0x80000000u);
         if (c == 0) { qz_wave_sync(); qzk_wave_copy(out + pos + 4, src + bs, bn, lane); c = bn; }
         if (lane == 0) { out[pos] = (uint8_t)bh; out[pos + 1] = (uint8_t)(bh >> 8); out[pos + 2] = (uint8_t)(bh >> 16); out[pos + 3] = (uint8_t)(bh >> 24); }

@@ -314,3 +314,25 @@ def test_lz4_linked_frames_match_liblz4_goldens(sim):
         out = C.create_string_buffer(n + n // 255 + 4096); ol = C.c_uint32(0)
         sim.sim_lz4c_linked(src, n, out, C.byref(ol))
         assert out.raw[:ol.value] == exp, (kind, n, seed, ol.value, len(exp))
+
+
+def test_lz4_frames_match_oracle(sim):
+    """K4: one frame per call of at most 64 KB (LZ4F_compressFrame with one independent block, src/qatzip_sw.c:443-471):
+    the kernel's 16-bit hash table and its elected last writer against the oracle, every kind, sizes around the limits of
+    lz4's loop (MFLIMIT, 64 KB) and incompressible input (stored block)"""
+    sim.sim_lz4c.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    for kind in datagen.KINDS:
+        for n, fs in ((0, 65536), (1, 65536), (12, 65536), (13, 65536), (14, 65536), (300, 65536), (65535, 65536), (65536, 65536),
+                      (200000, 65536), (70000, 16384), (9000, 1024)):
+            if kind == "lzmix" and n > 70000:
+                n = 66000
+            src = datagen.gen_bytes(kind, n, 41)
+            nfr = max(1, (n + fs - 1) // fs)
+            stride = (fs + 15 + 4 + 8 + 64 + 15) & ~15
+            slots = np.zeros(nfr * stride, np.uint8); lens = np.zeros(nfr, np.uint32)
+            sim.sim_lz4c(src, n, fs, slots.ctypes.data, stride, lens.ctypes.data)
+            for i in range(nfr):
+                piece = src[i * fs:(i + 1) * fs]
+                exp = O.sw_compress("LZ4", piece, 65536, 1, cap=len(piece) + len(piece) // 255 + 200)[2]
+                got = bytes(slots[i * stride:i * stride + int(lens[i])])
+                assert got == exp, (kind, n, fs, i, int(lens[i]), len(exp))
