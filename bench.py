@@ -261,6 +261,55 @@ def lz4_leg(ctx, qz, d_src, mb):
             "ratio": round(cl / n, 4), "note": "64 KB frames, XXH32 content checksum made and verified in-kernel, host call to host return"}
 
 
+def sessions_leg(qz, dev, d_src, call_n, d_comp, steps):
+    """The same job driven the way the reference's harness drives a device (test/main.c:2175-2202, `-t`): one session per
+    host thread, started together.  Thread i owns call i of the buffer: compress it, decompress it, `steps` times.  Not the
+    headline (that is one session, one call after the other); it shows what the device does when calls overlap - a call's
+    phase A is one latency chain per segment and leaves the chip half empty, a second session's kernels fill it."""
+    import threading
+    ctxs = [qz.Context(dev) for _ in call_n]
+    backs = [c.alloc(n) for c, n in zip(ctxs, call_n)]
+    err = []
+    bar = threading.Barrier(len(call_n) + 1)
+
+    def body(i):
+        c, n = ctxs[i], call_n[i]
+        try:
+            src = view(qz, d_src, i * CALL_BYTES, n)
+            for it in range(steps + 1):                 # pass 0 warms this context up (scratch, tables)
+                if it == 1:
+                    bar.wait(); bar.wait()
+                c.deflate_raw_async(src, n, CHUNK, 1, 1, d_comp[i]); c.sync()
+                cl = c.result()
+                iu, ol, _ = c.inflate_stream(d_comp[i], cl, backs[i], CHUNK, want_crc=True)
+                assert iu == cl and ol == n
+        except Exception as e:   # noqa: BLE001
+            err.append(repr(e))
+            try:
+                bar.abort()
+            except Exception:   # noqa: BLE001
+                pass
+
+    th = [threading.Thread(target=body, args=(i,)) for i in range(len(call_n))]
+    for t in th:
+        t.start()
+    try:
+        bar.wait()                                      # everybody warmed up
+        t0 = time.perf_counter()
+        bar.wait()
+    except threading.BrokenBarrierError:
+        pass
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0 if not err else 0.0
+    for b in backs:
+        b.free()
+    if err or dt <= 0:
+        return {"error": "; ".join(err)[:200]}
+    return {"sessions": len(call_n), "GBps": round(2.0 * sum(call_n) * steps / dt / 1e9, 3), "steps": steps,
+            "note": "one host thread and one session per 2 GiB call, started together; compress + decompress, uncompressed bytes both ways"}
+
+
 def view(qz, buf, off, n):
     v = qz.DevBuf.__new__(qz.DevBuf)
     v.ctx, v.nbytes, v.ptr = buf.ctx, n, buf.ptr + off
@@ -373,6 +422,12 @@ def main():
             barrier(pg)
         elif rank == 0:
             emb = min(args.extra_mb, args.mb)
+            if ncalls > 1:
+                try:
+                    extra["concurrent_sessions"] = sessions_leg(qatzip_amd, int(os.environ.get("QATZIP_AMD_BENCH_DEVICE", local)),
+                                                                d_src, call_n, d_comp, args.steps)
+                except Exception as e:   # noqa: BLE001 - an extra leg must not cost the headline
+                    extra["concurrent_sessions"] = {"error": str(e)[:200]}
             for d in d_comp:
                 d.free()
             d_back.free()
