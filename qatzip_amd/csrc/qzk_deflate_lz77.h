@@ -57,7 +57,10 @@
 #define QZK_K1_OCC 1               /* workgroups per CU the register budget is cut for */
 #endif
 #define QZK_RINGW (QZK_RING / 4)
-#define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW)   /* words of LDS one wave's parse needs */
+#ifndef QZK_NSLOT2
+#define QZK_NSLOT2 256              /* second slot table, keyed by the hash's high bits */
+#endif
+#define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW + QZK_NSLOT2)   /* words of LDS one wave's parse needs */
 #ifndef QZK_K1_WAVES
 #define QZK_K1_WAVES 16            /* waves per K1 workgroup, one chunk each; they share the lines of the candidate table */
 #endif
@@ -170,10 +173,12 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     /* this wave's QZK_K1_LDSW words of LDS:
      *   slot[QZK_NSLOT]  per-window: min(lane<<16 | hash) over the lanes on a hash key
      *   scnt[QZK_NSLOT]  per-window: number of lanes on the key
+     *   slot2[QZK_NSLOT2] per-window: lowest lane on the hash's HIGH bits - a lane that has an earlier lane with its hash
+     *     has one on both keys; half of the lanes the first table alone sent to the exact path had none
      *   ring[QZK_RINGW]  the last QZK_RING bytes of input (and ~100 ahead of the parse point).  Every candidate compare
      *     drags a 128-byte line through L2 for 16 bytes, three quarters of them less than 4 KiB back; with a dozen
      *     waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
-    uint32_t *const slot = lds, *const scnt = lds + QZK_NSLOT, *const ring = lds + 2 * QZK_NSLOT;
+    uint32_t *const slot = lds, *const scnt = lds + QZK_NSLOT, *const ring = lds + 2 * QZK_NSLOT, *const slot2 = ring + QZK_RINGW;
     uint32_t rhi = 0;                      /* chunk offset the ring is filled up to (multiple of 256) */
     uint32_t crc_acc = 0;                  /* this lane's share of the chunk's CRC-32 (crcT != NULL) */
     uint32_t rnext = qzk_ld32g_fast(src, (uint64_t)chunk * chunk_sz + 4 * (uint32_t)qz_lane(), src_len);   /* my dword of the row at rhi */
@@ -329,13 +334,14 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
              * slot[key] <- min(lane<<16 | hash), cnt[key] <- number of lanes on the key.  A lane is clean when it is
              * the lowest lane of its key, or when the key holds exactly two lanes and the other one has a different
              * hash; everything else takes the exact path. */
-            if (canh) { slot[key] = 0xffffffffu; scnt[key] = 0; }
+            const uint32_t key2 = (h >> (16 - 8)) & (QZK_NSLOT2 - 1);
+            if (canh) { slot[key] = 0xffffffffu; scnt[key] = 0; slot2[key2] = 0xffffffffu; }
             qz_lds_sync();
-            if (canh) { atomicMin(&slot[key], ((uint32_t)lane << 16) | h); atomicAdd(&scnt[key], 1u); }
+            if (canh) { atomicMin(&slot[key], ((uint32_t)lane << 16) | h); atomicAdd(&scnt[key], 1u); atomicMin(&slot2[key2], (uint32_t)lane); }
             qz_lds_sync();
             {
-                const uint32_t sv = canh ? slot[key] : 0, sc = canh ? scnt[key] : 0;
-                suspect = canh && (sv >> 16) != (uint32_t)lane && !(sc == 2 && (sv & 0xffff) != h);
+                const uint32_t sv = canh ? slot[key] : 0, sc = canh ? scnt[key] : 0, s2 = canh ? slot2[key2] : 0;
+                suspect = canh && (sv >> 16) != (uint32_t)lane && !(sc == 2 && (sv & 0xffff) != h) && s2 != (uint32_t)lane;
             }
             bool done = false;
             for (int k = 0; k < 4; k++) {
@@ -414,6 +420,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                  * the speculative answer is already exact */
                 const uint64_t earlier = qz_ballot(canh && h == h_l) & qz_below(l);
                 if (earlier == 0 && !((CAPM >> l) & 1)) {
+                    QZK_C(15, 1);
                     Pm |= 1ull << l;
                     uint32_t ml = qz_readlane(mlen, l);
                     l += ml ? (int)ml : 1;

@@ -114,3 +114,29 @@ def test_k1_residency_variants_are_bit_exact(monkeypatch, mix):
             assert got == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2], (mix, kind, n, chunk)
     finally:
         c.close()
+
+
+def test_separate_k2_and_crc_launches_are_bit_exact_too():
+    """QATZIP_AMD_FUSE=0: round 1's pipeline (K2 and the chunk CRCs as launches of their own beside the next batch's K1,
+    symbols per chunk of a batch) stays available for comparison - the switch is read once per process, so a fresh one"""
+    import os, subprocess, sys
+    code = r'''
+import sys, zlib
+sys.path.insert(0, "tests")
+import datagen, oracle_lib as O, qatzip_amd
+c = qatzip_amd.Context(0)
+for kind, n, chunk in (("silesia", 3 << 20, 65536), ("text", 300000, 16384), ("rand", 70000, 65536), ("runs", 0, 65536)):
+    src = datagen.gen_bytes(kind, n, 11)
+    d_src = c.alloc(max(n, 1) + 512); d_dst = c.alloc(qatzip_amd.max_deflate_len(n, chunk))
+    d_src.upload(src)
+    ol, crcs = c.deflate_raw(d_src, n, chunk, 1, 1, d_dst)
+    got = d_dst.download(ol)
+    assert bytes(got) == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2], (kind, n, chunk)
+    for i, v in enumerate(crcs):
+        assert int(v) == (zlib.crc32(src[i * chunk:(i + 1) * chunk]) & 0xffffffff)
+print("ok")
+'''
+    env = dict(os.environ, QATZIP_AMD_FUSE="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

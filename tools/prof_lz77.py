@@ -58,6 +58,8 @@ def main():
         print("  %-16s %12.0f ticks/chunk  %5.1f %%  %8.1f /window" % (names[k], tot[k], 100 * tot[k] / cyc, tot[k] / tot[8]))
     print("  windows/chunk %.0f  complex lanes/window %.2f  suspect commits/window %.2f  symbols/window %.1f"
           % (tot[8], tot[9] / tot[8], tot[10] / tot[8], tot[11] / tot[8]))
+    print("  exact path: %.2f lanes/window, of which %.2f leave at the first test (no earlier lane with the hash, nothing to extend)"
+          % (tot[9] / tot[8], tot[15] / tot[8]))
     print("  K2 in the wave: %.0f ticks/chunk (%.1f %% on top of the parse), of which the serial tree build %.0f"
           % (tot[13], 100 * tot[13] / cyc, tot[14]))
     per = prof[:, [0, 1, 2, 3, 4, 5, 6, 7, 12]].sum(1)
