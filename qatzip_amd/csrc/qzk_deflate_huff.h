@@ -545,11 +545,11 @@ QZ_DEV void qzk_huff_chunk(qzk_huff_lds *Sp, const int lane, const uint8_t *in, 
         /* zlib's trees: the heap is one lane following a chain of LDS round trips while the CU's other waves parse, the
          * loops around it run on the wave.  At raised priority its instructions go out as soon as their operands are there
          * instead of waiting for a turn among the other waves of the SIMD */
-#if !defined(QZ_SIM) && !defined(QZK_NO_SETPRIO)
+#ifndef QZ_SIM
         __builtin_amdgcn_s_setprio(3);
 #endif
         qzk_plan_block(&S, be - bs, (cs >> b) & 1, lane);
-#if !defined(QZ_SIM) && !defined(QZK_NO_SETPRIO)
+#ifndef QZ_SIM
         __builtin_amdgcn_s_setprio(0);
 #endif
 #if defined(QZK_PROF) && !defined(QZ_SIM)

@@ -79,7 +79,7 @@ typedef uint32_t qzk_u32x4 __attribute__((vector_size(16)));
  * single home of the line within the XCD, and a wave's loads follow its own stores to it in issue order. */
 QZ_DEV qzk_u32x4 qzk_ld_bkt(const qzk_bkt *p)
 {
-#if defined(QZ_SIM) || defined(QZK_PLAIN_LD)
+#ifdef QZ_SIM
     return *(const qzk_u32x4 *)p;
 #else
     qzk_u32x4 v;
@@ -293,11 +293,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         /* the previous window's table stores are ahead of this gather in the wave's memory stream (same wave, same CU) */
         qz_lds_sync();
         qzk_u32x4 ev = {0, 0, 0, 0};
-#ifdef QZK_DIAG_NOGATHER      /* timing diagnostics only (wrong output): every lane reads one hot entry */
-        if (canh) ev = qzk_ld_bkt(&tab[(size_t)(bucket & 63) * QZK_K1_WAVES]);
-#else
         if (canh) ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_WAVES]);
-#endif
         const bool ev_ok = ev[3] == epoch;                /* another chunk's entry: as good as empty */
         const uint32_t q0 = ev_ok ? ev[0] & 0xffffffu : 0, q1 = ev_ok ? (ev[0] >> 24) | ((ev[1] & 0xffffu) << 8) : 0,
                        q2 = ev_ok ? (ev[1] >> 16) | ((ev[2] & 0xffu) << 16) : 0, q3 = ev_ok ? ev[2] >> 8 : 0;   /* chunk offsets, 0 = none */
@@ -552,11 +548,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         }
         if (store) {
             const qzk_u32x4 e = {n0 | (n1 << 24), (n1 >> 8) | (n2 << 16), (n2 >> 16) | (n3 << 8), epoch};
-#ifdef QZK_DIAG_NOSCATTER
-            *(qzk_u32x4 *)&tab[(size_t)(bucket & 63) * QZK_K1_WAVES] = e;
-#else
             *(qzk_u32x4 *)&tab[(size_t)bucket * QZK_K1_WAVES] = e;
-#endif
         }
         pos += (uint32_t)l;
         QZK_T(12);

@@ -507,25 +507,11 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
              * that lanes parked in a cold state get their turn. ---- */
             b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;     /* hand whole bytes back */
             uint64_t pw = qzk_ld64u(b->p + b->pos);
-#if !defined(QZ_SIM) && defined(QZK_PREFETCH)
-            uint32_t pf1 = 0, pf2 = 0;                  /* lines requested one / two trips ago */
-#endif
             for (int round = 0; round < 32 && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; round++) {
                 for (int trip = 0; trip < QZK_TOK_ROUND && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
                     b->bb |= pw << b->bc;
                     b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
                     pw = qzk_ld64u(b->p + b->pos);
-#if !defined(QZ_SIM) && defined(QZK_PREFETCH)
-                    {
-                        /* experiment (measured on MI355X, no gain: the compiler waits with vmcnt(0) at the loop head, so
-                         * the request is not left in flight - DESIGN.md section 7): every lane also asks for the line three
-                         * ahead of its read position and claims the value two trips later */
-                        const uint32_t ahead = b->pos + 192 < b->end - 8 ? b->pos + 192 : b->end - 8;
-                        const uint32_t pf0 = qz_ld32(b->p + (ahead & ~63u));
-                        asm volatile("" :: "v"(pf2));
-                        pf2 = pf1; pf1 = pf0;
-                    }
-#endif
                     qzk_lane_symbol<false, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0, LR, DR);
 #ifdef QZK_INF_PROF
                     prof_trips++;
@@ -606,27 +592,15 @@ QZ_DEV uint32_t qzk_wave_scan_incl(uint32_t v, int lane)
     return v;
 }
 
-/* Phase B reads back bytes its own wave stored a moment ago (a match's source is earlier output).  With the plain
- * variant the stores are made visible by a workgroup-scope fence (s_waitcnt vmcnt(0): the wave waits for its stores to
- * reach the L2 at every dependency step); QZK_RES_L2 serves those loads from the L2 instead (non-temporal loads bypass
- * the CU's vector L1, the only place a stale copy could sit; a wave's requests reach an L2 channel in issue order), so
- * a wave-local fence is enough and nothing waits. */
-#if defined(QZK_RES_L2) && !defined(QZ_SIM)
-typedef uint64_t qz_u64ntu __attribute__((aligned(1)));
-typedef uint32_t qz_u32ntu __attribute__((aligned(1)));
-typedef uint16_t qz_u16ntu __attribute__((aligned(1)));
-#define QZK_RLD64(p) __builtin_nontemporal_load((const qz_u64ntu *)(p))
-#define QZK_RLD32(p) __builtin_nontemporal_load((const qz_u32ntu *)(p))
-#define QZK_RLD16(p) __builtin_nontemporal_load((const qz_u16ntu *)(p))
-#define QZK_RLD8(p) __builtin_nontemporal_load((const uint8_t *)(p))
-#define QZK_RSYNC() qz_lds_sync()
-#else
+/* Phase B reads back bytes its own wave stored a moment ago (a match's source is earlier output): the stores are made
+ * visible by a workgroup-scope fence (s_waitcnt vmcnt(0): the wave waits for its stores to reach the L2 at every
+ * dependency step).  Serving those loads from the L2 instead (non-temporal loads, wave-local fence, nothing waits) was
+ * measured slower: every one of them then misses the L1. */
 #define QZK_RLD64(p) qzk_ld64u(p)
 #define QZK_RLD32(p) qz_ld32(p)
 #define QZK_RLD16(p) qz_ld16(p)
 #define QZK_RLD8(p) (*(const uint8_t *)(p))
 #define QZK_RSYNC() qz_wave_sync()
-#endif
 
 /* copy one match inside the output: len bytes from d - dist to d (the classic overlapping LZ77 copy) */
 QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
