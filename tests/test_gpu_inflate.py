@@ -139,3 +139,36 @@ def test_speculative_phase_a_is_bit_exact(ctx, monkeypatch, k):
     comp = co.compress(src) + co.flush()
     iu, out, crc = _inflate(ctx, comp, len(src))
     assert out == src
+
+
+def test_two_sessions_on_one_gpu_at_once():
+    """Two contexts driven by two host threads at the same time (the reference's harness shape, test/main.c:2175-2202;
+    bench.py's concurrent_sessions leg): the compress side shares the device's tables and scratch under a lock, the decode
+    side has per-context scratch - both threads must get their own bytes back."""
+    import threading
+    import qatzip_amd
+    errs = []
+
+    def body(seed):
+        try:
+            c = qatzip_amd.Context(0)
+            for rep in range(3):
+                n, chunk = (5 << 20) + 12345 * seed + rep, 65536
+                src = datagen.gen_bytes("silesia" if seed & 1 else "text", n, 100 + seed + rep)
+                d_src = c.alloc(n); d_src.upload(src)
+                d_comp = c.alloc(qatzip_amd.max_deflate_len(n, chunk)); d_back = c.alloc(n)
+                cl, _ = c.deflate_raw(d_src, n, chunk, 1, 1, d_comp)
+                assert d_comp.download(cl).tobytes() == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2]
+                iu, ol, crc = c.inflate_stream(d_comp, cl, d_back, chunk, want_crc=True)
+                assert iu == cl and ol == n and d_back.download(n).tobytes() == src
+                d_src.free(); d_comp.free(); d_back.free()
+            c.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=body, args=(s,)) for s in (1, 2, 3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
