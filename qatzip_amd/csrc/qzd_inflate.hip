@@ -62,11 +62,20 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
                      qzk_infres *h_res, uint32_t K, hipStream_t st, bool run_b = true)
 {
     const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
-    int rc = qzd_aux_reserve(c, sb + rb + 64);
+    /* everything that crosses PCIe here goes through the pinned mirror of the aux scratch (a copy from or to pageable
+     * memory is staged by the runtime in pieces, each with its own wait: a quarter of a millisecond per megabyte, four
+     * times per call, between two kernels) */
+    const size_t o_res = (sb + 15) & ~(size_t)15, o_ts = o_res + ((rb + 15) & ~(size_t)15);
+    const size_t o_ord = o_ts + (((size_t)nsegs * K * sizeof(qzk_tokseg) + 15) & ~(size_t)15);
+    int rc = qzd_aux_reserve(c, o_ord + (size_t)nsegs * 4 + 64);
     if (rc) return rc;
     qzk_infseg *d_segs = (qzk_infseg *)c->d_aux;
-    qzk_infres *d_res = (qzk_infres *)(c->d_aux + ((sb + 15) & ~(size_t)15));
-    std::vector<qzk_tokseg> tsv((size_t)nsegs * K);
+    qzk_infres *d_res = (qzk_infres *)(c->d_aux + o_res);
+    qzk_infseg *st_segs = (qzk_infseg *)c->h_aux;
+    qzk_infres *st_res = (qzk_infres *)(c->h_aux + o_res);
+    qzk_tokseg *tsv = (qzk_tokseg *)(c->h_aux + o_ts);
+    uint32_t *st_ord = (uint32_t *)(c->h_aux + o_ord);
+    memcpy(st_segs, hs, sb);
     uint64_t lit_total = 0, seq_total = 0;
     for (uint32_t i = 0; i < nsegs; i++) {
         const bool writes = !(hs[i].flags & QZK_INF_COUNT_ONLY);
@@ -101,9 +110,9 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     uint8_t *lit_d = pb; pb += litb;
     qzk_seq *seq_d = (qzk_seq *)pb; pb += (seqb + 255) & ~(size_t)255;
     uint32_t *ord_d = (uint32_t *)pb;
-    if (stream_out) HIPCHK(c, hipMemcpyAsync(ord_d, c->so_nat, (size_t)nsegs * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_segs, hs, sb, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(ts_d, tsv.data(), tsv.size() * sizeof(qzk_tokseg), hipMemcpyHostToDevice, st));
+    if (stream_out) { memcpy(st_ord, c->so_nat, (size_t)nsegs * 4); HIPCHK(c, hipMemcpyAsync(ord_d, st_ord, (size_t)nsegs * 4, hipMemcpyHostToDevice, st)); }
+    HIPCHK(c, hipMemcpyAsync(d_segs, st_segs, sb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(ts_d, tsv, (size_t)nsegs * K * sizeof(qzk_tokseg), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[1][1], st));
     if (K == 1) {
         /* segments per single-wave workgroup: each lane keeps 1.25 KiB of root tables in LDS, and partly filled waves
@@ -134,9 +143,10 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     if (!run_b) {
         /* phase A only (K == 1): its results say which candidates are real segments and where their output belongs;
          * two_phase_resolve() runs phase B once the host has decided */
-        HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(st_res, d_res, rb, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         HIPCHK(c, hipGetLastError());
+        memcpy(h_res, st_res, rb);
         return QZD_OK;
     }
     if (!stream_out) {
@@ -166,9 +176,10 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         HIPCHK(c, hipStreamSynchronize(c->st[1]));
         c->so_sent = off[QZD_SO_PARTS];
     }
-    HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(st_res, d_res, rb, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
+    memcpy(h_res, st_res, rb);
     float t = 0;
     if (hipEventElapsedTime(&t, c->ev[1][0], c->ev[1][2]) == hipSuccess) c->inf_ms[2] += t;     /* phase B share */
     if (K == 1) return QZD_OK;
@@ -201,8 +212,16 @@ static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, 
 {
     if (nsegs != c->tp.nsegs || c->tp.K != 1 || count == 0) return QZD_ERR_PARAM;
     qzk_infseg *d_segs = (qzk_infseg *)c->tp.segs; qzk_infres *d_res = (qzk_infres *)c->tp.res;
-    HIPCHK(c, hipMemcpyAsync(d_segs, hs, (size_t)nsegs * sizeof(qzk_infseg), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->tp.ord, h_order, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    /* the pinned mirror, laid out as two_phase() left it (same nsegs, K == 1) */
+    const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
+    const size_t o_res = (sb + 15) & ~(size_t)15, o_ts = o_res + ((rb + 15) & ~(size_t)15);
+    const size_t o_ord = o_ts + (((size_t)nsegs * sizeof(qzk_tokseg) + 15) & ~(size_t)15);
+    if (o_ord + (size_t)nsegs * 4 > c->aux_cap) return QZD_ERR_PARAM;
+    qzk_infres *st_res = (qzk_infres *)(c->h_aux + o_res);
+    memcpy(c->h_aux, hs, sb);
+    memcpy(c->h_aux + o_ord, h_order, (size_t)count * 4);
+    HIPCHK(c, hipMemcpyAsync(d_segs, c->h_aux, sb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->tp.ord, c->h_aux + o_ord, (size_t)count * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[1][0], st));
     const uint32_t parts = h_dst && count >= QZD_LANE_MIN_SEGS ? QZD_SO_PARTS : 1u;
     uint64_t off[QZD_SO_PARTS + 1];
@@ -224,9 +243,10 @@ static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, 
         HIPCHK(c, hipStreamSynchronize(c->st[1]));
         c->so_sent = off[parts];
     }
-    HIPCHK(c, hipMemcpyAsync(h_res, d_res, (size_t)nsegs * sizeof(qzk_infres), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(st_res, d_res, rb, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
+    memcpy(h_res, st_res, rb);
     float t = 0;
     if (hipEventElapsedTime(&t, c->ev[1][0], c->ev[1][2]) == hipSuccess) c->inf_ms[2] += t;
     return QZD_OK;
@@ -510,9 +530,10 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
                 oo += r.out_len;
                 if (r.status == QZK_INF_FINAL) { total_in = (uint64_t)start[k] + r.in_used; break; }
                 const uint32_t nxt = start[k] + r.in_used;
-                auto it = std::lower_bound(start.begin() + k + 1, start.end(), nxt);
-                if (it == start.end() || *it != nxt) { ok = false; break; }
-                k = (uint32_t)(it - start.begin());
+                uint32_t j = k + 1;                                 /* the starts are sorted and nxt only grows */
+                while (j < ns && start[j] < nxt) j++;
+                if (j >= ns || start[j] != nxt) { ok = false; break; }
+                k = j;
             }
             if (ok && oo > dst_cap) return QZD_ERR_DSTCAP;
             if (ok) {
