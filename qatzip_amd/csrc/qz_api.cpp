@@ -417,6 +417,7 @@ static void write_header(unsigned char *dest, int fmt, unsigned lvl)
 }
 
 /* ------------------------------------------------------------------ compress */
+static bool pinned_span(const void *p, size_t len);
 static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
                             unsigned char *dest, unsigned int *dest_len, unsigned int last, unsigned long *crc)
 {
@@ -434,7 +435,14 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
     if (rc) return rc;
     uint64_t produced = 0;
     s->crcs.resize(nchunks); s->lens.resize(nchunks);
-    if (qzd_deflate_raw_from_host(s->ctx, src, s->d_in, n, hw, (int)s->p.comp_lvl, (int)last, s->d_out, s->out_cap, &produced, s->crcs.data()) != QZD_OK) {
+    /* A destination in qzMalloc(PINNED_MEM) memory that holds the worst case: the gather kernels write the stream
+     * straight into it - the compressed bytes of a batch cross PCIe while the next batch is parsed, instead of as one
+     * copy after the last kernel (the device can address hipHostMalloc memory; 1 GiB call: 8 ms of a 52 ms call). */
+    const unsigned fl_all = last ? ftr_len(fmt) : 0;
+    const bool direct = n >= (8u << 20) && fmt != F_ZLIB && (uint64_t)hl + worst + fl_all <= cap && pinned_span(dest + hl, cap - hl);
+    uint8_t *const dev_dst = direct ? (uint8_t *)dest + hl : s->d_out;
+    const uint64_t dev_cap = direct ? (uint64_t)cap - hl - fl_all : s->out_cap;
+    if (qzd_deflate_raw_from_host(s->ctx, src, s->d_in, n, hw, (int)s->p.comp_lvl, (int)last, dev_dst, dev_cap, &produced, s->crcs.data()) != QZD_OK) {
         logmsg(LOG_ERROR, "GPU deflate failed: %s\n", qzd_last_error(s->ctx));
         return QZ_FAIL;
     }
@@ -458,7 +466,7 @@ static int compress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src
         write_header(dest, fmt, lvl);
         s->open = true; s->run_sum = fmt == F_ZLIB ? 1u : 0u; s->st_in = 0; s->st_out = hl;
     }
-    if (bytes && qzd_d2h(s->ctx, dest + hl, s->d_out, bytes) != QZD_OK) return QZ_FAIL;
+    if (bytes && !direct && qzd_d2h(s->ctx, dest + hl, s->d_out, bytes) != QZD_OK) return QZ_FAIL;
     /* running CRC-32 of the stream (zlib's strm->adler for gzip) + the crc out-parameter of
      * src/qatzip_sw.c:217-230, including its cumulative-fold behaviour on multi-chunk calls */
     uint32_t done_in = 0;
@@ -966,6 +974,17 @@ extern "C" void qzFree(void *m)
 }
 /* 1 for ANY address inside a pinned allocation (the reference's page table marks every page of one,
  * src/qatzip_mem.c:102-149), 0 otherwise */
+/* [p, p + len) lies inside one pinned allocation of qzMalloc */
+static bool pinned_span(const void *p, size_t len)
+{
+    bool r = false;
+    pthread_mutex_lock(&g_mem_lock);
+    std::map<uintptr_t, size_t>::const_iterator it = g_pinned.upper_bound((uintptr_t)p);
+    if (it != g_pinned.begin()) { --it; const uintptr_t o = (uintptr_t)p - it->first; r = o < it->second && len <= it->second - o; }
+    pthread_mutex_unlock(&g_mem_lock);
+    return r;
+}
+
 extern "C" int qzMemFindAddr(unsigned char *a)
 {
     int r = 0;
