@@ -842,7 +842,8 @@ extern "C" int qzd_lz4_decompress_frames(qzd_ctx *c, const uint8_t *d_comp, uint
     hipStream_t st = c->st[0];
     HIPCHK(c, hipMemcpyAsync(d_segs, h_segs, sb, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev_begin, st));
-    hipLaunchKernelGGL(qzk_lz4d_kernel, dim3((nsegs + 3) / 4), dim3(256), 0, st, d_comp, d_out, d_segs, d_res, nsegs);
+    /* single-wave workgroups: a workgroup leaves with its slowest frame (the resolve kernel of the deflate side: -12 %) */
+    hipLaunchKernelGGL(qzk_lz4d_kernel, dim3(nsegs), dim3(64), 0, st, d_comp, d_out, d_segs, d_res, nsegs);
     HIPCHK(c, hipEventRecord(c->ev_end, st));
     HIPCHK(c, hipMemcpyAsync(h_res, d_res, rb, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

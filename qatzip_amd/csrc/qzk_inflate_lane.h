@@ -638,14 +638,19 @@ QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
     }
 }
 
-/* one wave per segment; QZK_RES_WAVES segments per workgroup.  ts_stride sub-streams per segment (1 after the serial
+/* one wave per segment; QZK_RES_WAVES segments per workgroup (one: single-wave workgroups).  ts_stride sub-streams per segment (1 after the serial
  * phase A, K after the speculative one); the chain says which pieces of which sub-streams make up the segment.  The
  * output-dependent checks (capacity, history) live here because a speculative sub-decoder does not know its offset. */
-#define QZK_RES_WAVES 4
+#ifndef QZK_RES_WAVES
+#define QZK_RES_WAVES 1            /* segments (waves) per workgroup: 1 / 2 / 4 / 8 -> 11.6 / 11.9 / 13.1 / 15.0 ms per 2 GiB call - a
+                                    * workgroup leaves with its slowest segment, and segments differ */
+#endif
 #ifndef QZK_RES_OCC
 #define QZK_RES_OCC 6              /* waves per SIMD the register budget is cut for (measured: 8 -> 15.6 ms and 7 -> 19.1 ms with their spills, 6 -> 13.2 ms) */
 #endif
+#ifndef QZK_COOP_LEN
 #define QZK_COOP_LEN 32            /* matches at least this long are copied by the whole wave */
+#endif
 QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                 const qzk_tokseg *ts, uint32_t ts_stride, const uint8_t *lits, const qzk_seq *seqs,
                                 const qzk_chain *chains, const uint32_t *order /* or NULL */, uint32_t count)
