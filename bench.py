@@ -304,6 +304,8 @@ def sessions_leg(qz, dev, d_src, call_n, d_comp, steps):
     dt = time.perf_counter() - t0 if not err else 0.0
     for b in backs:
         b.free()
+    for c in ctxs:
+        c.close()                                       # the contexts' decode scratch (several GiB each) goes back
     if err or dt <= 0:
         return {"error": "; ".join(err)[:200]}
     return {"sessions": len(call_n), "GBps": round(2.0 * sum(call_n) * steps / dt / 1e9, 3), "steps": steps,
