@@ -793,3 +793,31 @@ def test_plain_c_caller_links_and_round_trips(tmp_path):
                            env=dict(os.environ, BT_PINNED=pin))
         assert r.returncode == 0 and "Gbps" in r.stdout, r.stdout + r.stderr
         print(r.stdout)
+
+
+@pytest.mark.parametrize("fmt", ["GZIP_EXT", "GZIP", "RAW", "4B"])
+def test_pinned_destination_receives_the_stream_directly(fmt):
+    """qzCompress into qzMalloc(PINNED_MEM) memory that holds the worst case: the gather kernels write the stream straight
+    into the caller's buffer, batch by batch (no copy after the last kernel) - same bytes as the software path, header and
+    trailer around them, nothing written past the reported length"""
+    L = A.lib()
+    data_fmt = {"GZIP_EXT": A.QZ_DEFLATE_GZIP_EXT, "GZIP": A.QZ_DEFLATE_GZIP, "RAW": A.QZ_DEFLATE_RAW, "4B": A.QZ_DEFLATE_4B}[fmt]
+    s = A.Session(data_fmt=data_fmt, hw_buff_sz=65536)
+    n = (24 << 20) + 777                                   # above the 8 MiB at which the direct path starts, several batches
+    src = datagen.gen_bytes("silesia", n, 61)
+    cap = L.qzMaxCompressedLength(n, C.byref(s.s)) + 64
+    psrc = L.qzMalloc(n, -1, A.PINNED_MEM); pdst = L.qzMalloc(cap + 4096, -1, A.PINNED_MEM)
+    assert psrc and pdst
+    C.memmove(psrc, src, n)
+    C.memset(pdst, 0xA5, cap + 4096)
+    sl, dl = C.c_uint(n), C.c_uint(cap)
+    rc = L.qzCompress(C.byref(s.s), C.cast(psrc, C.c_char_p), C.byref(sl), C.c_void_p(pdst), C.byref(dl), 1)
+    assert rc == A.QZ_OK and sl.value == n
+    got = C.string_at(pdst, dl.value)
+    exp = O.sw_compress(fmt, src, 65536, 1, cap=cap)[2]
+    assert got == exp, (fmt, len(got), len(exp))
+    assert C.string_at(pdst + cap, 4096) == b"\xa5" * 4096          # the guard behind the buffer is untouched
+    back = s.decompress(got, n + 64)
+    assert back[0] == A.QZ_OK and back[2] == src
+    L.qzFree(psrc); L.qzFree(pdst)
+    s.close()
