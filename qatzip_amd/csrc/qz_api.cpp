@@ -512,7 +512,7 @@ static int compress_deflate_hw(QzSession_T *sess, Sess *s, const unsigned char *
     const uint32_t n = *src_len, cap = *dest_len, hw = s->p.hw_buff_sz;
     *src_len = 0; *dest_len = 0;
     if (s->p.comp_lvl < 1 || s->p.comp_lvl > 9) return QZ_NOT_SUPPORTED;
-    if (n == 0) return QZ_OK;                                       /* the engine has nothing to submit */
+    if (n == 0) return QZ_OK;                                       /* (not reached: calls below input_sz_thrshold take the software path) */
     const uint32_t nchunks = (n + hw - 1) / hw;
     const unsigned hl = fmt == F_GZIP_EXT ? 24 : fmt == F_GZIP ? 10 : 4, fl = fmt == F_4B ? 0 : 8;
     const uint64_t in_bytes = (uint64_t)nchunks * hw;
@@ -665,7 +665,10 @@ static int compress_direct(QzSession_T *sess, const unsigned char *src, unsigned
     }
     if (s->p.fmt == F_LZ4) rc = compress_lz4(sess, s, src, src_len, dest, dest_len);
     else if (s->p.fmt == F_LZ4S) rc = QZ_UNSUPPORTED_FMT;
-    else if (s->hw_framing && !s->open && (s->p.fmt == F_GZIP_EXT || s->p.fmt == F_GZIP || s->p.fmt == F_4B))
+    /* the reference sends a call below input_sz_thrshold to its software path even on a QAT box (src/qatzip.c:1934-1947):
+     * such a call - an empty one included - keeps the software path's framing */
+    else if (s->hw_framing && !s->open && *src_len >= s->p.input_sz_thrshold &&
+             (s->p.fmt == F_GZIP_EXT || s->p.fmt == F_GZIP || s->p.fmt == F_4B))
         rc = compress_deflate_hw(sess, s, src, src_len, dest, dest_len, crc);
     else rc = compress_deflate(sess, s, src, src_len, dest, dest_len, last, crc);
     sess->thd_sess_stat = rc;

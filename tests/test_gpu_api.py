@@ -121,7 +121,7 @@ def test_hardware_path_framing_on_the_compress_side(fmt):
     for hw in (65536, 16384):
         s = A.Session(FMT[fmt], hw)
         assert L.qzamd_set_hw_framing(C.byref(s.s), 1) == A.QZ_OK
-        for kind, n in (("silesia", 5 * hw + 777), ("rand", 2 * hw), ("text", hw), ("runs", 1000), ("allA", 3 * hw + 1)):
+        for kind, n in (("silesia", 5 * hw + 777), ("rand", 2 * hw), ("text", hw), ("runs", 1024), ("allA", 3 * hw + 1)):
             src = datagen.gen_bytes(kind, n, 31)
             rc, used, out, crc = s.compress(src, 1, crc0=0)
             assert rc == A.QZ_OK and used == n, (fmt, hw, kind, rc)
@@ -144,6 +144,12 @@ def test_hardware_path_framing_on_the_compress_side(fmt):
                 assert b"".join(zlib.decompress(m, 31) for m in _split_members(out, fmt)) == src
             rc, cused, back = s.decompress(out, n + 64)
             assert rc == A.QZ_OK and back == src and cused == len(out), (fmt, hw, kind, rc)
+        # calls below input_sz_thrshold (1024 by default) - the empty call too - go to the reference's software path even
+        # on a QAT box (src/qatzip.c:1934-1947), so they keep its framing
+        for n in (0, 1, 1000, 1023):
+            small = datagen.gen_bytes("runs", n, 32)
+            rc, used, out, _ = s.compress(small, 1)
+            assert rc == A.QZ_OK and used == n and out == O.sw_compress(fmt, small, hw, 1, cap=n + 4096)[2], (fmt, hw, n)
         # a destination for two members only: whole members, QZ_BUF_ERROR, the caller resumes behind them
         src = datagen.gen_bytes("text", 4 * hw, 5)
         full = s.compress(src, 1)[2]

@@ -43,7 +43,8 @@ while time.time() - t0 < budget:
             rc, used, out, _ = s.compress(src, 1, cap=n + 64 * (n // 65536 + 2))
             exp = O.sw_compress("LZ4", src, 65536, 1, cap=n + 64 * (n // 65536 + 2))[2]
             ok &= rc == A.QZ_OK and used == n and out == exp
-        elif hwf and n:                                         # the hardware path's framing: a complete member per chunk
+        elif hwf and n >= 1024:                                 # the hardware path's framing: a complete member per chunk (calls below
+                                                                # input_sz_thrshold keep the software path's, src/qatzip.c:1934-1947)
             import zlib
             rc, used, out, _ = s.compress(src, 1)
             exp = b""
