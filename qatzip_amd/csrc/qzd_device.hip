@@ -394,6 +394,69 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
 static int deflate_lazy_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level, int last,
                              uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks, const uint32_t *cdesc);
 
+#include "qzk_deflate_wide.h"
+/* EXPERIMENTAL, QATZIP_AMD_K1=wide (level 1, chunks of at most 64 KB): K1w - one chunk per 1024-thread workgroup, the
+ * candidate table on chip (qzk_deflate_wide.h) - in place of K1; then K2 / CRC / scan / gather as launches of their own.
+ * One batch = the whole call, on one stream.  Not the product path: it exists to be measured. */
+static int deflate_wide_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int last,
+                             uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks, const uint32_t *cdesc)
+{
+    const uint32_t stride = slot_stride_for(chunk_sz);
+    const uint32_t wgs = nchunks < 256u ? nchunks : 256u;
+    const size_t symb = ((size_t)nchunks * chunk_sz + 511) & ~(size_t)255;
+    const size_t metab = ((size_t)nchunks * sizeof(qzk_lzmeta) + 255) & ~(size_t)255;
+    const size_t slotb = ((size_t)nchunks * stride + 255) & ~(size_t)255;
+    const size_t prevb = (size_t)wgs * 65536 * 2;
+    const size_t need = symb * 3 + metab + slotb + prevb + 256;
+    if (need > c->lane_cap) {
+        hipDeviceSynchronize();
+        if (c->d_lane) hipFree(c->d_lane);
+        c->d_lane = NULL; c->lane_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_lane, need));
+        c->lane_cap = need;
+    }
+    if (nchunks > c->call_cap) {
+        hipDeviceSynchronize();
+        hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs);
+        c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL; c->call_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_len, (size_t)nchunks * 4));
+        HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nchunks * 4));
+        HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nchunks * 8));
+        c->call_cap = nchunks;
+    }
+    uint8_t *pb = c->d_lane;
+    uint8_t *sym_lc = pb; pb += symb;
+    uint16_t *sym_dist = (uint16_t *)pb; pb += 2 * symb;
+    qzk_lzmeta *meta = (qzk_lzmeta *)pb; pb += metab;
+    uint8_t *slots = pb; pb += slotb;
+    uint16_t *prevtab = (uint16_t *)pb;
+    hipStream_t st = c->st[0];
+    c->last_nchunks = nchunks; c->nbatches = 1; c->k1ev_n = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_running, 0, 8, st));
+    HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, st));
+    HIPCHK(c, hipMemsetAsync(c->k1_counter, 0, 4, st));
+    HIPCHK(c, hipEventRecord(c->ev_begin, st));
+    HIPCHK(c, hipEventRecord(c->ev[0][0], st));
+    HIPCHK(c, hipEventRecord(c->k1ev[0][0], st));
+    hipLaunchKernelGGL(qzk_lz77_wide_kernel, dim3(wgs), dim3(QZW_W), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist, meta,
+                       prevtab, c->k1_counter, cdesc);
+    HIPCHK(c, hipEventRecord(c->k1ev[0][1], st)); c->k1ev_chunks[0] = nchunks; c->k1ev_n = 1;
+    HIPCHK(c, hipEventRecord(c->ev[0][1], st));
+    hipLaunchKernelGGL(qzk_huff_kernel, dim3(nchunks), dim3(QZK_HW), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist,
+                       meta, slots, stride, last ? nchunks - 1 : ~0u, c->d_len, cdesc);
+    hipLaunchKernelGGL(qzk_crc_chunks_kernel, dim3(nchunks), dim3(QZK_HT), 0, st, d_src, n, chunk_sz, nchunks, c->d_crc, cdesc);
+    HIPCHK(c, hipEventRecord(c->ev[0][2], st));
+    hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len, nchunks, c->d_offs, c->d_running);
+    hipLaunchKernelGGL(qzk_gather_kernel, dim3(nchunks), dim3(256), 0, st, slots, stride, c->d_len, c->d_offs, nchunks,
+                       d_dst, dst_cap, c->d_overflow);
+    HIPCHK(c, hipEventRecord(c->ev[0][3], st));
+    HIPCHK(c, hipMemcpyAsync(c->h_running, c->d_running, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev_end, st));
+    HIPCHK(c, hipGetLastError());
+    return QZD_OK;
+}
+
 /* cdesc (device memory, or NULL): per-chunk length / closes-its-stream flag of a coalesced launch (qzk_chunk_len) */
 static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
                                 int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc, const uint8_t *h_src);
@@ -425,6 +488,11 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         const char *lz = getenv("QATZIP_AMD_LAZY");
         if (level >= 4 && !(lz && lz[0] == '0')) return deflate_lazy_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
         if (level != 1 || (force && force[0] == 'l')) return deflate_lane_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
+        const char *k1 = getenv("QATZIP_AMD_K1");
+        if (k1 && k1[0] == 'w' && chunk_sz <= 65536) {
+            if (h_src && n) HIPCHK(c, hipMemcpy((void *)d_src, h_src, n, hipMemcpyHostToDevice));
+            return deflate_wide_path(c, d_src, n, chunk_sz, last, d_dst, dst_cap, nchunks, cdesc);
+        }
     }
     const uint32_t max_wgs = (c->k1_wgs + QZK_K1_WAVES - 1) / QZK_K1_WAVES;      /* workgroups of a full launch (one per CU) */
     qzd_k1pool *const pool = &g_k1pool[c->device % QZD_MAX_DEVICES];

@@ -8,6 +8,7 @@
 #include "hipsim.h"
 #include "../../qatzip_amd/csrc/qzk_deflate_lz77.h"
 #include "../../qatzip_amd/csrc/qzk_deflate_huff.h"
+#include "../../qatzip_amd/csrc/qzk_deflate_wide.h"
 #include "../../qatzip_amd/csrc/qzk_deflate_lz77_lane.h"
 #include "../../qatzip_amd/csrc/qzk_inflate.h"
 #include "../../qatzip_amd/csrc/qzk_inflate_lane.h"
@@ -73,6 +74,34 @@ static int deflate_variant(int variant, const uint8_t *src, uint64_t n, uint32_t
         });
     }
     if (variant != 1) sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data(), nullptr); });
+    uint64_t pos = 0;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);
+        pos += olen[c];
+        if (crcs) crcs[c] = ocrc[c];
+    }
+    *out_len = pos;
+    return (int)nchunks;
+}
+
+/* K1w (experimental wide-window parse, one chunk of at most 64 KB per 1024-thread workgroup) + K2: the same stream */
+int sim_deflate_wide(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last, uint8_t *out, uint64_t *out_len, uint32_t *crcs)
+{
+    uint32_t nchunks = n ? (uint32_t)((n + chunk_sz - 1) / chunk_sz) : 1;
+    std::vector<uint8_t> lc(n + 64);
+    std::vector<uint16_t> dist(n + 64);
+    std::vector<qzk_lzmeta> meta(nchunks);
+    uint32_t stride = (chunk_sz * 9u / 8u + 1024u + 3u) & ~3u;
+    std::vector<uint8_t> slots((size_t)nchunks * stride);
+    std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
+    std::vector<uint16_t> prevtab((size_t)2 * 65536, 0x5a5a);
+    uint32_t counter = 0;
+    sim::launch(2, QZW_W, 0, [&] { qzk_lz77_wide_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), prevtab.data(), &counter, nullptr); });
+    sim::launch(nchunks, QZK_HW, 0, [&] {
+        qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
+                        last ? nchunks - 1 : ~0u, olen.data(), nullptr);
+    });
+    sim::launch(nchunks, QZK_HT, 0, [&] { qzk_crc_chunks_kernel(src, n, chunk_sz, nchunks, ocrc.data(), nullptr); });
     uint64_t pos = 0;
     for (uint32_t c = 0; c < nchunks; c++) {
         memcpy(out + pos, slots.data() + (size_t)c * stride, olen[c]);

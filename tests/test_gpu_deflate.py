@@ -140,3 +140,26 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_experimental_wide_window_kernel_is_bit_exact():
+    """QATZIP_AMD_K1=wide: K1w (qzk_deflate_wide.h: one chunk per 1024-thread workgroup, zlib's own head[] / prev[] on chip,
+    the parse as the fixpoint of assume-inserted / match / parse rounds) in place of K1 - same bytes, in a fresh process"""
+    import os, subprocess, sys
+    code = r'''
+import sys, zlib
+sys.path.insert(0, "tests")
+import datagen, oracle_lib as O, qatzip_amd
+c = qatzip_amd.Context(0)
+for kind, n, chunk in (("silesia", 6 << 20, 65536), ("text", 300000, 16384), ("rand", 70000, 65536), ("runs", 200000, 65536), ("records", 65536 * 3 + 5, 65536), ("text", 0, 65536)):
+    src = datagen.gen_bytes(kind, n, 13)
+    d_src = c.alloc(max(n, 1) + 512); d_dst = c.alloc(qatzip_amd.max_deflate_len(n, chunk))
+    d_src.upload(src)
+    ol, crcs = c.deflate_raw(d_src, n, chunk, 1, 1, d_dst)
+    assert bytes(d_dst.download(ol)) == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2], (kind, n, chunk)
+print("ok")
+'''
+    env = dict(os.environ, QATZIP_AMD_K1="wide")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -31,6 +31,7 @@ def sim():
     S.sim_deflate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint64),
                               C.c_void_p]
     S.sim_deflate_fused.argtypes = S.sim_deflate.argtypes
+    S.sim_deflate_wide.argtypes = S.sim_deflate.argtypes
     return S
 
 
@@ -336,3 +337,21 @@ def test_lz4_frames_match_oracle(sim):
                 exp = O.sw_compress("LZ4", piece, 65536, 1, cap=len(piece) + len(piece) // 255 + 200)[2]
                 got = bytes(slots[i * stride:i * stride + int(lens[i])])
                 assert got == exp, (kind, n, fs, i, int(lens[i]), len(exp))
+
+
+def test_wide_window_parse_is_exact(sim):
+    """K1w (experimental, qzk_deflate_wide.h): one chunk of at most 64 KB per 1024-thread workgroup, the parse found as the
+    fixpoint of assume-inserted / match / parse rounds over 1024-position windows, zlib's own head[] / prev[] on chip -
+    the same bytes as the software path on every kind, at the sizes where zlib's end-of-chunk rules bite"""
+    for kind in datagen.KINDS:
+        for n, chunk in ((0, 65536), (1, 65536), (3, 65536), (300, 65536), (1020, 65536), (1024, 65536), (1025, 65536), (9000, 1024),
+                         (65274, 65536), (65275, 65536), (65400, 65536), (65536, 65536), (200000, 65536), (70000, 16384)):
+            if kind == "lzmix" and n > 70000:
+                n = 66000
+            src = datagen.gen_bytes(kind, n, 53)
+            nch = max(1, (n + chunk - 1) // chunk)
+            cap = n * 9 // 8 + 4096 * (nch + 1)
+            for last in (1, 0):
+                out = C.create_string_buffer(cap); ol = C.c_uint64(0); crcs = np.zeros(nch, np.uint32)
+                sim.sim_deflate_wide(src, n, chunk, last, out, C.byref(ol), crcs.ctypes.data)
+                assert out.raw[:ol.value] == O.sw_compress("RAW", src, chunk, 1, last=last, cap=cap)[2], (kind, n, chunk, last)
