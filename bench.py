@@ -10,7 +10,8 @@ counts uncompressed bytes for either direction and doubles them for "both", test
 Multi-GPU: independent chunks shard across ranks with no data-path collective in the timed region (weak scaling:
 every rank owns its own buffer); gloo carries the barrier and the max/sum reductions of the timings.  After the timed
 region the ranks also build ONE gzip-ext member out of one shard each (config 5's shape): the compressed shards travel
-to rank 0's HBM as peer-to-peer copies over xGMI (qzd_shard_*, IPC memory), `config.one_stream` reports it.
+to rank 0's HBM - as peer-to-peer copies into an IPC window and as an RCCL send/recv group, both timed - and
+`config.one_stream` reports them.  `python bench.py --gpus N` launches its own N ranks when no launcher set WORLD_SIZE.
 
 Beside the headline the line carries (rank 0, N = 1 only, all outside the timed region):
   config.api_*          the same work through qatzip.h itself: qzCompress / qzDecompress on qzMalloc(PINNED_MEM) buffers
@@ -49,6 +50,27 @@ def dist_setup():
         dist.init_process_group("gloo", rank=rank, world_size=world)
         pg = dist
     return rank, world, local, pg
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: become the launcher - one process per GPU (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, exactly what torch.distributed.run sets), gloo rendezvous on
+    127.0.0.1, rank 0's JSON line passed through.  Under torchrun (WORLD_SIZE already set) this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ps = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        ps.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                   stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in ps:
+        rc = p.wait() or rc
+    sys.exit(rc)
 
 
 def barrier(pg):
@@ -318,12 +340,72 @@ def view(qz, buf, off, n):
     return v
 
 
-def one_stream_leg(ctx, qz, pg, rank, world, d_src, shard_mb):
-    """config 5's shape: every rank deflates ONE shard of a logical buffer, the compressed shards travel to rank 0's HBM
-    as peer copies (xGMI between GPUs), rank 0 folds the CRCs and closes the gzip-ext member (qzd_shard_*)."""
+def one_stream_leg(ctx, qz, pg, rank, world, d_src, shard_mb, steps):
+    """config 5's shape, timed: every rank deflates ONE shard of a logical buffer (shard_mb MiB each: 8 ranks x 511 MiB is
+    the largest member gzip-ext holds), the compressed shards travel to rank 0's HBM, rank 0 folds the CRCs and closes
+    the member - `steps` members per transport, max-over-ranks time between barriers.  Both transports are measured
+    (IPC window with peer copies / RCCL send-recv group) and the faster one is the leg's headline; a transport that cannot
+    start on this box reports its error instead.  Rank 0 checks every member's header and trailer against the ranks' own
+    CPU CRC-32s and a prefix of its payload against the oracle (outside the timed loop)."""
+    import zlib
     from qatzip_amd import shard
     n = shard_mb << 20
-    return shard.one_stream(ctx, pg, rank, world, view(qz, d_src, 0, n), n, CHUNK, verify="sample")
+    src = view(qz, d_src, 0, n)
+    host = d_src.download(n) if n <= (1 << 30) else None
+    my_crc = zlib.crc32(host.tobytes()) & 0xffffffff if host is not None else 0
+    out = {"ranks": world, "shard_MiB": shard_mb, "member_raw_MiB": shard_mb * world, "steps": steps}
+    best = None
+    for transport in ("ipc", "rccl"):
+        try:
+            one = shard.OneStream(ctx, pg, rank, world, n, CHUNK, 1, transport)
+            if one.error:
+                out[transport] = {"error": one.error[:200]}
+                continue
+            r = one.run(src, want_member=True)                       # warm-up + the member that is checked
+            if "error" in r:
+                out[transport] = {"error": r["error"][:200]}
+                one.close()
+                continue
+            recs = shard.all_gather_records(pg, shard.pack_record(n, r["comp_len"], my_crc), world) if world > 1 else [(n, r["comp_len"], my_crc)]
+            verified = None
+            if rank == 0:
+                mb = r["stream"]
+                verified = shard.member_is_consistent(mb, recs)
+                if verified and host is not None:
+                    import oracle_lib as O
+                    k = min(n, 4 << 20) // CHUNK * CHUNK
+                    exp = O.sw_compress("RAW", host[:k].tobytes(), CHUNK, 1, last=0 if (world > 1 or k < n) else 1, cap=k * 9 // 8 + 65536)[2]
+                    verified = mb[24:24 + len(exp)] == exp
+            barrier(pg)
+            t0 = time.perf_counter()
+            tg = 0.0
+            ok = True
+            for _ in range(steps):
+                r2 = one.run(src)
+                ok = ok and "error" not in r2
+                tg += r2.get("gather_ms", 0.0)
+            barrier(pg)
+            dt = allreduce(pg, time.perf_counter() - t0, "MAX")
+            tg = allreduce(pg, tg, "MAX")
+            one.close()
+            if not ok:
+                out[transport] = {"error": "a member of the timed loop failed"}
+                continue
+            res = {"GBps": round(world * n * steps / dt / 1e9, 3), "ms_per_member": round(dt / steps * 1e3, 2),
+                   "gather_ms_per_member": round(tg / steps, 2), "gather_share": round(tg / steps / (dt / steps * 1e3), 3)}
+            if rank == 0:
+                res.update({"member_bytes": r["member_bytes"], "crc32": r["crc32"], "verified": bool(verified)})
+            out[transport] = res
+            if best is None or res["GBps"] > out[best]["GBps"]:
+                best = transport
+        except Exception as e:   # noqa: BLE001 - a transport that does not work here must not cost the other one
+            out[transport] = {"error": repr(e)[:200]}
+    out["transport"] = best
+    if best:
+        out["GBps"] = out[best]["GBps"]
+    out["note"] = ("ipc = peer copies into an IPC window in rank 0's HBM (xGMI between GPUs); rccl = ncclAllGather of the records + "
+                   "ncclSend/ncclRecv group; uncompressed bytes of the member / max-over-ranks time, deflate included")
+    return out
 
 
 def main():
@@ -345,14 +427,18 @@ def main():
     if args.cpu_worker is not None:
         cpu_worker(args.cpu_worker, args.cpu_mb, args.base_mb)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                      # does not return
 
     rank, world, local, pg = dist_setup()
     import datagen
     import qatzip_amd
 
-    # one process per GPU: LOCAL_RANK picks the device (QATZIP_AMD_BENCH_DEVICE overrides it, for exercising the
-    # multi-rank path on a box with fewer GPUs than ranks)
-    ctx = qatzip_amd.Context(int(os.environ.get("QATZIP_AMD_BENCH_DEVICE", local)))
+    # one process per GPU: LOCAL_RANK picks the device.  More ranks than GPUs (exercising the multi-rank path on a smaller
+    # box) wrap around and the line says so; QATZIP_AMD_BENCH_DEVICE pins every rank to one device.
+    ndev = max(1, qatzip_amd.load().qzd_device_count())
+    dev = int(os.environ.get("QATZIP_AMD_BENCH_DEVICE", local % ndev))
+    ctx = qatzip_amd.Context(dev)
     total = args.mb << 20
     base_n = min(args.base_mb << 20, total)
     base = datagen.gen("silesia", base_n, 20250523 + rank)
@@ -418,7 +504,8 @@ def main():
     if not args.no_extra:
         if world > 1:
             try:
-                one = one_stream_leg(ctx, qatzip_amd, pg, rank, world, d_src, min(256, args.mb))
+                # 8 ranks x 511 MiB: the largest member a gzip-ext header can describe (both sizes are 32-bit)
+                one = one_stream_leg(ctx, qatzip_amd, pg, rank, world, d_src, min(512, 4095 // world, args.mb), max(1, args.steps))
             except Exception as e:   # noqa: BLE001 - the headline must survive a box without peer access
                 one = {"error": str(e)[:200]}
             barrier(pg)
@@ -426,14 +513,18 @@ def main():
             emb = min(args.extra_mb, args.mb)
             if ncalls > 1:
                 try:
-                    extra["concurrent_sessions"] = sessions_leg(qatzip_amd, int(os.environ.get("QATZIP_AMD_BENCH_DEVICE", local)),
-                                                                d_src, call_n, d_comp, args.steps)
+                    extra["concurrent_sessions"] = sessions_leg(qatzip_amd, dev, d_src, call_n, d_comp, args.steps)
                 except Exception as e:   # noqa: BLE001 - an extra leg must not cost the headline
                     extra["concurrent_sessions"] = {"error": str(e)[:200]}
             for d in d_comp:
                 d.free()
             d_back.free()
             extra["hbm_copy_GBps"] = round(ctx.stream_copy_peak(1 << 30, 3), 1)
+            try:
+                h2d, d2h = ctx.pcie_peak(1 << 30, 2)
+                extra["pcie_h2d_GBps"], extra["pcie_d2h_GBps"] = round(h2d, 2), round(d2h, 2)
+            except Exception as e:   # noqa: BLE001
+                extra["pcie_error"] = str(e)[:120]
             extra["raw_sweep"] = raw_sweep(ctx, qatzip_amd, d_src, emb)
             extra["lz4"] = lz4_leg(ctx, qatzip_amd, d_src, emb)
             extra.update(api_leg(base, tile, emb))
@@ -487,7 +578,23 @@ def main():
                                               "of which qzk_lz_resolve_kernel": round(inf_ms[2], 3),
                                               "qzk_crc_kernel(last call)": round(inf_ms[1], 3)}},
         }
+        # the decode side's kernels of the last call (phase A + phase B of the two-phase inflate, or the wave-per-segment
+        # kernel), by the same rule: algorithmic bytes (compressed bytes read + plain bytes written) / their HIP-event time
+        dec_alg = float(comp_len[-1]) + float(call_n[-1])
+        if inf_ms[0] > 0:
+            res["roofline_decode"] = {"bound": "hbm", "kernel": "qzk_inflate_tok_kernel + qzk_lz_resolve_kernel",
+                                      "achieved": round(dec_alg / (inf_ms[0] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(dec_alg / (inf_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                                      "algorithmic_bytes": int(dec_alg), "launch_ms": round(inf_ms[0], 3),
+                                      "of_which_resolve_ms": round(inf_ms[2], 3), "call_MiB": call_n[-1] >> 20}
         res["config"].update(extra)
+        if "pcie_h2d_GBps" in extra and "api_compress_GBps" in extra:
+            # the host-to-host API against what bounds it: input over the link while the kernels run, output back
+            kc, kd = res["config"]["compress_GBps"], res["config"]["decompress_GBps"]
+            res["config"]["api_compress_vs_bound"] = round(extra["api_compress_GBps"] / min(extra["pcie_h2d_GBps"], kc), 3)
+            res["config"]["api_decompress_vs_bound"] = round(extra["api_decompress_GBps"] / min(extra["pcie_d2h_GBps"], kd), 3)
+        if ndev < world:
+            res["config"]["ranks_share_devices"] = "%d ranks on %d device(s)" % (world, ndev)
         if one is not None:
             res["config"]["one_stream"] = one
         if not args.no_cpu and world == 1:

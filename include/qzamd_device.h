@@ -36,6 +36,7 @@ int qzd_create(int device, qzd_ctx **ctx);
 void qzd_destroy(qzd_ctx *ctx);
 const char *qzd_last_error(qzd_ctx *ctx);
 int qzd_device_count(void);
+int qzd_ctx_device(qzd_ctx *ctx);      /* the GPU this context was created on (-1: no context) */
 /* chunks the compress path hands to one launch of its LZ77 kernel on this device (a whole number of rounds over
  * the resident workgroups); callers that pipeline their own work can size it in these units */
 uint32_t qzd_batch_chunks(qzd_ctx *ctx);
@@ -46,6 +47,8 @@ int qzd_k1_stats(qzd_ctx *ctx, double *ms, uint64_t *launches, uint64_t *chunks,
 /* measured stream-copy rate of the device, read + written decimal GB per second (a hand-written 16-byte-per-lane copy
  * kernel over two buffers of `bytes` each, best of `iters`): the yardstick beside the 8 TB/s datasheet figure */
 int qzd_stream_copy_peak(qzd_ctx *ctx, uint64_t bytes, int iters, double *gbps);
+/* what the host link delivers: pinned hipMemcpyAsync of `bytes` each way, best of `iters`, decimal GB/s */
+int qzd_pcie_peak(qzd_ctx *ctx, uint64_t bytes, int iters, double *h2d_gbps, double *d2h_gbps);
 
 /* plain HBM / pinned-host memory helpers (replace qaeMemAllocNUMA, src/qatzip_mem.c:169-224) */
 void *qzd_dev_alloc(qzd_ctx *ctx, size_t n);
@@ -168,6 +171,10 @@ typedef struct { int32_t status; uint32_t in_used, out_len, pad; } qzd_lz4res;
  * when incompressible) when it is called on that piece alone; frames are written back to back.  h_frame_len (optional) <- size of every frame. */
 int qzd_lz4_compress_frames(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t frame_sz, uint8_t *d_dst,
                             uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len);
+/* the same frames with the header the reference's HARDWARE path writes per chunk (qzLZ4HeaderGen,
+ * src/qatzip_lz4.c:104-132: FLG 0x4C, content size = the chunk's bytes); footer as qzLZ4FooterGen (:134-143) */
+int qzd_lz4_compress_frames_hw(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t frame_sz, uint8_t *d_dst,
+                               uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len);
 /* ONE call above 64 KB as the one frame LZ4F_compressFrame writes for it (src/qatzip_sw.c:451-456): FLG 0x4C, the 64 KB
  * blocks linked - one parse state for the whole frame, hence one wave's serial work; 64 KB < n <= 0x7fff0000 (beyond that
  * liblz4 rescales its 32-bit positions, which is not reproduced) */
@@ -196,11 +203,25 @@ int qzd_shard_root_create(qzd_ctx *ctx, uint32_t world, uint64_t cap_bytes, uint
 int qzd_shard_attach(qzd_ctx *ctx, uint32_t rank, uint32_t world, const uint8_t handle[64], uint64_t cap_bytes, qzd_shard **out);
 int qzd_shard_put(qzd_shard *s, const uint8_t *d_comp, uint64_t comp_len, uint64_t raw_len, uint32_t crc32, uint32_t seq,
                   double timeout_s, uint64_t *h_offset);
-int qzd_shard_finish(qzd_shard *s, uint32_t seq, double timeout_s, uint8_t **d_stream, uint64_t *stream_len,
+/* level: the comp_lvl the shards were deflated at (the header's XFL byte follows it, as in a qzCompress call) */
+int qzd_shard_finish(qzd_shard *s, uint32_t seq, double timeout_s, int level, uint8_t **d_stream, uint64_t *stream_len,
                      uint32_t *crc_out, uint64_t *raw_total);
 void qzd_shard_close(qzd_shard *s);
+/* The same gather over RCCL (the collective library over xGMI that north_star names): the records as one ncclAllGather,
+ * the shards as one group of ncclSend / ncclRecv into the root's HBM, every wait on the device.  Rank 0 makes the
+ * 128-byte id, the launcher hands it to every rank (any transport), every rank creates its end with it.  librccl.so.1 is
+ * looked up at run time; QZD_ERR_UNSUPPORTED when it is not there.  qzd_rccl_gather(): every rank passes its shard; on
+ * the root *d_stream / *stream_len describe the finished member, byte for byte what qzd_shard_finish() builds. */
+typedef struct qzd_rccl qzd_rccl;
+int qzd_rccl_unique_id(uint8_t id_out[128]);
+int qzd_rccl_create(qzd_ctx *ctx, uint32_t rank, uint32_t world, const uint8_t id[128], uint64_t cap_bytes, qzd_rccl **out);
+int qzd_rccl_gather(qzd_rccl *s, const uint8_t *d_comp, uint64_t comp_len, uint64_t raw_len, uint32_t crc32, int level,
+                    uint8_t **d_stream, uint64_t *stream_len, uint32_t *crc_out, uint64_t *raw_total);
+void qzd_rccl_close(qzd_rccl *s);
 /* zlib crc32_combine(): CRC-32 of A || B from the CRC-32s of A and B and the length of B */
 uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+/* the same folded over the per-chunk CRC-32s of an n-byte buffer cut every chunk_sz bytes (host arrays) */
+uint32_t qzd_crc32_fold(const uint32_t *h_crc, uint32_t nchunks, uint32_t chunk_sz, uint64_t n);
 
 /* GPU time (ms) of the last qzd_inflate_stream call: [0] inflate kernels, [1] crc kernels, [2] the part of [0]
  * spent in the match-resolve phase of the two-phase path (0 on the wave-per-segment path), [3] reserved (0) */

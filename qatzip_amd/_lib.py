@@ -52,15 +52,24 @@ def load(build_if_missing=True):
     L.qzd_crc32_ranges.argtypes = [vp, u8p, vp, C.c_uint32, vp]
     L.qzd_last_inflate_timing.argtypes = [vp, C.POINTER(C.c_float * 4)]
     L.qzd_lz4_compress_frames.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
+    L.qzd_lz4_compress_frames_hw.argtypes = L.qzd_lz4_compress_frames.argtypes
     L.qzd_lz4_compress_linked.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.qzd_lz4_decompress_frames.argtypes = [vp, u8p, u8p, vp, C.c_uint32, vp]
     L.qzd_chunk_lens.argtypes = [vp, vp, C.c_uint32]
     L.qzd_shard_root_create.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_char_p, C.POINTER(vp)]
     L.qzd_shard_attach.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(vp)]
     L.qzd_shard_put.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_uint64)]
-    L.qzd_shard_finish.argtypes = [vp, C.c_uint32, C.c_double, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+    L.qzd_shard_finish.argtypes = [vp, C.c_uint32, C.c_double, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                    C.POINTER(C.c_uint64)]
     L.qzd_shard_close.argtypes = [vp]
+    L.qzd_rccl_unique_id.argtypes = [C.c_char_p]
+    L.qzd_rccl_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(vp)]
+    L.qzd_rccl_gather.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.qzd_rccl_close.argtypes = [vp]
+    L.qzd_ctx_device.argtypes = [vp]
+    L.qzd_pcie_peak.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.qzd_crc32_fold.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]; L.qzd_crc32_fold.restype = C.c_uint32
     L.qzd_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]; L.qzd_crc32_combine.restype = C.c_uint32
     _lib = L
     return L
@@ -75,14 +84,15 @@ LZ4RES_DT = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"),
 
 def exported_symbols():
     """Names include/*.h declares that must be exported by the library (checked on CPU too)."""
-    return ["qzd_create", "qzd_destroy", "qzd_last_error", "qzd_device_count", "qzd_dev_alloc", "qzd_dev_free",
+    return ["qzd_create", "qzd_destroy", "qzd_last_error", "qzd_device_count", "qzd_ctx_device", "qzd_dev_alloc", "qzd_dev_free",
             "qzd_h2d", "qzd_d2h", "qzd_host_alloc_pinned", "qzd_host_free_pinned", "qzd_deflate_raw",
             "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing", "qzd_inflate_segments",
             "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing",
-            "qzd_lz4_compress_frames", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats",
+            "qzd_lz4_compress_frames", "qzd_lz4_compress_frames_hw", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats",
             "qzd_adler32_chunks", "qzd_adler32_combine", "qzd_stream_copy_peak", "qzd_deflate_raw_from_host",
             "qzd_deflate_slots", "qzd_inflate_stream_to_host", "qzamd_async_stats", "qzd_shard_root_create",
-            "qzd_shard_attach", "qzd_lz4_compress_linked", "qzd_shard_put", "qzd_shard_finish", "qzd_shard_close", "qzd_crc32_combine"]
+            "qzd_shard_attach", "qzd_lz4_compress_linked", "qzd_shard_put", "qzd_shard_finish", "qzd_shard_close", "qzd_crc32_combine",
+            "qzd_crc32_fold", "qzd_pcie_peak", "qzd_rccl_unique_id", "qzd_rccl_create", "qzd_rccl_gather", "qzd_rccl_close"]
 
 
 class DevBuf:
@@ -166,6 +176,12 @@ class Context:
         g = C.c_double(0)
         self._chk(self.L.qzd_stream_copy_peak(self.h, nbytes, iters, C.byref(g)))
         return g.value
+
+    def pcie_peak(self, nbytes=1 << 30, iters=2):
+        """pinned hipMemcpyAsync rates (host -> device, device -> host), GB/s"""
+        a, b = C.c_double(0), C.c_double(0)
+        self._chk(self.L.qzd_pcie_peak(self.h, nbytes, iters, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def batch_chunks(self):
         return int(self.L.qzd_batch_chunks(self.h))

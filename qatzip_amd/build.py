@@ -38,7 +38,7 @@ def build(force=False, verbose=False):
     units = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
            "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC, "-x", "hip"] + units + \
-          ["-o", SO, "-lpthread"]
+          ["-o", SO, "-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -555,6 +555,46 @@ static int compress_deflate_hw(QzSession_T *sess, Sess *s, const unsigned char *
     return take == nchunks ? QZ_OK : QZ_BUF_ERROR;
 }
 
+/* An LZ4 session in the HARDWARE path's framing (qzamd_set_hw_framing): every hw_buff_sz chunk is a frame of its own
+ * behind qzLZ4HeaderGen's header - FLG 0x4C (blocks not marked independent), BD 64 KB, content size = the bytes the chunk
+ * consumed, header checksum - and in front of qzLZ4FooterGen's end mark + XXH32 of the chunk (src/qatzip_lz4.c:104-143;
+ * retired chunk by chunk, src/qatzip.c:1691-1718).  A chunk of at most 64 KB is one block; a larger hw_buff_sz gives the
+ * frame several 64 KB blocks that may reach back into each other, which is what the linked-block kernel writes (its
+ * header is this very one).  Whole frames that fit, QZ_BUF_ERROR with progress otherwise (the hardware contract). */
+static int compress_lz4_hw(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
+                           unsigned char *dest, unsigned int *dest_len)
+{
+    const uint32_t n = *src_len, cap = *dest_len, hw = s->p.hw_buff_sz;
+    *src_len = 0; *dest_len = 0;
+    if (s->p.comp_lvl >= 3) return QZ_NOT_SUPPORTED;
+    const uint32_t nchunks = (n + hw - 1) / hw;
+    const uint64_t per = 15 + 4ull * ((hw + 65535) >> 16) + hw + 8;       /* header, block headers, stored blocks, footer */
+    int rc = reserve(s, n, (uint64_t)nchunks * per + 64);
+    if (rc) return rc;
+    if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
+    std::vector<uint32_t> lens(nchunks);
+    uint64_t produced = 0;
+    if (hw <= 65536) {
+        if (qzd_lz4_compress_frames_hw(s->ctx, s->d_in, n, hw, s->d_out, s->out_cap, &produced, lens.data()) != QZD_OK) return QZ_FAIL;
+    } else {
+        for (uint32_t k = 0; k < nchunks; k++) {
+            const uint32_t cl = std::min<uint32_t>(hw, n - k * hw);
+            uint64_t one = 0;
+            if (cl > 65536) { if (qzd_lz4_compress_linked(s->ctx, s->d_in + (size_t)k * hw, cl, s->d_out + produced, s->out_cap - produced, &one) != QZD_OK) return QZ_FAIL; }
+            else if (qzd_lz4_compress_frames_hw(s->ctx, s->d_in + (size_t)k * hw, cl, 65536, s->d_out + produced, s->out_cap - produced, &one, NULL) != QZD_OK) return QZ_FAIL;
+            lens[k] = (uint32_t)one; produced += one;
+        }
+    }
+    uint32_t take = 0; uint64_t bytes = 0;
+    while (take < nchunks && bytes + lens[take] <= cap) bytes += lens[take++];
+    if (take == 0) return QZ_BUF_ERROR;
+    if (qzd_d2h(s->ctx, dest, s->d_out, bytes) != QZD_OK) return QZ_FAIL;
+    const uint32_t used = take == nchunks ? n : take * hw;
+    *src_len = used; *dest_len = (unsigned int)bytes;
+    sess->total_in += used; sess->total_out += bytes;
+    return take == nchunks ? QZ_OK : QZ_BUF_ERROR;
+}
+
 /* LZ4 sessions: one frame per call, `last` ignored (src/qatzip_sw.c:443-471) */
 static int compress_lz4(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
                         unsigned char *dest, unsigned int *dest_len)
@@ -663,7 +703,8 @@ static int compress_direct(QzSession_T *sess, const unsigned char *src, unsigned
         if (rc == QZ_OK || rc == QZ_BUF_ERROR) return rc;
         goto fail;
     }
-    if (s->p.fmt == F_LZ4) rc = compress_lz4(sess, s, src, src_len, dest, dest_len);
+    if (s->p.fmt == F_LZ4 && s->hw_framing && *src_len >= s->p.input_sz_thrshold) rc = compress_lz4_hw(sess, s, src, src_len, dest, dest_len);
+    else if (s->p.fmt == F_LZ4) rc = compress_lz4(sess, s, src, src_len, dest, dest_len);
     else if (s->p.fmt == F_LZ4S) rc = QZ_UNSUPPORTED_FMT;
     /* the reference sends a call below input_sz_thrshold to its software path even on a QAT box (src/qatzip.c:1934-1947):
      * such a call - an empty one included - keeps the software path's framing */
@@ -952,16 +993,21 @@ extern "C" void *qzMalloc(size_t sz, int numa, int force_pinned)
          * hipHostMalloc is told to follow it; numa < 0: the default local-node policy, which is what the reference's
          * "node of the current CPU" amounts to */
         bool policy = false;
-#ifdef SYS_set_mempolicy
-        if (numa >= 0 && numa < 1024) {
+#if defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
+        /* the calling thread's own policy (numactl --interleave / --membind ...) is put back afterwards, not MPOL_DEFAULT */
+        int old_mode = MPOL_DEFAULT; unsigned long old_mask[16] = {0};
+        if (numa >= 0 && numa < 1024 &&
+            syscall(SYS_get_mempolicy, &old_mode, old_mask, (unsigned long)(sizeof(old_mask) * 8), NULL, 0ul) == 0) {
             unsigned long mask[16] = {0};
             mask[numa / (8 * sizeof(unsigned long))] = 1ul << (numa % (8 * sizeof(unsigned long)));
             policy = syscall(SYS_set_mempolicy, MPOL_PREFERRED, mask, (unsigned long)(sizeof(mask) * 8)) == 0;
         }
 #endif
         p = qzd_host_alloc_pinned_numa(sz, policy ? 1 : 0);
-#ifdef SYS_set_mempolicy
-        if (policy) syscall(SYS_set_mempolicy, MPOL_DEFAULT, NULL, 0ul);
+#if defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
+        if (policy && syscall(SYS_set_mempolicy, old_mode, old_mode == MPOL_DEFAULT ? NULL : old_mask,
+                              old_mode == MPOL_DEFAULT ? 0ul : (unsigned long)(sizeof(old_mask) * 8)) != 0)
+            syscall(SYS_set_mempolicy, MPOL_DEFAULT, NULL, 0ul);
 #endif
     }
     if (p) { pthread_mutex_lock(&g_mem_lock); g_pinned[(uintptr_t)p] = sz ? sz : 1; pthread_mutex_unlock(&g_mem_lock); return p; }
@@ -1172,6 +1218,9 @@ static Sess *batchable(const AsyncReq &q)
     if (!q.compress || !q.sess || !q.res || ensure_ready(q.sess, &s) < 0 || !s) return NULL;
     const int f = s->p.fmt;
     if (!(f == F_GZIP || f == F_GZIP_EXT || f == F_RAW || f == F_4B) || s->open) return NULL;
+    /* a hardware-framing session writes one complete member per chunk (compress_deflate_hw); compress_batch writes the
+     * software path's framing, so such a request runs alone - its framing must not depend on what else was queued */
+    if (s->hw_framing) return NULL;
     if (s->p.comp_lvl < 1 || s->p.comp_lvl > 9 || q.res->src_len > AQ_BATCH_MAX_REQ) return NULL;
     return s;
 }
@@ -1337,7 +1386,9 @@ static void *async_consumer(void *)
                 AsyncReq q = g_aq[g_aq_head];
                 pthread_mutex_unlock(&g_aq_lock);                /* ensure_ready may take the global lock */
                 Sess *s = q.compress != comp ? NULL : comp ? batchable(q) : batchable_d(q, &a_, &b_, &c_);
-                const bool ok = s && (!comp || (s->p.fmt == s0->p.fmt && s->p.comp_lvl == s0->p.comp_lvl && s->p.hw_buff_sz == s0->p.hw_buff_sz));
+                /* one launch runs on one GPU: only sessions of the oldest request's device ride along */
+                const bool ok = s && qzd_ctx_device(s->ctx) == qzd_ctx_device(s0->ctx) &&
+                                (!comp || (s->p.fmt == s0->p.fmt && s->p.comp_lvl == s0->p.comp_lvl && s->p.hw_buff_sz == s0->p.hw_buff_sz));
                 pthread_mutex_lock(&g_aq_lock);
                 if (!ok) break;
                 run.push_back(q); ss.push_back(s); g_aq_head++;
@@ -1399,8 +1450,21 @@ static void async_drain(QzSession_T *sess)
     pthread_mutex_unlock(&g_aq_lock);
 }
 
+/* fork(): the child inherits the queue's state but not its consumer thread (the reference API supports forked workers,
+ * max_forks).  Its first queued call would wait for ever: start over - empty queue, fresh lock (it may have been held at
+ * the moment of the fork), no consumer. */
+static void aq_atfork_child(void)
+{
+    pthread_mutex_init(&g_aq_lock, NULL);
+    pthread_cond_init(&g_aq_more, NULL); pthread_cond_init(&g_aq_idle, NULL); pthread_cond_init(&g_aq_done, NULL);
+    g_aq.clear(); g_aq_head = 0; g_aq_running.clear();
+    g_aq_thread = false;
+}
+
 static bool consumer_started_locked()
 {
+    static bool atfork_set = false;
+    if (!atfork_set) { pthread_atfork(NULL, NULL, aq_atfork_child); atfork_set = true; }
     if (!g_aq_thread) {
         pthread_t th;
         if (pthread_create(&th, NULL, async_consumer, NULL) != 0) return false;

@@ -82,7 +82,10 @@ static qzd_k1pool g_k1pool[QZD_MAX_DEVICES];
 static pthread_once_t g_k1pool_once = PTHREAD_ONCE_INIT;
 static void k1pool_init(void)
 {
-    for (int i = 0; i < QZD_MAX_DEVICES; i++) { memset(&g_k1pool[i], 0, sizeof(g_k1pool[i])); pthread_mutex_init(&g_k1pool[i].lock, NULL); g_k1pool[i].epoch = 1; }
+    /* QATZIP_AMD_EPOCH0: where the chunk epochs start (tests put it just below the 32-bit wrap) */
+    uint32_t e0 = 1;
+    if (const char *e = getenv("QATZIP_AMD_EPOCH0")) { unsigned long long v = strtoull(e, NULL, 0); if (v > 0 && v < 0xffffffffull) e0 = (uint32_t)v; }
+    for (int i = 0; i < QZD_MAX_DEVICES; i++) { memset(&g_k1pool[i], 0, sizeof(g_k1pool[i])); pthread_mutex_init(&g_k1pool[i].lock, NULL); g_k1pool[i].epoch = e0; }
 }
 
 int qzd_aux_reserve(qzd_ctx *c, size_t n)
@@ -121,6 +124,21 @@ uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
     for (uint64_t n = len2; n; n >>= 1, k++) if (n & 1) p = crc_multmodp(x2n[k & 31], p);
     return crc_multmodp(p, crc1) ^ crc2;
 }
+
+/* CRC-32 of a whole buffer from the CRC-32s of its chunks (chunk_sz bytes each, the last one n - (nchunks - 1) * chunk_sz):
+ * crc32_combine folded left to right, the multiplier of a full chunk computed once */
+extern "C" uint32_t qzd_crc32_fold(const uint32_t *h_crc, uint32_t nchunks, uint32_t chunk_sz, uint64_t n)
+{
+    if (!h_crc || nchunks == 0) return 0;
+    uint32_t crc = h_crc[0];
+    if (nchunks == 1) return crc;
+    const uint32_t op = qzd_crc32_combine(1u << 31, 0, chunk_sz);      /* x^(8 * chunk_sz) mod P */
+    for (uint32_t i = 1; i + 1 < nchunks; i++) crc = crc_multmodp(op, crc) ^ h_crc[i];
+    const uint64_t tail = n - (uint64_t)(nchunks - 1) * chunk_sz;
+    return qzd_crc32_combine(crc, h_crc[nchunks - 1], tail);
+}
+
+extern "C" int qzd_ctx_device(qzd_ctx *c) { return c ? c->device : -1; }
 
 extern "C" int qzd_device_count(void)
 {
@@ -164,7 +182,6 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         c->batch_chunks = QZD_BATCH_ROUNDS * c->k1_wgs;
         /* the tables (16 MiB per workgroup, 4 GiB for a full device) belong to the device (g_k1pool): allocated by the
          * first call that needs them and only as many as its chunks can occupy, shared by every context on the GPU */
-        c->k1_held = false;
         if (hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) QZD_CREATE_FAIL;
     }
     if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) QZD_CREATE_FAIL;
@@ -196,7 +213,6 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);
     for (int i = 0; i < QZD_K1EV; i++) { if (c->k1ev[i][0]) hipEventDestroy(c->k1ev[i][0]); if (c->k1ev[i][1]) hipEventDestroy(c->k1ev[i][1]); }
-    if (c->k1_held) { c->k1_held = false; pthread_mutex_unlock(&g_k1pool[c->device % QZD_MAX_DEVICES].lock); }
     hipFree(c->k1_counter);
     hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
     hipHostFree(c->h_running); hipHostFree(c->h_overflow);
@@ -232,6 +248,35 @@ extern "C" int qzd_stream_copy_peak(qzd_ctx *c, uint64_t bytes, int iters, doubl
     hipFree(a); hipFree(b);
     if (best <= 0) return QZD_ERR_HIP;
     *gbps = 2.0 * (double)bytes / (best * 1e-3) / 1e9;
+    return QZD_OK;
+}
+
+/* what the host link delivers to this device: pinned hipMemcpyAsync of `bytes`, host -> device and device -> host, best of
+ * `iters`, decimal GB/s each (the bound of the host-to-host API beside the kernels; the QAT path's DMA, src/qatzip.c:1542) */
+extern "C" int qzd_pcie_peak(qzd_ctx *c, uint64_t bytes, int iters, double *h2d_gbps, double *d2h_gbps)
+{
+    if (!c || !bytes || iters < 1) return QZD_ERR_PARAM;
+    hipSetDevice(c->device);
+    void *h = NULL, *d = NULL;
+    if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) return QZD_ERR_HIP;
+    if (hipMalloc(&d, bytes) != hipSuccess) { hipHostFree(h); return QZD_ERR_HIP; }
+    memset(h, 0x5a, bytes);
+    float best[2] = {0, 0};
+    for (int dir = 0; dir < 2; dir++)
+        for (int it = 0; it <= iters; it++) {
+            hipEventRecord(c->ev_begin, c->st[0]);
+            if (dir == 0) hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->st[0]);
+            else hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->st[0]);
+            hipEventRecord(c->ev_end, c->st[0]);
+            hipStreamSynchronize(c->st[0]);
+            float t = 0;
+            if (hipEventElapsedTime(&t, c->ev_begin, c->ev_end) != hipSuccess) t = 0;
+            if (it > 0 && t > 0 && (best[dir] == 0 || t < best[dir])) best[dir] = t;
+        }
+    hipFree(d); hipHostFree(h);
+    if (best[0] <= 0 || best[1] <= 0) return QZD_ERR_HIP;
+    if (h2d_gbps) *h2d_gbps = (double)bytes / (best[0] * 1e-3) / 1e9;
+    if (d2h_gbps) *d2h_gbps = (double)bytes / (best[1] * 1e-3) / 1e9;
     return QZD_OK;
 }
 
@@ -463,12 +508,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
 static int deflate_enqueue(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
                            int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc, const uint8_t *h_src = NULL)
 {
-    const int rc = deflate_enqueue_impl(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, cdesc, h_src);
-    if (rc != QZD_OK && c && c->k1_held) {          /* an enqueue that failed half way gives the device's tables back */
-        hipStreamSynchronize(c->st[0]); hipStreamSynchronize(c->st[1]); hipStreamSynchronize(c->st_copy);
-        c->k1_held = false; pthread_mutex_unlock(&g_k1pool[c->device % QZD_MAX_DEVICES].lock);
-    }
-    return rc;
+    return deflate_enqueue_impl(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, cdesc, h_src);
 }
 static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int level,
                                 int last, uint8_t *d_dst, uint64_t dst_cap, const uint32_t *cdesc, const uint8_t *h_src)
@@ -496,13 +536,36 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
     }
     const uint32_t max_wgs = (c->k1_wgs + QZK_K1_WAVES - 1) / QZK_K1_WAVES;      /* workgroups of a full launch (one per CU) */
     qzd_k1pool *const pool = &g_k1pool[c->device % QZD_MAX_DEVICES];
+    pthread_once(&g_k1pool_once, k1pool_init);
+    /* The device's tables and batch scratch are used by one call at a time - on the GPU: this call's streams wait for the
+     * event the previous call (of whichever context) recorded behind its last launch, and leave theirs when everything is
+     * enqueued.  The mutex is held while this function runs and never across API calls. */
+    struct PoolGuard {
+        qzd_k1pool *p; qzd_ctx *c; bool launched;
+        PoolGuard(qzd_k1pool *p_, qzd_ctx *c_) : p(p_), c(c_), launched(false) { pthread_mutex_lock(&p->lock); }
+        ~PoolGuard()
+        {
+            if (launched) {
+                /* behind everything this call put on its streams (st[1] and the copy stream are joined into st[0] on the
+                 * success path; on an error path both are waited for here) */
+                if (!p->busy) hipEventCreateWithFlags(&p->busy, hipEventDisableTiming);
+                hipEvent_t j = c->done[1];
+                if (hipEventRecord(j, c->st[1]) == hipSuccess) hipStreamWaitEvent(c->st[0], j, 0);
+                if (p->busy && hipEventRecord(p->busy, c->st[0]) == hipSuccess) p->busy_valid = true;
+                else { hipStreamSynchronize(c->st[0]); hipStreamSynchronize(c->st[1]); p->busy_valid = false; }
+            }
+            pthread_mutex_unlock(&p->lock);
+        }
+    } guard(pool, c);
+    if (pool->busy_valid) {
+        HIPCHK(c, hipStreamWaitEvent(c->st[0], pool->busy, 0));
+        HIPCHK(c, hipStreamWaitEvent(c->st[1], pool->busy, 0));
+    }
     {
         /* a launch of few chunks spreads them over workgroups (CUs) before it stacks them on the waves of one */
         const uint32_t want = nchunks < max_wgs ? nchunks : max_wgs;
         /* the device's tables and batch scratch: taken for the whole call (released by qzd_sync, or by the caller of
          * this function when it fails) */
-        pthread_once(&g_k1pool_once, k1pool_init);
-        if (!c->k1_held) { pthread_mutex_lock(&pool->lock); c->k1_held = true; }
         const int rc = ensure_scratch(c, pool, chunk_sz, nchunks);
         if (rc) return rc;
         if (want > pool->tab_wgs) {
@@ -516,7 +579,6 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
                                                                            * (non-blocking) work streams do not wait for it */
                 if (pool->tables) hipFree(pool->tables);
                 pool->tables = NULL;
-                c->k1_held = false; pthread_mutex_unlock(&pool->lock);
                 snprintf(c->err, sizeof(c->err), "K1 tables: out of device memory");
                 return QZD_ERR_HIP;
             }
@@ -540,6 +602,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
     c->k1ev_n = 0;
     c->nbatches = (nchunks + BATCH - 1) / BATCH;
 
+    guard.launched = true;
     HIPCHK(c, hipMemsetAsync(c->d_running, 0, 8, c->st[0]));
     HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, c->st[0]));
     HIPCHK(c, hipEventRecord(c->ev_begin, c->st[0]));
@@ -749,7 +812,6 @@ extern "C" int qzd_sync(qzd_ctx *c)
     if (!c) return QZD_ERR_PARAM;
     hipSetDevice(c->device);
     const hipError_t e0 = hipStreamSynchronize(c->st[0]), e1 = hipStreamSynchronize(c->st[1]), e2 = hipStreamSynchronize(c->st_copy);
-    if (c->k1_held) { c->k1_held = false; pthread_mutex_unlock(&g_k1pool[c->device % QZD_MAX_DEVICES].lock); }   /* the call's K1 launches are done */
     HIPCHK(c, e0); HIPCHK(c, e1); HIPCHK(c, e2);
     for (uint32_t k = 0; k < c->k1ev_n; k++) {      /* harvest the K1 launch timings of the call that just finished */
         float t = 0;
@@ -822,8 +884,18 @@ extern "C" int qzd_last_timing(qzd_ctx *c, float ms[4])
 
 /* every frame_sz bytes of d_src become one LZ4 frame (what one qzCompress call of an LZ4 session emits for
  * src_len <= 64 KB, src/qatzip_sw.c:443-471); frames are written back to back to d_dst */
+static int lz4_compress_frames_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t frame_sz,
+                                    uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len, uint32_t hw_hdr);
 extern "C" int qzd_lz4_compress_frames(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t frame_sz,
                                        uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len)
+{ return lz4_compress_frames_impl(c, d_src, n, frame_sz, d_dst, dst_cap, h_out_len, h_frame_len, 0); }
+/* the same frames behind the header of the reference's hardware path (FLG 0x4C, content size = the chunk's bytes,
+ * src/qatzip_lz4.c:104-132): what a QAT box writes per hw_buff_sz chunk of an LZ4 session */
+extern "C" int qzd_lz4_compress_frames_hw(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t frame_sz,
+                                          uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len)
+{ return lz4_compress_frames_impl(c, d_src, n, frame_sz, d_dst, dst_cap, h_out_len, h_frame_len, 1); }
+static int lz4_compress_frames_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t frame_sz,
+                                    uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len, uint32_t hw_hdr)
 {
     if (!c || !d_dst || (n && !d_src) || !h_out_len) return QZD_ERR_PARAM;
     if (frame_sz == 0 || frame_sz > QZK_LZ4_MAXBLK) { snprintf(c->err, sizeof(c->err), "LZ4 frames above 64 KB (linked blocks) are not produced"); return QZD_ERR_UNSUPPORTED; }
@@ -854,7 +926,7 @@ extern "C" int qzd_lz4_compress_frames(qzd_ctx *c, const uint8_t *d_src, uint64_
     for (uint32_t b = 0; b < nfr; b += batch) {
         const uint32_t bn = nfr - b < batch ? nfr - b : batch;
         const uint64_t boff = (uint64_t)b * frame_sz;
-        hipLaunchKernelGGL(qzk_lz4c_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, bn, c->slots[0], stride, c->d_len + b);
+        hipLaunchKernelGGL(qzk_lz4c_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, bn, c->slots[0], stride, c->d_len + b, hw_hdr);
         hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);
         hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, c->slots[0], stride, c->d_len + b, c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
     }

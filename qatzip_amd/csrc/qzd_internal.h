@@ -27,7 +27,6 @@ struct qzd_ctx {
     /* The tables belong to the DEVICE, not to the context (qzd_k1pool): every session of a process on one GPU parses
      * with the same 4 GiB - a context borrows them from its first K1 launch of a call until qzd_sync(). */
     uint32_t *k1_counter;
-    bool k1_held;                                   /* this context holds its device's table pool */
     uint32_t k1_wgs;                                /* resident pulling WAVES (QZK_K1_WAVES per workgroup, one workgroup per CU) */
     uint32_t batch_chunks;
     /* K1 launch durations (HIP events around every K1 launch, harvested at qzd_sync): bench.py's roofline input */
@@ -61,10 +60,13 @@ struct qzd_ctx {
     return QZD_ERR_HIP; } } while (0)
 
 /* K1's candidate tables, one set per device and process: 65536 x QZK_K1_WAVES entries of 16 bytes per workgroup, grown
- * on demand; `epoch` = next unused chunk epoch (entries are tagged with it; never 0).  lock serialises the K1 launches of
- * different contexts (one big call fills the chip anyway; small calls meet in the coalescing queue, not here). */
+ * on demand; `epoch` = next unused chunk epoch (entries are tagged with it; never 0).  The calls of different contexts
+ * use the pool one after the other ON THE GPU: every call's streams first wait for `busy` (recorded behind the previous
+ * call's last launch), so no host thread ever holds anything across API calls; `lock` only guards these fields while a
+ * call is being enqueued (one big call fills the chip anyway; small calls meet in the coalescing queue, not here). */
 struct qzd_k1pool {
     pthread_mutex_t lock; qzk_bkt *tables; uint32_t tab_wgs; uint32_t epoch;
+    hipEvent_t busy; bool busy_valid;
     /* K1 -> K2 hand-over of a batch (symbols, block marks) and K2's output slots, two sets: the same lifetime as the
      * tables' loan, so they are the device's as well (6.3 GiB at 64 KB chunks, once instead of per session) */
     uint8_t *sym_lc[2]; uint16_t *sym_dist[2]; uint8_t *slots[2]; qzk_lzmeta *meta[2];

@@ -136,7 +136,18 @@ extern "C" int qzd_shard_put(qzd_shard *s, const uint8_t *d_comp, uint64_t comp_
 /* root only: wait until every shard has arrived, fold the trailer (crc32_combine in rank order, ISIZE mod 2^32), write
  * the gzip-ext header with both sizes in front of the payload and the trailer behind it.  *d_stream points at the
  * finished member inside the window (valid until the next stream or qzd_shard_close). */
-extern "C" int qzd_shard_finish(qzd_shard *s, uint32_t seq, double timeout_s, uint8_t **d_stream, uint64_t *stream_len,
+/* the member's 24-byte gzip-ext header with both sizes (src/qatzip_sw.c:61-75,158-166; XFL follows the level as zlib's own
+ * gzip header does: 4 = fastest, 2 = best, 0 otherwise) and its trailer */
+static void member_frame(unsigned char hdr[24], unsigned char tr[8], int level, uint64_t raw, uint64_t comp, uint32_t crc)
+{
+    static const unsigned char h0[24] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0, 'Q', 'Z', 8, 0};
+    memcpy(hdr, h0, 24);
+    hdr[8] = level == 9 ? 2 : level < 2 ? 4 : 0;
+    for (int i = 0; i < 4; i++) { hdr[16 + i] = (unsigned char)(raw >> (8 * i)); hdr[20 + i] = (unsigned char)(comp >> (8 * i)); }
+    for (int i = 0; i < 4; i++) { tr[i] = (unsigned char)(crc >> (8 * i)); tr[4 + i] = (unsigned char)(raw >> (8 * i)); }
+}
+
+extern "C" int qzd_shard_finish(qzd_shard *s, uint32_t seq, double timeout_s, int level, uint8_t **d_stream, uint64_t *stream_len,
                                 uint32_t *crc_out, uint64_t *raw_total)
 {
     if (!s || s->rank != 0 || !d_stream || !stream_len) return QZD_ERR_PARAM;
@@ -162,14 +173,171 @@ extern "C" int qzd_shard_finish(qzd_shard *s, uint32_t seq, double timeout_s, ui
     }
     free(h);
     if (raw > 0xffffffffull || comp > 0xffffffffull) { snprintf(c->err, sizeof(c->err), "a gzip-ext member holds less than 4 GiB"); return QZD_ERR_PARAM; }
-    /* the header of the software path's GZIP_EXT member (src/qatzip_sw.c:61-75,158-166) with both sizes, and its trailer */
-    unsigned char hdr[24] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0, 'Q', 'Z', 8, 0}, tr[8];
-    for (int i = 0; i < 4; i++) { hdr[16 + i] = (unsigned char)(raw >> (8 * i)); hdr[20 + i] = (unsigned char)(comp >> (8 * i)); }
-    for (int i = 0; i < 4; i++) { tr[i] = (unsigned char)(crc >> (8 * i)); tr[4 + i] = (unsigned char)(raw >> (8 * i)); }
+    unsigned char hdr[24], tr[8];
+    member_frame(hdr, tr, level, raw, comp, crc);
     uint8_t *pay = win_payload(s);
     HIPCHK(c, hipMemcpy(pay - QZD_SHARD_HDR, hdr, 24, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(pay + comp, tr, 8, hipMemcpyHostToDevice));
     *d_stream = pay - QZD_SHARD_HDR; *stream_len = QZD_SHARD_HDR + comp + 8;
+    if (crc_out) *crc_out = crc;
+    if (raw_total) *raw_total = raw;
+    return QZD_OK;
+}
+
+
+/* ------------------------------------------------------------------ the same gather over RCCL
+ *
+ * north_star names RCCL over xGMI for "the trivial gather"; this is it, next to the IPC window above: the 32-byte records
+ * travel as one ncclAllGather, the variable-size shards as one group of ncclSend (every rank but the root) / ncclRecv (the
+ * root, one per rank, each at the offset the records give) on the context's stream - the waits are RCCL's, on the
+ * device, no host polling.  The library is looked up at run time (librccl.so.1 of the ROCm the process runs on): a
+ * single-GPU user of libqatzip_amd.so never loads half a gigabyte of collectives.  bench.py measures both transports
+ * and reports the faster one; a box where RCCL cannot start (ranks sharing a device, no peer access) keeps the window. */
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct qzd_rccl_api {
+    void *so;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*GroupStart)(void);
+    ncclResult_t (*GroupEnd)(void);
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+};
+static qzd_rccl_api g_rccl;
+static pthread_once_t g_rccl_once = PTHREAD_ONCE_INIT;
+static void rccl_load(void)
+{
+    void *so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!so) return;
+#define QZD_SYM(f) *(void **)&g_rccl.f = dlsym(so, "nccl" #f)
+    QZD_SYM(GetUniqueId); QZD_SYM(CommInitRank); QZD_SYM(CommDestroy); QZD_SYM(GroupStart); QZD_SYM(GroupEnd);
+    QZD_SYM(Send); QZD_SYM(Recv); QZD_SYM(AllGather); QZD_SYM(GetErrorString);
+#undef QZD_SYM
+    if (g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.GroupStart && g_rccl.GroupEnd &&
+        g_rccl.Send && g_rccl.Recv && g_rccl.AllGather && g_rccl.GetErrorString) g_rccl.so = so;
+}
+static bool rccl_ready(void) { pthread_once(&g_rccl_once, rccl_load); return g_rccl.so != NULL; }
+
+struct qzd_rccl {
+    qzd_ctx *ctx;
+    uint32_t rank, world;
+    uint64_t cap;
+    ncclComm_t comm;
+    uint8_t *win;                   /* root: [24-byte header | payload cap | 8-byte trailer] */
+    qzd_shard_rec *d_recs;          /* world + 1 records: [0..world) gathered, [world] mine */
+    qzd_shard_rec *h_recs;          /* pinned mirror */
+};
+#define RCCLCHK(c, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    snprintf((c)->err, sizeof((c)->err), "%s -> %s", #call, g_rccl.GetErrorString(r_)); return QZD_ERR_HIP; } } while (0)
+
+extern "C" int qzd_rccl_unique_id(uint8_t id_out[128])
+{
+    if (!id_out) return QZD_ERR_PARAM;
+    if (!rccl_ready()) return QZD_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes in the ABI");
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return QZD_ERR_HIP;
+    memcpy(id_out, &id, 128);
+    return QZD_OK;
+}
+
+extern "C" void qzd_rccl_close(qzd_rccl *s)
+{
+    if (!s) return;
+    hipSetDevice(s->ctx->device);
+    hipDeviceSynchronize();
+    if (s->comm) g_rccl.CommDestroy(s->comm);
+    if (s->win) hipFree(s->win);
+    if (s->d_recs) hipFree(s->d_recs);
+    if (s->h_recs) hipHostFree(s->h_recs);
+    delete s;
+}
+
+/* every rank, with the 128 bytes rank 0 got from qzd_rccl_unique_id(); cap_bytes = payload capacity of the root's buffer */
+extern "C" int qzd_rccl_create(qzd_ctx *c, uint32_t rank, uint32_t world, const uint8_t id[128], uint64_t cap_bytes, qzd_rccl **out)
+{
+    if (!c || !out || !id || world == 0 || rank >= world || world > 4096) return QZD_ERR_PARAM;
+    *out = NULL;
+    if (!rccl_ready()) { snprintf(c->err, sizeof(c->err), "librccl.so.1 not found: %s", dlerror() ? dlerror() : "?"); return QZD_ERR_UNSUPPORTED; }
+    hipSetDevice(c->device);
+    qzd_rccl *s = new (std::nothrow) qzd_rccl();
+    if (!s) return QZD_ERR_HIP;
+    s->ctx = c; s->rank = rank; s->world = world; s->cap = cap_bytes; s->comm = NULL; s->win = NULL; s->d_recs = NULL; s->h_recs = NULL;
+    if (hipMalloc(&s->d_recs, (size_t)(world + 1) * sizeof(qzd_shard_rec)) != hipSuccess ||
+        hipHostMalloc((void **)&s->h_recs, (size_t)(world + 1) * sizeof(qzd_shard_rec), hipHostMallocDefault) != hipSuccess ||
+        (rank == 0 && hipMalloc(&s->win, QZD_SHARD_HDR + cap_bytes + 8 + 256) != hipSuccess)) {
+        snprintf(c->err, sizeof(c->err), "RCCL gather: out of memory");
+        qzd_rccl_close(s); return QZD_ERR_HIP;
+    }
+    ncclUniqueId uid;
+    memcpy(&uid, id, 128);
+    ncclResult_t r = g_rccl.CommInitRank(&s->comm, (int)world, uid, (int)rank);
+    if (r != ncclSuccess) {
+        snprintf(c->err, sizeof(c->err), "ncclCommInitRank(%u of %u on device %d) -> %s", rank, world, c->device, g_rccl.GetErrorString(r));
+        s->comm = NULL; qzd_rccl_close(s); return QZD_ERR_HIP;
+    }
+    *out = s;
+    return QZD_OK;
+}
+
+/* every rank: my shard (raw-deflate stream of my chunk range, its CRC-32) joins the member in the root's HBM.  On the
+ * root *d_stream / *stream_len describe the finished member (valid until the next gather or qzd_rccl_close); the other
+ * ranks get NULL / 0.  Returns when this rank's part is done (its stream is synchronised). */
+extern "C" int qzd_rccl_gather(qzd_rccl *s, const uint8_t *d_comp, uint64_t comp_len, uint64_t raw_len, uint32_t crc32, int level,
+                               uint8_t **d_stream, uint64_t *stream_len, uint32_t *crc_out, uint64_t *raw_total)
+{
+    if (!s || (comp_len && !d_comp)) return QZD_ERR_PARAM;
+    qzd_ctx *c = s->ctx;
+    hipSetDevice(c->device);
+    hipStream_t st = c->st[0];
+    qzd_shard_rec *mine = s->h_recs + s->world;
+    mine->raw_len = raw_len; mine->comp_len = comp_len; mine->crc = crc32; mine->seq = 1; mine->done = 0; mine->pad = 0;
+    HIPCHK(c, hipMemcpyAsync(s->d_recs + s->world, mine, sizeof(*mine), hipMemcpyHostToDevice, st));
+    RCCLCHK(c, g_rccl.AllGather(s->d_recs + s->world, s->d_recs, sizeof(qzd_shard_rec), ncclUint8, s->comm, st));
+    HIPCHK(c, hipMemcpyAsync(s->h_recs, s->d_recs, (size_t)s->world * sizeof(qzd_shard_rec), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    uint64_t raw = 0, comp = 0, my_off = 0; uint32_t crc = 0;
+    for (uint32_t r = 0; r < s->world; r++) {
+        if (r == s->rank) my_off = comp;
+        crc = r == 0 ? s->h_recs[r].crc : qzd_crc32_combine(crc, s->h_recs[r].crc, s->h_recs[r].raw_len);
+        raw += s->h_recs[r].raw_len; comp += s->h_recs[r].comp_len;
+    }
+    if (raw > 0xffffffffull || comp > 0xffffffffull) { snprintf(c->err, sizeof(c->err), "a gzip-ext member holds less than 4 GiB"); return QZD_ERR_PARAM; }
+    if (comp > s->cap) { snprintf(c->err, sizeof(c->err), "RCCL gather: root buffer too small"); return QZD_ERR_DSTCAP; }
+    (void)my_off;
+    if (s->rank == 0) {
+        uint8_t *pay = s->win + QZD_SHARD_HDR;
+        if (comp_len) HIPCHK(c, hipMemcpyAsync(pay, d_comp, comp_len, hipMemcpyDeviceToDevice, st));
+        RCCLCHK(c, g_rccl.GroupStart());
+        uint64_t off = s->h_recs[0].comp_len;
+        for (uint32_t r = 1; r < s->world; r++) {
+            if (s->h_recs[r].comp_len) RCCLCHK(c, g_rccl.Recv(pay + off, s->h_recs[r].comp_len, ncclUint8, (int)r, s->comm, st));
+            off += s->h_recs[r].comp_len;
+        }
+        RCCLCHK(c, g_rccl.GroupEnd());
+        unsigned char *ht = (unsigned char *)(s->h_recs + s->world);     /* pinned: 32 bytes = header 24 + trailer 8 */
+        member_frame(ht, ht + 24, level, raw, comp, crc);
+        HIPCHK(c, hipMemcpyAsync(s->win, ht, 24, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(pay + comp, ht + 24, 8, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (d_stream) *d_stream = s->win;
+        if (stream_len) *stream_len = QZD_SHARD_HDR + comp + 8;
+    } else {
+        if (comp_len) {
+            RCCLCHK(c, g_rccl.GroupStart());
+            RCCLCHK(c, g_rccl.Send(d_comp, comp_len, ncclUint8, 0, s->comm, st));
+            RCCLCHK(c, g_rccl.GroupEnd());
+        }
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (d_stream) *d_stream = NULL;
+        if (stream_len) *stream_len = 0;
+    }
     if (crc_out) *crc_out = crc;
     if (raw_total) *raw_total = raw;
     return QZD_OK;

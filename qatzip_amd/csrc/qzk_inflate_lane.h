@@ -342,9 +342,11 @@ QZ_DEV void qzk_tok_bytes(qzk_tok_out *O, uint64_t v, uint32_t k)
     }
     O->lrun += k;
 }
+QZ_DEV void qzk_tok_round_flush(qzk_tok_out *O);
 QZ_DEV void qzk_tok_seq(qzk_tok_out *O, uint32_t mlen, uint32_t dm1)
 {
     if (!O->count_only) {
+        if (O->sk == 8) qzk_tok_round_flush(O);       /* never a ninth staged sequence (callers flush in time; belt and braces) */
         const uint64_t w = (uint64_t)O->lrun | (uint64_t)mlen << 32 | (uint64_t)dm1 << 48;
         const uint32_t k = O->sk;
         O->s0 = k == 0 ? w : O->s0; O->s1 = k == 1 ? w : O->s1; O->s2 = k == 2 ? w : O->s2; O->s3 = k == 3 ? w : O->s3;
@@ -542,6 +544,10 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
                 /* a stored block never enters the literal stream: phase B copies it straight from the input.  The
                  * sequences so far become a piece of their own (their pending literals end it) */
                 if (O.lrun) qzk_tok_seq(&O, 0u, 0u);
+                /* that sequence leaves now: the staging registers hold eight, a round of the hot loop may add eight, and
+                 * one left over from here would make nine (the ninth was dropped and the round's flush then wrote the
+                 * other eight one slot too low: wrong bytes with status 0 behind literals + stored block + eight matches) */
+                qzk_tok_round_flush(&O);
                 if (O.nseq > piece_seq0) {
                     qzk_chain_el e; e.sub = 0; e.seq_first = piece_seq0; e.seq_count = O.nseq - piece_seq0; e.lit_first = piece_lit0; e.lrun_skip = 0;
                     C->el[nel++] = e;

@@ -269,8 +269,11 @@ QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint3
 
 /* K4: one LZ4 frame (<= 64 KB of content, one independent block) per wave, written to its slot:
  * LZ4F_compressFrame with {contentChecksum, contentSize, autoFlush, level < 3}. */
+/* hw_hdr: the header the reference's HARDWARE path puts in front of a chunk's frame (qzLZ4HeaderGen, src/qatzip_lz4.c:104-132):
+ * FLG 0x4C - version 1, blocks NOT marked independent, content size always present, content checksum - instead of
+ * liblz4's 0x6C (or 0x64 for an empty call); everything behind the header checksum byte is the same frame */
 QZ_KERNEL_MAX(64) qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
-                          uint8_t *slots, uint32_t stride, uint32_t *out_len)
+                          uint8_t *slots, uint32_t stride, uint32_t *out_len, uint32_t hw_hdr)
 {
     QZ_LDS uint16_t table[QZK_LZ4_HASHSZ];
     QZ_LDS uint32_t slot[1024];
@@ -285,12 +288,12 @@ QZ_KERNEL_MAX(64) qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t
     /* frame header: magic, FLG (v1 | independent | [content size] | content checksum), BD 64 KB */
     if (lane == 0) {
         o[0] = 0x04; o[1] = 0x22; o[2] = 0x4d; o[3] = 0x18;
-        o[4] = (uint8_t)((1u << 6) | (1u << 5) | (n ? 1u << 3 : 0) | (1u << 2));
+        o[4] = hw_hdr ? (uint8_t)0x4C : (uint8_t)((1u << 6) | (1u << 5) | (n ? 1u << 3 : 0) | (1u << 2));
         o[5] = 4u << 4;
-        if (n) { o[6] = (uint8_t)n; o[7] = (uint8_t)(n >> 8); o[8] = (uint8_t)(n >> 16); o[9] = (uint8_t)(n >> 24); o[10] = o[11] = o[12] = o[13] = 0; }
+        if (n || hw_hdr) { o[6] = (uint8_t)n; o[7] = (uint8_t)(n >> 8); o[8] = (uint8_t)(n >> 16); o[9] = (uint8_t)(n >> 24); o[10] = o[11] = o[12] = o[13] = 0; }
     }
     qz_wave_sync();
-    pos = n ? 14 : 6;
+    pos = (n || hw_hdr) ? 14 : 6;
     {
         uint32_t hc = qzk_wave_xxh32(o + 4, pos - 4, lane);
         if (lane == 0) o[pos] = (uint8_t)(hc >> 8);

@@ -258,7 +258,14 @@ int sim_inflate(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_i
 int sim_lz4c(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, uint32_t stride, uint32_t *out_len)
 {
     uint32_t nframes = n ? (uint32_t)((n + frame_sz - 1) / frame_sz) : 1;
-    sim::launch(nframes, 64, 0, [&] { qzk_lz4c_kernel(src, n, frame_sz, nframes, slots, stride, out_len); });
+    sim::launch(nframes, 64, 0, [&] { qzk_lz4c_kernel(src, n, frame_sz, nframes, slots, stride, out_len, 0); });
+    return (int)nframes;
+}
+/* the same frames behind the hardware path's header (FLG 0x4C, content size always there) */
+int sim_lz4c_hw(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, uint32_t stride, uint32_t *out_len)
+{
+    uint32_t nframes = n ? (uint32_t)((n + frame_sz - 1) / frame_sz) : 1;
+    sim::launch(nframes, 64, 0, [&] { qzk_lz4c_kernel(src, n, frame_sz, nframes, slots, stride, out_len, 1); });
     return (int)nframes;
 }
 

@@ -827,3 +827,38 @@ def test_pinned_destination_receives_the_stream_directly(fmt):
     assert back[0] == A.QZ_OK and back[2] == src
     L.qzFree(psrc); L.qzFree(pdst)
     s.close()
+
+
+def test_async_requests_of_a_hardware_framing_session_keep_their_framing():
+    """advisor (round 2): qzCompress2 requests of a qzamd_set_hw_framing session that wait in the queue together must come
+    out framed exactly like one running alone - one complete member per chunk, XFL 0, OS 255 - not in the software path's
+    framing the coalesced launch writes"""
+    import threading
+    L = A.lib()
+    L.qzamd_set_hw_framing.argtypes = [C.c_void_p, C.c_int]
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, 65536)
+    assert L.qzamd_set_hw_framing(C.byref(s.s), 1) == A.QZ_OK
+    srcs = [datagen.gen_bytes("silesia", n, 70 + i) for i, n in enumerate((65536, 3 * 65536 + 5, 2000, 131072, 65536, 70000, 4096, 65536))]
+    alone = [s.compress(x, 1)[2] for x in srcs]                         # one synchronous call each (compress_deflate_hw)
+    bufs_in = [C.create_string_buffer(x, len(x)) for x in srcs]
+    bufs_out = [C.create_string_buffer(len(x) * 9 // 8 + 8192) for x in srcs]
+    results = [A.QzResult() for _ in srcs]
+    done, count = threading.Event(), []
+
+    def on_done(res):
+        count.append(1)
+        if len(count) == len(srcs):
+            done.set()
+        return 0
+    cb = A.QzAsyncCallback(on_done)
+    for i, x in enumerate(srcs):                                        # submitted back to back: they meet in the queue
+        results[i].cb_tag = i + 1; results[i].src_len = len(x); results[i].dest_len = len(bufs_out[i])
+        assert L.qzCompress2(C.byref(s.s), bufs_in[i], bufs_out[i], cb, C.byref(results[i])) == A.QZ_OK
+    assert done.wait(120)
+    for i, x in enumerate(srcs):
+        r = results[i]
+        assert r.status == A.QZ_OK and r.src_len == len(x)
+        got = bufs_out[i].raw[:r.dest_len]
+        assert got == alone[i], (i, len(got), len(alone[i]))
+        assert got[8] == 0 and got[9] == 255
+    s.close()

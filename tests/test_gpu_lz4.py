@@ -103,3 +103,46 @@ def test_lz4_throughput_smoke(ctx):
     print("lz4 32 MiB: compress %.1f ms (%.2f GB/s), decompress %.1f ms (%.2f GB/s), ratio %.3f"
           % ((t1 - t0) * 1e3, base.size / (t1 - t0) / 1e9, (t3 - t2) * 1e3, base.size / (t3 - t2) / 1e9, total / base.size))
     assert total < base.size
+
+
+def test_lz4_session_in_hardware_path_framing():
+    """qzamd_set_hw_framing on an LZ4 session: one frame per hw_buff_sz chunk behind qzLZ4HeaderGen's header (FLG 0x4C,
+    content size = consumed, src/qatzip_lz4.c:104-132) with qzLZ4FooterGen's end mark + XXH32 (:134-143); hw_buff_sz above
+    64 KB gives each chunk's frame linked 64 KB blocks.  liblz4-compatible: the session's own decoder (and the oracle's)
+    read it back; calls below input_sz_thrshold keep the software framing (src/qatzip.c:1934-1947)."""
+    import ctypes as C
+    L = A.lib()
+    L.qzamd_set_hw_framing.argtypes = [C.c_void_p, C.c_int]
+    for hw in (65536, 16384, 131072):
+        s = A.Session(lz4=True, hw_buff_sz=hw)
+        assert L.qzamd_set_hw_framing(C.byref(s.s), 1) == A.QZ_OK
+        for kind, n in (("silesia", 5 * hw + 777), ("rand", 2 * hw), ("text", hw), ("allA", 3 * hw + 1)):
+            src = datagen.gen_bytes(kind, n, 61)
+            rc, used, out, _ = s.compress(src, 1)
+            assert rc == A.QZ_OK and used == n, (hw, kind, rc)
+            exp = b""
+            for off in range(0, n, hw):
+                piece = src[off:off + hw]
+                sw = O.sw_compress("LZ4", piece, 65536, 1, cap=len(piece) + len(piece) // 255 + 4096)[2]
+                desc = bytes([0x4C, 0x40]) + len(piece).to_bytes(8, "little")
+                hdr = bytes([0x04, 0x22, 0x4D, 0x18]) + desc + bytes([(O.lib().qzo_xxh32(desc, len(desc), 0) >> 8) & 0xff])
+                # a chunk above 64 KB is liblz4's own linked frame (its header is already this one); up to 64 KB only the
+                # header differs from the software frame (0x6C: one independent block)
+                assert len(piece) <= 65536 or sw[:15] == hdr
+                exp += hdr + sw[15:]
+            assert out == exp, (hw, kind, n, len(out), len(exp))
+            rc, cused, back = s.decompress(out, n + 64)
+            assert rc == A.QZ_OK and back == src and cused == len(out)
+            assert O.sw_decompress("LZ4", out, n + 64)[2] == src
+        small = datagen.gen_bytes("text", 1000, 3)
+        assert s.compress(small, 1)[2] == O.sw_compress("LZ4", small, 65536, 1, cap=2000)[2]
+        # a destination for two frames only: whole frames, QZ_BUF_ERROR with progress
+        src = datagen.gen_bytes("text", 4 * hw, 5)
+        full = s.compress(src, 1)[2]
+        first_two = 0
+        for off in (0, hw):
+            piece = src[off:off + hw]
+            first_two += len(O.sw_compress("LZ4", piece, 65536, 1, cap=len(piece) + 4096)[2])
+        rc, used, out, _ = s.compress(src, 1, cap=first_two + 5)
+        assert rc == A.QZ_BUF_ERROR and used == 2 * hw and out == full[:first_two]
+        s.close()

@@ -355,3 +355,80 @@ def test_wide_window_parse_is_exact(sim):
                 out = C.create_string_buffer(cap); ol = C.c_uint64(0); crcs = np.zeros(nch, np.uint32)
                 sim.sim_deflate_wide(src, n, chunk, last, out, C.byref(ol), crcs.ctypes.data)
                 assert out.raw[:ol.value] == O.sw_compress("RAW", src, chunk, 1, last=last, cap=cap)[2], (kind, n, chunk, last)
+
+
+def _fixed_block_bits():
+    """a tiny fixed-Huffman DEFLATE writer (RFC 1951 3.2.6) for hand-built streams"""
+    class W:
+        def __init__(self):
+            self.acc = 0; self.n = 0; self.out = bytearray()
+        def bits(self, v, k):                      # LSB first (header fields, extra bits)
+            self.acc |= v << self.n; self.n += k
+            while self.n >= 8:
+                self.out.append(self.acc & 0xff); self.acc >>= 8; self.n -= 8
+        def code(self, c, k):                      # Huffman codes go MSB first
+            self.bits(int(format(c, "0%db" % k)[::-1], 2), k)
+        def lit(self, b):
+            self.code(0x30 + b, 8) if b < 144 else self.code(0x190 + b - 144, 9)
+        def eob(self):
+            self.code(0, 7)
+        def match3(self, dist_code):               # length 3 = symbol 257 (7 bits), 5-bit distance code, no extra bits
+            self.code(1, 7); self.code(dist_code, 5)
+        def align(self):
+            if self.n: self.bits(0, 8 - self.n)
+    return W()
+
+
+def test_lane_inflate_stored_block_between_literals_and_matches(sim):
+    """Advisor finding (round 2, high): literals, then a stored block, then eight or more matches in one round of phase A left
+    nine sequences for eight staging slots - the last one was dropped and the output was wrong with status 0."""
+    sim.sim_inflate_lane.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    seg_dt = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
+    res_dt = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
+    for nlit, nstored, nmatch in ((400, 100, 40), (1, 100, 8), (5, 7, 9), (37, 65535, 64), (3, 1, 8)):
+        w = _fixed_block_bits()
+        w.bits(0, 1); w.bits(1, 2)
+        for i in range(nlit):
+            w.lit(97 + i % 23)
+        w.eob()
+        w.bits(0, 1); w.bits(0, 2); w.align()
+        w.bits(nstored, 16); w.bits(nstored ^ 0xffff, 16)
+        w.out += bytes((i * 7 + 3) & 0xff for i in range(nstored))
+        w.bits(1, 1); w.bits(1, 2)
+        for i in range(nmatch):
+            w.match3(i % 4)
+        w.eob(); w.align()
+        comp = bytes(w.out)
+        exp = zlib.decompressobj(-15).decompress(comp)
+        assert len(exp) == nlit + nstored + 3 * nmatch
+        cbuf = np.frombuffer(comp + b"\0" * 64, np.uint8).copy(); obuf = np.zeros(len(exp) + 64, np.uint8)
+        sa = np.array([(0, 0, len(comp), len(exp), 0, 0)], dtype=seg_dt); res = np.zeros(1, res_dt)
+        sim.sim_inflate_lane(cbuf.ctypes.data, obuf.ctypes.data, sa.ctypes.data, res.ctypes.data, 1)
+        assert int(res["status"][0]) >= 0 and int(res["out_len"][0]) == len(exp), (nlit, nstored, nmatch)
+        assert bytes(obuf[:len(exp)]) == exp, (nlit, nstored, nmatch)
+
+
+def _lz4_hw_frame(piece, sw_frame):
+    """what the reference's hardware path puts around a chunk (src/qatzip_lz4.c:104-143): qzLZ4HeaderGen's 15 bytes - magic,
+    FLG 0x4C, BD 64 KB, content size = the chunk's bytes, (XXH32(FLG..size) >> 8) & 0xff - then the block(s), then
+    qzLZ4FooterGen's end mark + XXH32 of the chunk; the part behind the header is the software frame's"""
+    desc = bytes([0x4C, 0x40]) + len(piece).to_bytes(8, "little")
+    return bytes([0x04, 0x22, 0x4D, 0x18]) + desc + bytes([(O.lib().qzo_xxh32(desc, len(desc), 0) >> 8) & 0xff]) + sw_frame[15:]
+
+
+def test_lz4_hardware_path_header(sim):
+    """K4 with hw_hdr: a frame per chunk behind the header qzLZ4HeaderGen writes (FLG 0x4C, content size, header checksum),
+    expectation built from the reference's generator + the oracle's frame body"""
+    sim.sim_lz4c_hw.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    for kind in ("silesia", "rand", "runs", "allA"):
+        for n, fs in ((65536, 65536), (200000, 65536), (70000, 16384), (1024, 65536)):
+            src = datagen.gen_bytes(kind, n, 43)
+            nfr = max(1, (n + fs - 1) // fs)
+            stride = (fs + 15 + 4 + 8 + 64 + 15) & ~15
+            slots = np.zeros(nfr * stride, np.uint8); lens = np.zeros(nfr, np.uint32)
+            sim.sim_lz4c_hw(src, n, fs, slots.ctypes.data, stride, lens.ctypes.data)
+            for i in range(nfr):
+                piece = src[i * fs:(i + 1) * fs]
+                sw = O.sw_compress("LZ4", piece, 65536, 1, cap=len(piece) + len(piece) // 255 + 200)[2]
+                got = bytes(slots[i * stride:i * stride + int(lens[i])])
+                assert got == _lz4_hw_frame(piece, sw), (kind, n, fs, i)
