@@ -175,6 +175,7 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) QZD_CREATE_FAIL;
         const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+        c->cus = cus;
         c->k1_wgs = QZD_K1_WGS_PER_CU * cus;
         const char *e = getenv("QATZIP_AMD_K1_WGS");
         unsigned a = 0;
@@ -440,14 +441,15 @@ static int deflate_lazy_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
                              uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks, const uint32_t *cdesc);
 
 #include "qzk_deflate_wide.h"
-/* EXPERIMENTAL, QATZIP_AMD_K1=wide (level 1, chunks of at most 64 KB): K1w - one chunk per 1024-thread workgroup, the
- * candidate table on chip (qzk_deflate_wide.h) - in place of K1; then K2 / CRC / scan / gather as launches of their own.
- * One batch = the whole call, on one stream.  Not the product path: it exists to be measured. */
+static uint64_t *g_wide_prof; static uint32_t g_wide_prof_cap, g_wide_prof_n;     /* QATZIP_AMD_WIDE_PROF=1: phase clocks of the last call */
+/* Level 1, chunks of at most 64 KB, launches of at most one chunk per CU (or QATZIP_AMD_K1=wide): K1w - one chunk per
+ * 1024-thread workgroup, everything it looks up on chip (qzk_deflate_wide.h) - in place of K1; then K2 / CRC / scan /
+ * gather as launches of their own.  One batch = the whole call, on one stream. */
 static int deflate_wide_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint32_t chunk_sz, int last,
                              uint8_t *d_dst, uint64_t dst_cap, uint32_t nchunks, const uint32_t *cdesc)
 {
     const uint32_t stride = slot_stride_for(chunk_sz);
-    const uint32_t wgs = nchunks < 256u ? nchunks : 256u;
+    const uint32_t wgs = nchunks < c->cus ? nchunks : c->cus;
     const size_t symb = ((size_t)nchunks * chunk_sz + 511) & ~(size_t)255;
     const size_t metab = ((size_t)nchunks * sizeof(qzk_lzmeta) + 255) & ~(size_t)255;
     const size_t slotb = ((size_t)nchunks * stride + 255) & ~(size_t)255;
@@ -475,6 +477,12 @@ static int deflate_wide_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     qzk_lzmeta *meta = (qzk_lzmeta *)pb; pb += metab;
     uint8_t *slots = pb; pb += slotb;
     uint16_t *prevtab = (uint16_t *)pb;
+    uint64_t *xprof = NULL;
+    if (const char *e = getenv("QATZIP_AMD_WIDE_PROF")) if (e[0] == '1') {
+        if (nchunks > g_wide_prof_cap) { hipDeviceSynchronize(); if (g_wide_prof) hipFree(g_wide_prof); g_wide_prof = NULL; g_wide_prof_cap = 0;
+            if (hipMalloc(&g_wide_prof, (size_t)nchunks * 128) == hipSuccess) g_wide_prof_cap = nchunks; }
+        if (g_wide_prof) { xprof = g_wide_prof; g_wide_prof_n = nchunks; hipMemsetAsync(xprof, 0, (size_t)nchunks * 128, c->st[0]); }
+    }
     hipStream_t st = c->st[0];
     c->last_nchunks = nchunks; c->nbatches = 1; c->k1ev_n = 0;
     HIPCHK(c, hipMemsetAsync(c->d_running, 0, 8, st));
@@ -483,8 +491,8 @@ static int deflate_wide_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
     HIPCHK(c, hipEventRecord(c->ev_begin, st));
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
     HIPCHK(c, hipEventRecord(c->k1ev[0][0], st));
-    hipLaunchKernelGGL(qzk_lz77_wide_kernel, dim3(wgs), dim3(QZW_W), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist, meta,
-                       prevtab, c->k1_counter, cdesc);
+    hipLaunchKernelGGL(qzk_lz77_wide_kernel, dim3(wgs), dim3(QZX_W), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist, meta,
+                       prevtab, c->k1_counter, cdesc, xprof);
     HIPCHK(c, hipEventRecord(c->k1ev[0][1], st)); c->k1ev_chunks[0] = nchunks; c->k1ev_n = 1;
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
     hipLaunchKernelGGL(qzk_huff_kernel, dim3(nchunks), dim3(QZK_HW), 0, st, d_src, n, chunk_sz, nchunks, sym_lc, sym_dist,
@@ -528,8 +536,14 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         const char *lz = getenv("QATZIP_AMD_LAZY");
         if (level >= 4 && !(lz && lz[0] == '0')) return deflate_lazy_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
         if (level != 1 || (force && force[0] == 'l')) return deflate_lane_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
+        /* Two parse kernels for level 1.  A call that fills the chip gives every wave a chunk of its own (K1,
+         * qzk_lz77_pull_kernel: 4096 chunks in flight hide each other's latency; throughput).  A launch of at most one chunk
+         * per CU - a lone qzCompress of a block or two, the requests a few threads have in flight - gives every chunk a
+         * whole CU instead (K1w, qzk_lz77_wide_kernel: the chunk, prev[] and the window's work on chip; latency: a chunk
+         * takes about half the time one wave needs).  QATZIP_AMD_K1=wide / pull forces one of them. */
         const char *k1 = getenv("QATZIP_AMD_K1");
-        if (k1 && k1[0] == 'w' && chunk_sz <= 65536) {
+        const bool force_wide = k1 && k1[0] == 'w', force_pull = k1 && k1[0] == 'p';
+        if (chunk_sz <= 65536 && (force_wide || (!force_pull && nchunks <= c->cus))) {
             if (h_src && n) HIPCHK(c, hipMemcpy((void *)d_src, h_src, n, hipMemcpyHostToDevice));
             return deflate_wide_path(c, d_src, n, chunk_sz, last, d_dst, dst_cap, nchunks, cdesc);
         }
@@ -991,6 +1005,17 @@ extern "C" int qzd_lz4_decompress_frames(qzd_ctx *c, const uint8_t *d_comp, uint
     float t = 0;
     if (hipEventElapsedTime(&t, c->ev_begin, c->ev_end) == hipSuccess) c->ms[3] = t;
     return QZD_OK;
+}
+
+/* developer aid (QATZIP_AMD_WIDE_PROF=1): the phase clocks the workgroup-per-chunk parse left for the chunks of the last
+ * call, 16 words per chunk (qzk_deflate_wide.h); returns the number of chunks copied */
+extern "C" int qzd_debug_wide_prof(qzd_ctx *c, uint64_t *h_out, uint32_t nchunks)
+{
+    if (!c || !h_out || !g_wide_prof) return 0;
+    hipSetDevice(c->device);
+    if (nchunks > g_wide_prof_n) nchunks = g_wide_prof_n;
+    if (hipMemcpy(h_out, g_wide_prof, (size_t)nchunks * 128, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return (int)nchunks;
 }
 
 #ifdef QZK_PROF

@@ -20,6 +20,7 @@ struct qzd_ctx {
     hipStream_t st[QZD_NBUF];
     hipStream_t st_copy; hipEvent_t cp_ev[QZD_NBUF + 1];   /* host input arrives batch by batch while the previous batch is parsed */
     hipEvent_t done[QZD_NBUF], k1done[QZD_NBUF];
+    uint32_t cus;                                   /* compute units of the device */
     /* output slots of the LZ4 frame kernel (the deflate pipeline's scratch lives in the device's pool, qzd_k1pool) */
     uint8_t *slots[QZD_NBUF];
     /* K1 (persistent pull kernel): one candidate table (65536 x QZK_K1_WAVES entries of 16 bytes = 16 MiB) per resident

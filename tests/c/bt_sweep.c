@@ -11,6 +11,13 @@
  *   bt_sweep perfmt <mbytes> <block> <loops> <threads>   the harness' -t: every thread its own session and its own
  *                                             <mbytes> of data, one qzCompress / qzDecompress per block, started together
  *                                             (test/main.c:2175-2202), rates summed as run_perf_test.sh:111-123 does
+ *   bt_sweep run [-i file] [-t threads] [-l loops] [-v] [-C hw_buff_sz] [-b block_size] [-D comp|decomp|both]
+ *                [-O deflate|gzip|gzipext|deflate_4B|lz4|zlib] [-L level] [-p pinned|common] [-s bytes]
+ *                                             the harness' own option letters (test/main.c:6319-6374, its test mode 4): every
+ *                                             thread sets a session up with these parameters and runs `loops` passes of
+ *                                             compress (one qzCompress per block, or one call for the whole buffer when -b is
+ *                                             not given) and / or decompress over the file (or -s bytes of generated runs,
+ *                                             512 KB by default as in the harness); -v compares what came back
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -171,11 +178,155 @@ static int perfmt(unsigned mb, unsigned block, unsigned loops, unsigned nthr)
     return bad ? 1 : 0;
 }
 
+/* ---- run: the reference harness' option letters ---- */
+#include <unistd.h>
+typedef struct {
+    const unsigned char *data; size_t size; unsigned hw, block, loops, level, id; int dir, fmt, verify, pinned;
+    double secs; int rc; pthread_barrier_t *bar;
+} run_arg;
+enum { RUN_BOTH, RUN_COMP, RUN_DECOMP };
+enum { FMT_RAW, FMT_GZIP, FMT_GZIPEXT, FMT_4B, FMT_LZ4, FMT_ZLIB };
+
+static int run_setup(QzSession_T *sess, const run_arg *a)
+{
+    if (a->fmt == FMT_LZ4) {
+        QzSessionParamsLZ4_T p;
+        if (qzGetDefaultsLZ4(&p) != QZ_OK) return -1;
+        p.common_params.hw_buff_sz = a->hw; p.common_params.comp_lvl = a->level;
+        return qzSetupSessionLZ4(sess, &p);
+    }
+    if (a->fmt == FMT_ZLIB) {
+        QzSessionParamsDeflateExt_T p;
+        if (qzGetDefaultsDeflateExt(&p) != QZ_OK) return -1;
+        p.deflate_params.data_fmt = QZ_DEFLATE_RAW; p.zlib_format = 1;
+        p.deflate_params.common_params.hw_buff_sz = a->hw; p.deflate_params.common_params.comp_lvl = a->level;
+        return qzSetupSessionDeflateExt(sess, &p);
+    }
+    {
+        QzSessionParamsDeflate_T p;
+        if (qzGetDefaultsDeflate(&p) != QZ_OK) return -1;
+        p.data_fmt = a->fmt == FMT_RAW ? QZ_DEFLATE_RAW : a->fmt == FMT_GZIP ? QZ_DEFLATE_GZIP : a->fmt == FMT_4B ? QZ_DEFLATE_4B : QZ_DEFLATE_GZIP_EXT;
+        p.common_params.hw_buff_sz = a->hw; p.common_params.comp_lvl = a->level;
+        return qzSetupSessionDeflate(sess, &p);
+    }
+}
+
+static void *run_body(void *vp)
+{
+    run_arg *a = (run_arg *)vp;
+    QzSession_T sess;
+    const size_t block = a->block ? a->block : a->size, nblk = a->size ? (a->size + block - 1) / block : 1;
+    size_t i, off, cap_total = 0;
+    unsigned *csz = malloc(nblk * sizeof(unsigned)), *cof = malloc(nblk * sizeof(unsigned)), l;
+    unsigned char *src = NULL, *comp = NULL, *back = NULL;
+    double t0;
+    memset(&sess, 0, sizeof(sess));
+    a->rc = 2; a->secs = 0;
+    if (run_setup(&sess, a) >= 0 && csz && cof) {
+        const unsigned cap = qzMaxCompressedLength(block < a->size ? block : a->size, &sess) + 64;
+        cap_total = (size_t)cap * nblk;
+        src = qzMalloc(a->size ? a->size : 1, 0, a->pinned ? PINNED_MEM : COMMON_MEM);
+        comp = qzMalloc(cap_total, 0, a->pinned ? PINNED_MEM : COMMON_MEM);
+        back = qzMalloc(a->size ? a->size : 1, 0, a->pinned ? PINNED_MEM : COMMON_MEM);
+        if (src && comp && back) {
+            memcpy(src, a->data, a->size);
+            a->rc = 0;
+            /* -D decomp needs something to decompress: one untimed compress pass (the harness does the same) */
+            for (i = 0, off = 0; i < nblk && a->rc == 0; i++, off += block) {
+                unsigned sl = (unsigned)(a->size - off < block ? a->size - off : block), dl = cap;
+                cof[i] = (unsigned)(i * cap);
+                if (qzCompress(&sess, src + off, &sl, comp + cof[i], &dl, 1) != QZ_OK) a->rc = 3;
+                csz[i] = dl;
+            }
+        }
+    }
+    pthread_barrier_wait(a->bar);
+    t0 = now();
+    for (l = 0; l < a->loops && a->rc == 0; l++) {
+        if (a->dir != RUN_DECOMP)
+            for (i = 0, off = 0; i < nblk && a->rc == 0; i++, off += block) {
+                unsigned sl = (unsigned)(a->size - off < block ? a->size - off : block), dl = (unsigned)(cap_total / nblk);
+                if (qzCompress(&sess, src + off, &sl, comp + cof[i], &dl, 1) != QZ_OK) a->rc = 3;
+                csz[i] = dl;
+            }
+        if (a->dir != RUN_COMP)
+            for (i = 0, off = 0; i < nblk && a->rc == 0; i++, off += block) {
+                unsigned cl = csz[i], ol = (unsigned)(a->size - off < block ? a->size - off : block);
+                if (qzDecompress(&sess, comp + cof[i], &cl, back + off, &ol) != QZ_OK) a->rc = 4;
+            }
+        if (a->verify && a->dir != RUN_COMP && a->rc == 0 && memcmp(src, back, a->size)) a->rc = 5;
+    }
+    a->secs = now() - t0;
+    qzTeardownSession(&sess);
+    qzFree(src); qzFree(comp); qzFree(back); free(csz); free(cof);
+    return NULL;
+}
+
+static int run(int argc, char **argv)
+{
+    run_arg proto; pthread_t th[256]; run_arg arg[256]; pthread_barrier_t bar;
+    const char *file = NULL; unsigned nthr = 1, t; size_t gen = 512 * 1024; unsigned char *data; int c, bad = 0; double sum = 0;
+    memset(&proto, 0, sizeof(proto));
+    proto.hw = 64 * 1024; proto.block = 0; proto.loops = 2; proto.level = 1; proto.dir = RUN_BOTH; proto.fmt = FMT_GZIPEXT;
+    optind = 2;
+    while ((c = getopt(argc, argv, "i:t:l:vC:b:D:O:L:p:s:")) != -1) {
+        switch (c) {
+        case 'i': file = optarg; break;
+        case 't': nthr = (unsigned)atoi(optarg); break;
+        case 'l': proto.loops = (unsigned)atoi(optarg); break;
+        case 'v': proto.verify = 1; break;
+        case 'C': proto.hw = (unsigned)atoi(optarg); break;
+        case 'b': proto.block = (unsigned)atoi(optarg); break;
+        case 'L': proto.level = (unsigned)atoi(optarg); break;
+        case 's': gen = (size_t)atol(optarg); break;
+        case 'p': proto.pinned = !strcmp(optarg, "pinned"); break;
+        case 'D': proto.dir = !strcmp(optarg, "comp") ? RUN_COMP : !strcmp(optarg, "decomp") ? RUN_DECOMP : RUN_BOTH; break;
+        case 'O': proto.fmt = !strcmp(optarg, "deflate") ? FMT_RAW : !strcmp(optarg, "gzip") ? FMT_GZIP : !strcmp(optarg, "deflate_4B") ? FMT_4B :
+                              !strcmp(optarg, "lz4") ? FMT_LZ4 : !strcmp(optarg, "zlib") ? FMT_ZLIB : FMT_GZIPEXT; break;
+        default: return 64;
+        }
+    }
+    if (nthr < 1 || nthr > 256 || proto.loops < 1) return 64;
+    if (file) {
+        FILE *f = fopen(file, "rb"); long sz;
+        if (!f) { perror(file); return 66; }
+        fseek(f, 0, SEEK_END); sz = ftell(f); fseek(f, 0, SEEK_SET);
+        data = malloc(sz > 0 ? (size_t)sz : 1);
+        if (!data || fread(data, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return 66; }
+        fclose(f); gen = (size_t)sz;
+    } else {
+        size_t off; unsigned seed = 7;
+        data = malloc(gen ? gen : 1);
+        if (!data) return 2;
+        for (off = 0; off < gen;) {              /* genRandomData-style runs, test/main.c:293-310 */
+            size_t runl = (size_t)(rand_r(&seed) % 100), k; unsigned char v = (unsigned char)(rand_r(&seed) % 65 + 90);
+            for (k = 0; k < runl && off < gen; k++) data[off++] = v;
+        }
+    }
+    qzSetLogLevel(LOG_NONE);
+    pthread_barrier_init(&bar, NULL, nthr);
+    for (t = 0; t < nthr; t++) { arg[t] = proto; arg[t].data = data; arg[t].size = gen; arg[t].id = t; arg[t].bar = &bar; pthread_create(&th[t], NULL, run_body, &arg[t]); }
+    for (t = 0; t < nthr; t++) {
+        pthread_join(th[t], NULL);
+        if (arg[t].rc) { printf("run: thread %u failed (%d)\n", t, arg[t].rc); bad = 1; continue; }
+        /* the harness counts the source bytes once per direction (test/main.c:2336-2346) */
+        sum += (double)gen * 8 * arg[t].loops * (proto.dir == RUN_BOTH ? 2 : 1) / 1073741824.0 / arg[t].secs;
+    }
+    printf("run: %u thread(s), %zu bytes, hw_buff_sz %u, block %u, loops %u, %s%s: %.3f Gbps (sum over threads, host to host)\n",
+           nthr, gen, proto.hw, proto.block, proto.loops, proto.dir == RUN_COMP ? "comp" : proto.dir == RUN_DECOMP ? "decomp" : "both",
+           proto.verify ? ", verified" : "", sum);
+    free(data);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && !strcmp(argv[1], "run")) return run(argc, argv);
     if (argc >= 6 && !strcmp(argv[1], "perfmt")) return perfmt(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
     if (argc >= 5 && !strcmp(argv[1], "sweep")) return sweep(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
     if (argc >= 5 && !strcmp(argv[1], "perf")) return perf(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
-    fprintf(stderr, "usage: bt_sweep sweep <start> <end> <step> | perf <mbytes> <block> <loops>\n");
+    fprintf(stderr, "usage: bt_sweep sweep <start> <end> <step> | perf <mbytes> <block> <loops> | perfmt <mbytes> <block> <loops> <threads> |\n"
+                    "       run [-i file] [-t threads] [-l loops] [-v] [-C hw_buff_sz] [-b block_size] [-D comp|decomp|both]\n"
+                    "           [-O deflate|gzip|gzipext|deflate_4B|lz4|zlib] [-L level] [-p pinned|common] [-s bytes]\n");
     return 64;
 }

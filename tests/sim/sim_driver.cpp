@@ -96,7 +96,7 @@ int sim_deflate_wide(const uint8_t *src, uint64_t n, uint32_t chunk_sz, int last
     std::vector<uint32_t> olen(nchunks), ocrc(nchunks);
     std::vector<uint16_t> prevtab((size_t)2 * 65536, 0x5a5a);
     uint32_t counter = 0;
-    sim::launch(2, QZW_W, 0, [&] { qzk_lz77_wide_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), prevtab.data(), &counter, nullptr); });
+    sim::launch(2, QZX_W, 0, [&] { qzk_lz77_wide_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), prevtab.data(), &counter, nullptr, nullptr); });
     sim::launch(nchunks, QZK_HW, 0, [&] {
         qzk_huff_kernel(src, n, chunk_sz, nchunks, lc.data(), dist.data(), meta.data(), slots.data(), stride,
                         last ? nchunks - 1 : ~0u, olen.data(), nullptr);

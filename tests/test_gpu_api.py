@@ -801,6 +801,30 @@ def test_plain_c_caller_links_and_round_trips(tmp_path):
         print(r.stdout)
 
 
+def test_plain_c_caller_with_the_harness_options(tmp_path):
+    """bt_sweep run: the reference harness' own option letters (test/main.c:6319-6374: -i -t -l -v -C -b -D -O -L -p) -
+    a file, chunk and block sizes, every format, both directions, threads; -v compares what came back"""
+    exe = str(tmp_path / "bt_sweep")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "bt_sweep.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "qatzip_amd"), "-lqatzip_amd", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "qatzip_amd")])
+    f = tmp_path / "input.bin"
+    f.write_bytes(datagen.gen_bytes("silesia", 3 * 1024 * 1024 + 12345, 8))
+    for opts in (["-v"],                                                    # the harness' default: 512 KB of runs, one call each way
+                 ["-v", "-i", str(f), "-C", "65536", "-b", "65536", "-t", "4", "-l", "2"],
+                 ["-v", "-i", str(f), "-C", "16384", "-b", "131072", "-O", "gzip", "-D", "both"],
+                 ["-v", "-i", str(f), "-C", "131072", "-b", "131072", "-O", "deflate"],
+                 ["-v", "-i", str(f), "-O", "deflate_4B", "-b", "524288", "-p", "pinned"],
+                 ["-v", "-i", str(f), "-O", "zlib", "-C", "65536", "-b", "65536", "-L", "6"],
+                 ["-v", "-i", str(f), "-O", "lz4", "-b", "65536", "-t", "2"],
+                 ["-i", str(f), "-D", "comp", "-b", "1048576"],
+                 ["-v", "-i", str(f), "-D", "decomp", "-b", "65536", "-t", "8"]):
+        r = subprocess.run([exe, "run"] + opts, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "Gbps" in r.stdout, (opts, r.stdout + r.stderr)
+        print(r.stdout.strip())
+
+
 @pytest.mark.parametrize("fmt", ["GZIP_EXT", "GZIP", "RAW", "4B"])
 def test_pinned_destination_receives_the_stream_directly(fmt):
     """qzCompress into qzMalloc(PINNED_MEM) memory that holds the worst case: the gather kernels write the stream straight

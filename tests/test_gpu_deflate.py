@@ -29,8 +29,26 @@ def _gpu_raw(ctx, src, chunk, last=1, level=1):
     return out, crcs
 
 
+@pytest.fixture(params=["pull", "auto"])
+def parse_kernel(request):
+    """level 1 has two parse kernels: K1 (a wave per chunk, qzk_lz77_pull_kernel) for calls that fill the chip and K1w (a
+    workgroup per chunk, qzk_lz77_wide_kernel) for launches of at most one chunk per CU.  "auto" is the product's choice
+    (K1w for the small cases here); "pull" forces K1 so that both are compared with the oracle on every case."""
+    import os
+    old = os.environ.get("QATZIP_AMD_K1")
+    if request.param == "pull":
+        os.environ["QATZIP_AMD_K1"] = "pull"
+    else:
+        os.environ.pop("QATZIP_AMD_K1", None)
+    yield request.param
+    if old is None:
+        os.environ.pop("QATZIP_AMD_K1", None)
+    else:
+        os.environ["QATZIP_AMD_K1"] = old
+
+
 @pytest.mark.parametrize("kind", datagen.KINDS)
-def test_deflate_raw_matches_oracle(ctx, kind):
+def test_deflate_raw_matches_oracle(ctx, kind, parse_kernel):
     for n, chunk in ((0, 65536), (1, 65536), (2, 65536), (3, 65536), (100, 65536), (1023, 65536), (65535, 65536),
                      (65536, 65536), (65537, 65536), (65274, 65536), (65400, 65536), (200777, 65536),
                      (70000, 16384), (300000, 131072), (1 << 20, 65536), (20000, 1024), (600000, 524288)):
@@ -45,7 +63,7 @@ def test_deflate_raw_matches_oracle(ctx, kind):
             assert crcs[i] == (zlib.crc32(src[i * chunk:(i + 1) * chunk]) & 0xffffffff)
 
 
-def test_deflate_last0_ends_with_flush_marker(ctx):
+def test_deflate_last0_ends_with_flush_marker(ctx, parse_kernel):
     src = datagen.gen_bytes("text", 150000, 5)
     got, _ = _gpu_raw(ctx, src, 65536, last=0)
     rc, _, exp, _ = O.sw_compress("RAW", src, 65536, 1, last=0)
@@ -142,16 +160,17 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_experimental_wide_window_kernel_is_bit_exact():
-    """QATZIP_AMD_K1=wide: K1w (qzk_deflate_wide.h: one chunk per 1024-thread workgroup, zlib's own head[] / prev[] on chip,
-    the parse as the fixpoint of assume-inserted / match / parse rounds) in place of K1 - same bytes, in a fresh process"""
+def test_workgroup_per_chunk_kernel_on_a_call_that_fills_the_chip():
+    """QATZIP_AMD_K1=wide: K1w (qzk_deflate_wide.h: one chunk per 1024-thread workgroup, zlib's own prev[] and the chunk on
+    chip, the parse as the fixpoint of assume-inserted / match / parse rounds) also for calls of more chunks than CUs
+    (its persistent workgroups pull chunk after chunk) - same bytes, in a fresh process"""
     import os, subprocess, sys
     code = r'''
 import sys, zlib
 sys.path.insert(0, "tests")
 import datagen, oracle_lib as O, qatzip_amd
 c = qatzip_amd.Context(0)
-for kind, n, chunk in (("silesia", 6 << 20, 65536), ("text", 300000, 16384), ("rand", 70000, 65536), ("runs", 200000, 65536), ("records", 65536 * 3 + 5, 65536), ("text", 0, 65536)):
+for kind, n, chunk in (("silesia", 40 << 20, 65536), ("text", 300000, 16384), ("rand", 70000, 65536), ("runs", 200000, 65536), ("records", 65536 * 3 + 5, 65536), ("text", 0, 65536)):
     src = datagen.gen_bytes(kind, n, 13)
     d_src = c.alloc(max(n, 1) + 512); d_dst = c.alloc(qatzip_amd.max_deflate_len(n, chunk))
     d_src.upload(src)
