@@ -501,14 +501,30 @@ def main():
 
     extra = {}
     one = None
+    hard_exit = False
     if not args.no_extra:
         if world > 1:
-            try:
-                # 8 ranks x 511 MiB: the largest member a gzip-ext header can describe (both sizes are 32-bit)
-                one = one_stream_leg(ctx, qatzip_amd, pg, rank, world, d_src, min(512, 4095 // world, args.mb), max(1, args.steps))
-            except Exception as e:   # noqa: BLE001 - the headline must survive a box without peer access
-                one = {"error": str(e)[:200]}
-            barrier(pg)
+            # The leg runs on a helper thread with a deadline: its transports wait for other ranks on the device (RCCL) or
+            # in bounded polls (IPC window), and a rank that fell out of step must not take the headline with it - the
+            # timed region is already reduced over the ranks at this point.  After a timeout no further collective runs.
+            import threading
+            box = {}
+
+            def leg():
+                try:
+                    # 8 ranks x 511 MiB: the largest member a gzip-ext header can describe (both sizes are 32-bit)
+                    box["one"] = one_stream_leg(ctx, qatzip_amd, pg, rank, world, d_src, min(512, 4095 // world, args.mb), max(1, args.steps))
+                except Exception as e:   # noqa: BLE001 - the headline must survive a box without peer access
+                    box["one"] = {"error": str(e)[:200]}
+            th = threading.Thread(target=leg, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("QATZIP_AMD_BENCH_LEG_TIMEOUT", "240")))
+            if th.is_alive():
+                one = {"error": "the one-member leg did not finish in time on rank %d (a transport is waiting for a rank that is not coming)" % rank}
+                hard_exit = True
+            else:
+                one = box.get("one")
+            hard_exit = True        # multi-rank runs end without a last rendezvous: rank 0's line never waits for a peer's teardown
         elif rank == 0:
             emb = min(args.extra_mb, args.mb)
             if ncalls > 1:
@@ -599,7 +615,9 @@ def main():
             res["config"]["one_stream"] = one
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_mb, args.base_mb, args.cpu_threads)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
+    if hard_exit:
+        os._exit(0)                                  # a helper thread is still inside a collective: no orderly teardown
     if pg is not None:
         pg.destroy_process_group()
 

@@ -244,8 +244,15 @@ QZ_DEV void qzx_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, u
         const uint64_t Sle = S & (qz_below(lane) | (1ull << lane));
         const int ss = Sle ? qz_msb64(Sle) : -1;                /* my group's first lane in this wave; -1: it began in an earlier wave */
         const bool wave_open = (S & 1ull) == 0;                 /* the wave's first group continues one of an earlier wave */
-        const int last_ss = S ? qz_msb64(S) : 0;                /* first lane of the wave's last group */
-        const uint32_t hlast = qz_readlane(h, 63), h0 = qz_readlane(h, 0);
+        /* an open wave looks at its neighbour's elements every round (the carry): their keys and group starts are static */
+        uint32_t kprev = 0; uint64_t Sprev = 0;
+        if (wave_open) {                                         /* wave-uniform (wave 0 never is) */
+            const uint32_t idx = ((wv - 1) << 6) + (uint32_t)lane;
+            kprev = L->keyA[idx];
+            const uint32_t ks = qz_shfl(kprev, lane - 1);
+            const uint32_t km = lane ? ks : (idx ? L->keyA[idx - 1] : ~kprev);
+            Sprev = qz_ballot(idx == 0 || (km >> 10) != (kprev >> 10));
+        }
         /* the chain as the table held it at the window's start: head[h] (one gather per position, the same value for the
          * whole group) and up to three links, with zlib's validity rules (a first candidate may lie exactly MAX_DIST back, a
          * chained one must lie above the limit; at or below the window origin is NIL), and the 16 speculative bytes of each.
@@ -301,11 +308,14 @@ QZ_DEV void qzx_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, u
                 uint32_t cy0 = QZX_NOPOS, cy1 = QZX_NOPOS, cy2 = QZX_NOPOS, cy3 = QZX_NOPOS, ncy = 0;
                 if (wave_open) {                                   /* wave-uniform */
                     for (int j = (int)wv - 1; j >= 0 && ncy < 4; j--) {
-                        const uint32_t idx = ((uint32_t)j << 6) + (uint32_t)lane;
-                        const uint32_t kj = L->keyA[idx];
-                        const uint32_t kjs = qz_shfl(kj, lane - 1);
-                        const uint32_t kjm = lane ? kjs : (idx ? L->keyA[idx - 1] : ~kj);
-                        const uint64_t Sj = qz_ballot(idx == 0 || (kjm >> 10) != (kj >> 10));
+                        uint32_t kj = kprev; uint64_t Sj = Sprev;         /* the neighbour wave's keys and group starts are the window's */
+                        if (j != (int)wv - 1) {
+                            const uint32_t idx = ((uint32_t)j << 6) + (uint32_t)lane;
+                            kj = L->keyA[idx];
+                            const uint32_t kjs = qz_shfl(kj, lane - 1);
+                            const uint32_t kjm = lane ? kjs : (idx ? L->keyA[idx - 1] : ~kj);
+                            Sj = qz_ballot(idx == 0 || (kjm >> 10) != (kj >> 10));
+                        }
                         const uint32_t tj = kj & 1023u, pj = ws + tj;
                         bool fj = pj + 3 <= n && pj != 0;
                         if (round > 0) {
@@ -413,7 +423,7 @@ QZ_DEV void qzx_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, u
             qz_block_sync();
 
             QZX_DBG("  round %u matches done\n", round);
-            QZX_T(5);
+            if (round == 0) QZX_T(5); else QZX_T(13);
             /* ---- position order from here: thread = position ws + tid ---- */
             const uint32_t pp_ = ws + tid;
             const uint32_t avail_p = pp_ < n ? n - pp_ : 0;
@@ -474,6 +484,8 @@ QZ_DEV void qzx_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, u
             L->w.exitp[tid] = (uint16_t)J;
             qz_block_sync();
             QZX_T(7);
+            /* the sixteen exit tables chained from the window's first position (every wave walks the chain itself: uniform
+             * LDS reads, no exchange; fetching all sixteen tables at once and hopping with readlane measured the same) */
             uint32_t cur = 0;
             while (cur < (wv << 6) && cur < lim) cur = qz_readfirstlane(L->w.exitp[cur]);
             uint64_t P = 0;
