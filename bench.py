@@ -2,8 +2,9 @@
 """bench.py — the reference's headline workload on MI355X.
 
 Workload (BASELINE.json configs[1]): QZ_DEFLATE_GZIP_EXT, level 1, hw_buff_sz 64 KB, a 4 GB synthetic
-"Silesia-like" buffer per GPU, handled as 2 calls of 2 GiB (qatzip lengths are 32-bit), inputs already
-resident in HBM when the timed region starts.  One step = one pass of the hot path over that buffer:
+"Silesia-like" buffer per GPU, handled as ONE device-layer call of 4 GiB per direction (65536 chunks in one launch; the
+device ABI's lengths are 64-bit - through qatzip.h, whose lengths are 32-bit, the same buffer is two calls, see
+config.api_* and config.concurrent_sessions), inputs already resident in HBM when the timed region starts.  One step = one pass of the hot path over that buffer:
 compress every call, then decompress every call (the reference harness' "-D both", test/main.c:2204-2299).
 `value` = uncompressed bytes moved in both directions by all ranks / max-over-ranks wall time (the reference
 counts uncompressed bytes for either direction and doubles them for "both", test/main.c:2336-2346).
@@ -35,7 +36,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 CHUNK = 65536
-CALL_BYTES = 1 << 31            # one qzCompress-sized call (2 GiB)
+CALL_BYTES = 1 << 32            # one device-layer call: the device ABI's lengths are 64-bit (deflate: at most 4 GiB a call)
+API_CALL_BYTES = 1 << 31        # the same job through qatzip.h, whose lengths are 32-bit: calls of 2 GiB
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 TILE_SKEW = 4099                # the distinct data is tiled with a period that is no multiple of any chunk size
 
@@ -283,21 +285,23 @@ def lz4_leg(ctx, qz, d_src, mb):
             "ratio": round(cl / n, 4), "note": "64 KB frames, XXH32 content checksum made and verified in-kernel, host call to host return"}
 
 
-def sessions_leg(qz, dev, d_src, call_n, d_comp, steps):
+def sessions_leg(qz, dev, d_src, total, steps):
     """The same job driven the way the reference's harness drives a device (test/main.c:2175-2202, `-t`): one session per
     host thread, started together.  Thread i owns call i of the buffer: compress it, decompress it, `steps` times.  Not the
     headline (that is one session, one call after the other); it shows what the device does when calls overlap - a call's
     phase A is one latency chain per segment and leaves the chip half empty, a second session's kernels fill it."""
     import threading
+    call_n = [min(API_CALL_BYTES, total - o) for o in range(0, total, API_CALL_BYTES)]
     ctxs = [qz.Context(dev) for _ in call_n]
     backs = [c.alloc(n) for c, n in zip(ctxs, call_n)]
+    d_comp = [c.alloc(qz.max_deflate_len(n, CHUNK)) for c, n in zip(ctxs, call_n)]
     err = []
     bar = threading.Barrier(len(call_n) + 1)
 
     def body(i):
         c, n = ctxs[i], call_n[i]
         try:
-            src = view(qz, d_src, i * CALL_BYTES, n)
+            src = view(qz, d_src, i * API_CALL_BYTES, n)
             for it in range(steps + 1):                 # pass 0 warms this context up (scratch, tables)
                 if it == 1:
                     bar.wait(); bar.wait()
@@ -324,14 +328,14 @@ def sessions_leg(qz, dev, d_src, call_n, d_comp, steps):
     for t in th:
         t.join()
     dt = time.perf_counter() - t0 if not err else 0.0
-    for b in backs:
+    for b in backs + d_comp:
         b.free()
     for c in ctxs:
         c.close()                                       # the contexts' decode scratch (several GiB each) goes back
     if err or dt <= 0:
         return {"error": "; ".join(err)[:200]}
     return {"sessions": len(call_n), "GBps": round(2.0 * sum(call_n) * steps / dt / 1e9, 3), "steps": steps,
-            "note": "one host thread and one session per 2 GiB call, started together; compress + decompress, uncompressed bytes both ways"}
+            "note": "the same buffer as calls of 2 GiB (what a qatzip.h caller makes of it), one host thread and one session per call, started together; compress + decompress, uncompressed bytes both ways"}
 
 
 def view(qz, buf, off, n):
@@ -527,14 +531,14 @@ def main():
             hard_exit = True        # multi-rank runs end without a last rendezvous: rank 0's line never waits for a peer's teardown
         elif rank == 0:
             emb = min(args.extra_mb, args.mb)
-            if ncalls > 1:
-                try:
-                    extra["concurrent_sessions"] = sessions_leg(qatzip_amd, dev, d_src, call_n, d_comp, args.steps)
-                except Exception as e:   # noqa: BLE001 - an extra leg must not cost the headline
-                    extra["concurrent_sessions"] = {"error": str(e)[:200]}
             for d in d_comp:
                 d.free()
             d_back.free()
+            if total > API_CALL_BYTES:
+                try:
+                    extra["concurrent_sessions"] = sessions_leg(qatzip_amd, dev, d_src, total, args.steps)
+                except Exception as e:   # noqa: BLE001 - an extra leg must not cost the headline
+                    extra["concurrent_sessions"] = {"error": str(e)[:200]}
             extra["hbm_copy_GBps"] = round(ctx.stream_copy_peak(1 << 30, 3), 1)
             try:
                 h2d, d2h = ctx.pcie_peak(1 << 30, 2)
@@ -547,13 +551,13 @@ def main():
 
     if rank == 0:
         # HBM traffic per K1 launch: PMC counters cannot be read from inside this process; they come from the committed
-        # rocprofv3 --pmc passes of this same command (profiles/r2_pmc.json, tools/pmc_summary.py): FETCH_SIZE and
+        # rocprofv3 --pmc passes of this same command (profiles/r3_pmc.json, tools/pmc_summary.py): FETCH_SIZE and
         # WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note; quoted only when the
         # profiled command had the same launch mix (same --mb, same chunks per launch: a device-resident call is ONE launch
-        # of the fused K1+K2+CRC kernel, 32768 chunks for 2 GiB) - null otherwise, never stale.
+        # of the fused K1+K2+CRC kernel, 65536 chunks for 4 GiB) - null otherwise, never stale.
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r2_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r3_pmc.json")) as f:
                 pj = json.load(f)
             pk = pj["kernels"].get(pj.get("k1_key", ""))
             if pk and pj.get("bench_mb") == args.mb and pj.get("k1_launch_chunks") == round(k1_chunks / max(k1_launches, 1)):
@@ -575,8 +579,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "QZ_DEFLATE_GZIP_EXT level 1, 64 KB chunks, %d MiB Silesia-like buffer per GPU "
-                                   "(%d MiB distinct, tiled with period %d B so that no two chunks are equal), %d call(s) of "
-                                   "<= 2 GiB, compress then decompress" % (args.mb, base_n >> 20, tile, ncalls),
+                                   "(%d MiB distinct, tiled with period %d B so that no two chunks are equal), %d device-layer call(s) of "
+                                   "<= 4 GiB per direction, compress then decompress" % (args.mb, base_n >> 20, tile, ncalls),
                        "chunk": CHUNK, "ratio": round(ratio, 4), "parallelism": "chunks sharded over %d rank(s), "
                        "no data-path collective in the timed region" % world,
                        "compress_GBps": round(raw_total / tc / 1e9, 3), "decompress_GBps": round(raw_total / td / 1e9, 3)},

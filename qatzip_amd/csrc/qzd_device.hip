@@ -188,6 +188,8 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
     if (hipMalloc(&c->d_running, 8) != hipSuccess || hipMalloc(&c->d_overflow, 4) != hipSuccess) QZD_CREATE_FAIL;
     hipHostMalloc((void **)&c->h_running, 8, hipHostMallocDefault);
     hipHostMalloc((void **)&c->h_overflow, 4, hipHostMallocDefault);
+    /* watermark of a launch whose input is still arriving: read by the kernel over the link, so coherent + mapped */
+    if (hipHostMalloc((void **)&c->h_wm, 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) c->h_wm = NULL;
 #undef QZD_CREATE_FAIL
     *out = c;
     return QZD_OK;
@@ -216,7 +218,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     for (int i = 0; i < QZD_K1EV; i++) { if (c->k1ev[i][0]) hipEventDestroy(c->k1ev[i][0]); if (c->k1ev[i][1]) hipEventDestroy(c->k1ev[i][1]); }
     hipFree(c->k1_counter);
     hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
-    hipHostFree(c->h_running); hipHostFree(c->h_overflow);
+    hipHostFree(c->h_running); hipHostFree(c->h_overflow); if (c->h_wm) hipHostFree(c->h_wm);
     if (c->d_aux) hipFree(c->d_aux);
     if (c->h_aux) hipHostFree(c->h_aux);
     if (c->d_big) hipFree(c->d_big);
@@ -612,7 +614,18 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
      * is nothing left to overlap it with.  Input still on the host: batches, so that the copy of the next one runs beside
      * the kernels of this one. */
     const bool fuse = k1_fused();
-    const uint32_t BATCH = fuse && !h_src ? std::max<uint32_t>(nchunks, 1u) : c->batch_chunks;
+    uint32_t BATCH = fuse && !h_src ? std::max<uint32_t>(nchunks, 1u) : c->batch_chunks;
+    uint32_t first_env = 0;
+    if (h_src) {        /* developer knobs for the host-input pipeline: chunks per batch / in the first batch */
+        if (const char *e = getenv("QATZIP_AMD_HOST_BATCH")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 256) BATCH = v; }
+        if (const char *e = getenv("QATZIP_AMD_HOST_FIRST")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 256) first_env = v; }
+    }
+    /* Host input of 64 MiB and more (level 1, chunks of the common kind): ONE launch over the whole call that starts at
+     * once and takes its chunks as they land - the pieces of the copy go out behind it and the host raises the launch's
+     * watermark (c->h_wm, pinned) as each completes (qzk_wait_input).  No batch boundaries, so no tails but the last one,
+     * and the parse runs beside the whole copy instead of beside all but the first batch of it. */
+    const bool stream_in = h_src && fuse && !cdesc && n >= (64ull << 20) && c->h_wm && !getenv("QATZIP_AMD_HOST_BATCHED");
+    if (stream_in) { BATCH = nchunks; first_env = 0; c->h_wm[0] = 0; c->h_wm[1] = 0; }
     c->k1ev_n = 0;
     c->nbatches = (nchunks + BATCH - 1) / BATCH;
 
@@ -625,7 +638,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
 
     /* with the input still on the host the first batch is one round of the persistent workgroups instead of three:
      * nothing can overlap its copy, so it is kept short */
-    const uint32_t FIRST = h_src && nchunks > BATCH ? std::max<uint32_t>(c->k1_wgs, 1024u) : BATCH;
+    const uint32_t FIRST = h_src && nchunks > BATCH ? (first_env ? first_env : std::max<uint32_t>(c->k1_wgs, 1024u)) : BATCH;
     const uint32_t tab_wgs = pool->tab_wgs;
     if (FIRST != BATCH) c->nbatches = 1 + (nchunks - FIRST + BATCH - 1) / BATCH;
     for (uint32_t b = 0, k = 0, bnext = 0; b < nchunks; b = bnext, k++) {
@@ -646,7 +659,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
             hipError_t e = hipMemcpyAsync((void *)(d_src + o), h_src + o, len, hipMemcpyHostToDevice, c->st_copy);
             return e != hipSuccess ? e : hipEventRecord(c->cp_ev[kk % (QZD_NBUF + 1)], c->st_copy);
         };
-        if (h_src && n) {
+        if (h_src && n && !stream_in) {
             if (k == 0) HIPCHK(c, send(0, 0));
             HIPCHK(c, hipStreamWaitEvent(st, c->cp_ev[k % (QZD_NBUF + 1)], 0));
         }
@@ -667,7 +680,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64 * wpw), 0, st, d_src + boff, blen, chunk_sz, bn,
                            pool->sym_lc[sb], pool->sym_dist[sb], meta_b, pool->tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
                            pool->epoch, fuse ? slots_b : (uint8_t *)NULL, stride, final_chunk, c->d_len + b,
-                           fuse ? c->d_crc + b : (uint32_t *)NULL);
+                           fuse ? c->d_crc + b : (uint32_t *)NULL, stream_in ? (const uint32_t *)c->h_wm : (const uint32_t *)NULL);
         pool->epoch += bn;
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
@@ -687,7 +700,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
                            c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][3], st));
         HIPCHK(c, hipEventRecord(c->done[s], st));
-        if (h_src && bnext < nchunks) HIPCHK(c, send(k + 1, bnext));
+        if (h_src && !stream_in && bnext < nchunks) HIPCHK(c, send(k + 1, bnext));
     }
     /* join: stream 0 waits for stream 1, then publishes the totals */
     HIPCHK(c, hipStreamWaitEvent(c->st[0], c->done[1], 0));
@@ -696,6 +709,34 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
     HIPCHK(c, hipMemcpyAsync(c->h_overflow, c->d_overflow, 4, hipMemcpyDeviceToHost, c->st[0]));
     HIPCHK(c, hipEventRecord(c->ev_end, c->st[0]));
     HIPCHK(c, hipGetLastError());
+    if (stream_in) {
+        /* the copy, in pieces (small ones first: the launch is waiting), two in flight; the watermark follows the last
+         * piece known to be complete.  Whatever goes wrong, the launch is told (0xffffffff) before this returns. */
+        uint64_t off = 0, done_to = 0, ends[QZD_NBUF + 1] = {0};
+        hipError_t e = hipSuccess;
+        uint32_t i = 0;
+        auto landed = [&](uint64_t upto) {
+            __atomic_store_n(&c->h_wm[0], upto >= n ? nchunks : (uint32_t)(upto / chunk_sz), __ATOMIC_RELEASE);
+        };
+        for (; off < n && e == hipSuccess; i++) {
+            const uint64_t want = i < 2 ? (4ull << 20) : i < 6 ? (4ull << 20) << (i - 1) : (64ull << 20);
+            const uint64_t len = std::min<uint64_t>(want, n - off);
+            e = hipMemcpyAsync((void *)(d_src + off), h_src + off, len, hipMemcpyHostToDevice, c->st_copy);
+            if (e == hipSuccess) e = hipEventRecord(c->cp_ev[i % (QZD_NBUF + 1)], c->st_copy);
+            off += len; ends[i % (QZD_NBUF + 1)] = off;
+            if (i >= 1 && e == hipSuccess) {
+                e = hipEventSynchronize(c->cp_ev[(i - 1) % (QZD_NBUF + 1)]);
+                if (e == hipSuccess) landed(done_to = ends[(i - 1) % (QZD_NBUF + 1)]);
+            }
+        }
+        if (e == hipSuccess && i) e = hipEventSynchronize(c->cp_ev[(i - 1) % (QZD_NBUF + 1)]);
+        if (e != hipSuccess) {
+            __atomic_store_n(&c->h_wm[0], 0xffffffffu, __ATOMIC_RELEASE);
+            HIPCHK(c, e);
+        }
+        landed(n);
+        (void)done_to;
+    }
     return QZD_OK;
 }
 
@@ -790,6 +831,7 @@ extern "C" int qzd_deflate_raw_from_host(qzd_ctx *c, const uint8_t *h_src, uint8
     if (rc) return rc;
     rc = qzd_sync(c);
     if (rc) return rc;
+    if (c->h_wm && c->h_wm[1]) { c->h_wm[1] = 0; snprintf(c->err, sizeof(c->err), "the launch waited for its input in vain"); return QZD_ERR_HIP; }
     return qzd_result(c, h_out_len, h_chunk_crc, c->last_nchunks);
 }
 

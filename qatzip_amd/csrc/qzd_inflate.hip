@@ -135,13 +135,16 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         const char *le = getenv("QATZIP_AMD_INFLATE_LPW");
         if (le) { int v = atoi(le); if (v == 8 || v == 16 || v == 32 || v == 64) lpw = (uint32_t)v; }
         const dim3 grid((nsegs + lpw - 1) / lpw), blk(lpw);
+#ifndef QZD_TOK_OCC
+#define QZD_TOK_OCC 2           /* waves per SIMD of phase A's sixteen-lane workgroups: what their root tables leave room for in LDS */
+#endif
 #define QZD_TOK_LAUNCH(N, W) hipLaunchKernelGGL((qzk_inflate_tok_kernel<N, W>), grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
                                                ts_d, lit_d, seq_d, ch_d)
         const char *oe = getenv("QATZIP_AMD_INFLATE_OCC");
         const int occ = oe ? atoi(oe) : 0;
         if (lpw == 8) { if (occ == 2) QZD_TOK_LAUNCH(8, 2); else QZD_TOK_LAUNCH(8, 4); }
         else if (lpw == 32) QZD_TOK_LAUNCH(32, 1); else if (lpw == 64) QZD_TOK_LAUNCH(64, 1);
-        else QZD_TOK_LAUNCH(16, 2);
+        else QZD_TOK_LAUNCH(16, QZD_TOK_OCC);
 #undef QZD_TOK_LAUNCH
     } else {
         const uint32_t spw = 64 / K;

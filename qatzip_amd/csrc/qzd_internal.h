@@ -38,6 +38,7 @@ struct qzd_ctx {
     uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;
     uint64_t *d_running; uint32_t *d_overflow;
     uint64_t *h_running; uint32_t *h_overflow;      /* pinned */
+    uint32_t *h_wm;                                 /* pinned, read by qzk_lz77_pull_kernel: [0] chunks of host input landed, [1] a wave gave up waiting */
     /* timing */
     hipEvent_t ev[QZD_NBUF][4]; hipEvent_t ev_begin, ev_end;
     uint32_t nbatches; float ms[4];

@@ -628,12 +628,45 @@ QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t
  * following a chain of HBM round trips: as a separate launch beside the next batch's K1, K2 (two waves per CU in the LDS
  * K1 leaves) stretched that K1 launch by 7 of its 23 ms; inside the K1 waves it fills issue slots the parse leaves
  * empty, and a chunk's symbols are read back while they are still on their way through the L2. */
+/* Input that is still crossing PCIe when the launch starts (qzd_deflate_raw_from_host): `avail` points at two words of
+ * pinned HOST memory.  avail[0] = chunks of this launch whose bytes have landed in HBM - the host raises it as the
+ * pieces of its copy complete (a copy engine moves them, no compute unit is needed for it; these workgroups fill the
+ * register files, so nothing else could run beside them anyway).  A wave that has pulled chunk k waits until chunk k+1
+ * has landed too (the ring reads a few hundred bytes past the window, never more), asleep for about as long as the
+ * missing chunks take on the link, then drops its L1: the lines it is about to read have never been touched by this
+ * launch, so no L2 holds an older copy of them.  A wave that waits for a second in vain (the host is gone) says so in
+ * avail[1] and leaves; 0xffffffff in avail[0] is the host giving up. */
+QZ_DEV bool qzk_wait_input(const uint32_t *avail, uint32_t need)
+{
+#ifdef QZ_SIM
+    (void)avail; (void)need;
+    return true;
+#else
+    uint32_t slept = 0;
+    for (;;) {
+        const uint32_t wm = qz_readfirstlane(__hip_atomic_load(avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (wm == 0xffffffffu) return false;
+        if (wm >= need) break;
+        const uint32_t miss = need - wm < 4096u ? need - wm : 4096u;       /* ~1 us of sleep per missing 64 KiB chunk */
+        for (uint32_t k = 0; k < miss; k++) __builtin_amdgcn_s_sleep(38);
+        slept += miss;
+        if (slept > (1u << 20)) {
+            __hip_atomic_store((uint32_t *)avail + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+#endif
+}
+
 #define QZK_K1_LDSW (QZK_K1_PARSEW > (sizeof(qzk_huff_lds) + 3) / 4 ? QZK_K1_PARSEW : (sizeof(qzk_huff_lds) + 3) / 4)
 QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                                                      uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tables,
                                                      uint32_t *counter, const uint32_t *cdesc, uint32_t epoch_base,
                                                      uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk, uint32_t *out_len,
-                                                     uint32_t *crc_out /* per chunk, or NULL */)
+                                                     uint32_t *crc_out /* per chunk, or NULL */,
+                                                     const uint32_t *avail /* NULL: the input is all there */)
 {
     QZ_LDS uint32_t lds_all[QZK_K1_WAVES][QZK_K1_LDSW];
     QZ_LDS qzk_k1crc_lds crcT;
@@ -648,6 +681,7 @@ QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_p
         uint32_t chunk = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);
         chunk = qz_readfirstlane(chunk);
         if (chunk >= nchunks) break;
+        if (avail && !qzk_wait_input(avail, chunk + 2 < nchunks ? chunk + 2 : nchunks)) break;    /* kernel argument + wave-uniform values */
         /* symbols: with K2 in the wave they only live until the wave has coded them - one chunk's worth per WAVE (read
          * back at the L2: the same addresses carried the previous chunk's symbols); without, one per chunk of the launch */
         const uint64_t soff = slots ? (uint64_t)(blockIdx.x * QZK_K1_WAVES + (uint32_t)wv) * chunk_sz : (uint64_t)chunk * chunk_sz;

@@ -30,8 +30,14 @@
 
 /* root tables (the per-symbol lookups) live in LDS; the canonical ranges for longer codes and the code lengths
  * stay in a per-segment HBM record */
+#ifndef QZK_LLROOT
 #define QZK_LLROOT 9
+#endif
+#ifndef QZK_LDROOT
 #define QZK_LDROOT 7
+#endif
+/* the code-length code of a dynamic block (<= 7 bits) borrows the distance root: no wider than that table is */
+#define QZK_CLROOT (QZK_LDROOT < 7 ? QZK_LDROOT : 7)
 #define QZK_LANE_ROOTSZ ((1 << QZK_LLROOT) + (1 << QZK_LDROOT))
 
 typedef struct {
@@ -265,12 +271,12 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
     }
     int clmax = 0;
     /* the 7-bit code-length code borrows the distance-table arrays */
-    if (qzk_lane_build(T->lens, 19, droot, 7, T->dsorted, T->dcount, T->dfirst, T->dindex, &clmax) != 0) return;
+    if (qzk_lane_build(T->lens, 19, droot, QZK_CLROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &clmax) != 0) return;
     uint32_t i = 0, prev = 0;
     uint8_t *L = T->lens;               /* final place: [0, nlen) lit/len, [nlen, nlen+ndist) distance */
     while (i < nlen + ndist) {
         qzk_lrefill(b);
-        const int sym = qzk_ldecode(b, droot, 7, T->dsorted, T->dcount, T->dfirst, T->dindex, clmax);
+        const int sym = qzk_ldecode(b, droot, QZK_CLROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, clmax);
         if (sym < 0) return;
         if (sym < 16) { L[i++] = (uint8_t)sym; prev = (uint32_t)sym; continue; }
         uint32_t rep, val;

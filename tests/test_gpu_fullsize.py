@@ -70,6 +70,30 @@ def test_one_2GiB_launch_matches_the_oracle_on_sampled_chunks():
     ctx.close()
 
 
+def test_one_4GiB_call_per_direction_is_what_the_bench_times():
+    """the bench's timed region: ONE device-layer call of 4 GiB per direction (65536 chunks in one launch, 65536 segments in
+    one inflate call; the device ABI's lengths are 64-bit) - sampled chunk streams against the oracle, the stream CRC-32
+    from the chunks', the round trip"""
+    import qatzip_amd
+    ctx = qatzip_amd.Context(0)
+    total = 1 << 32
+    d_src = _bench_buffer(ctx, total)
+    d_dst = ctx.alloc(qatzip_amd.max_deflate_len(total, CHUNK))
+    n_out, crcs = ctx.deflate_raw(d_src, total, CHUNK, 1, 1, d_dst)
+    assert len(crcs) == total // CHUNK
+    checked = _check_sampled_chunks(ctx, d_src, d_dst, total, n_out, crcs, 256, 3)
+    crcs = np.ascontiguousarray(crcs, np.uint32)
+    want = ctx.crc32(d_src, total)
+    assert ctx.L.qzd_crc32_fold(crcs.ctypes.data, len(crcs), CHUNK, total) == want
+    d_back = ctx.alloc(total)
+    iu, ol, crc = ctx.inflate_stream(d_dst, n_out, d_back, CHUNK, want_crc=True)
+    assert iu == n_out and ol == total and crc == want
+    print("4 GiB call: %d chunk streams byte-identical to the oracle's, stream CRC and round trip equal" % checked)
+    for b in (d_src, d_dst, d_back):
+        b.free()
+    ctx.close()
+
+
 def test_inflate_of_an_oracle_made_member_at_call_scale():
     """the decoder on streams it did not write: 4096 chunk streams made by the ORACLE (256 MiB, what the oracle does in
     the test's time), concatenated as the software path lays them out, decoded in one call through the two-phase path"""
