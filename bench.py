@@ -425,6 +425,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the API / RAW sweep / LZ4 / one-stream legs")
     ap.add_argument("--extra-mb", type=int, default=1024, help="bytes of the extra legs, MiB")
+    ap.add_argument("--api-mb", type=int, default=2047, help="bytes of the one qzCompress / qzDecompress call of the API leg, MiB "
+                    "(qatzip.h lengths are 32-bit)")
     ap.add_argument("--no-probe", action="store_true", help="skip the lone 12288-chunk K1 launch after the timed region "
                     "(the rocprofv3 --pmc passes: every K1 launch of the run is then a whole 2 GiB call)")
     args = ap.parse_args()
@@ -547,7 +549,7 @@ def main():
                 extra["pcie_error"] = str(e)[:120]
             extra["raw_sweep"] = raw_sweep(ctx, qatzip_amd, d_src, emb)
             extra["lz4"] = lz4_leg(ctx, qatzip_amd, d_src, emb)
-            extra.update(api_leg(base, tile, emb))
+            extra.update(api_leg(base, tile, min(args.api_mb, args.mb)))
 
     if rank == 0:
         # HBM traffic per K1 launch: PMC counters cannot be read from inside this process; they come from the committed

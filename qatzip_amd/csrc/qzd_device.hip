@@ -23,6 +23,10 @@
 #include "qzk_deflate_huff.h"
 #include "qzk_checksum.h"
 
+/* per call: chunk offsets (8 B each) and, behind them, what a launch that moves the stream itself needs (qzk_outp): the
+ * front word and one published length per chunk */
+#define QZD_OFFS_BYTES(nchunks) ((size_t)(nchunks) * 12 + 16)
+
 /* ------------------------------------------------------------------ utility kernels */
 /* offs[i] = *running + sum(len[0..i)); then *running += sum.  One 1024-thread workgroup. */
 __global__ void qzk_scan_kernel(const uint32_t *len, uint32_t nchunks, uint64_t *offs, uint64_t *running)
@@ -366,7 +370,7 @@ static int ensure_scratch(qzd_ctx *c, qzd_k1pool *pool, uint32_t chunk_sz, uint3
         c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL; c->call_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_len, (size_t)nchunks * 4));
         HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nchunks * 4));
-        HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nchunks * 8));
+        HIPCHK(c, hipMalloc(&c->d_offs, QZD_OFFS_BYTES(nchunks)));
         c->call_cap = nchunks;
     }
     return QZD_OK;
@@ -398,7 +402,7 @@ static int deflate_lane_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
         c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL; c->call_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_len, (size_t)nchunks * 4));
         HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nchunks * 4));
-        HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nchunks * 8));
+        HIPCHK(c, hipMalloc(&c->d_offs, QZD_OFFS_BYTES(nchunks)));
         c->call_cap = nchunks;
     }
     uint8_t *pb = c->d_lane;
@@ -470,7 +474,7 @@ static int deflate_wide_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
         c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL; c->call_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_len, (size_t)nchunks * 4));
         HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nchunks * 4));
-        HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nchunks * 8));
+        HIPCHK(c, hipMalloc(&c->d_offs, QZD_OFFS_BYTES(nchunks)));
         c->call_cap = nchunks;
     }
     uint8_t *pb = c->d_lane;
@@ -626,6 +630,20 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
      * and the parse runs beside the whole copy instead of beside all but the first batch of it. */
     const bool stream_in = h_src && fuse && !cdesc && n >= (64ull << 20) && c->h_wm && !getenv("QATZIP_AMD_HOST_BATCHED");
     if (stream_in) { BATCH = nchunks; first_env = 0; c->h_wm[0] = 0; c->h_wm[1] = 0; }
+    /* one launch for the whole call: its waves also move the stream to d_dst (qzk_outp) - no scan, no gather behind it */
+    const char *oute = getenv("QATZIP_AMD_K1_OUT");
+    /* (measured, profiles/r3_api_stream.txt: with the destination across PCIe the stream then travels while the parse runs,
+     * 25.0 -> 27.3 GB/s for a 1 GiB qzCompress; with the destination in HBM the gather kernel's 2 ms are cheaper than the
+     * waves' own copies, 115.8 vs 117.9 ms per 4 GiB - so: calls fed from the host only, QATZIP_AMD_K1_OUT=launch|gather
+     * forces either) */
+    const bool out_in_launch = fuse && BATCH >= nchunks && (oute ? !strcmp(oute, "launch") : stream_in);
+    qzk_outp outp;
+    memset(&outp, 0, sizeof(outp));
+    if (out_in_launch) {
+        outp.dst = d_dst; outp.cap = dst_cap; outp.offs = c->d_offs; outp.front = c->d_offs + nchunks;
+        outp.pub = (uint32_t *)(c->d_offs + nchunks + 1); outp.running = c->d_running; outp.overflow = c->d_overflow;
+        HIPCHK(c, hipMemsetAsync(c->d_offs, 0, QZD_OFFS_BYTES(nchunks), c->st[0]));
+    }
     c->k1ev_n = 0;
     c->nbatches = (nchunks + BATCH - 1) / BATCH;
 
@@ -680,7 +698,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64 * wpw), 0, st, d_src + boff, blen, chunk_sz, bn,
                            pool->sym_lc[sb], pool->sym_dist[sb], meta_b, pool->tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
                            pool->epoch, fuse ? slots_b : (uint8_t *)NULL, stride, final_chunk, c->d_len + b,
-                           fuse ? c->d_crc + b : (uint32_t *)NULL, stream_in ? (const uint32_t *)c->h_wm : (const uint32_t *)NULL);
+                           fuse ? c->d_crc + b : (uint32_t *)NULL, stream_in ? (const uint32_t *)c->h_wm : (const uint32_t *)NULL, outp);
         pool->epoch += bn;
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }
@@ -695,9 +713,11 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][2], st));
         /* the running total serialises scan/gather of consecutive batches across the two streams */
         if (k > 0) HIPCHK(c, hipStreamWaitEvent(st, c->done[so], 0));
-        hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);
-        hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, slots_b, stride, c->d_len + b,
-                           c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
+        if (!out_in_launch) {
+            hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);
+            hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, slots_b, stride, c->d_len + b,
+                               c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
+        }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[s][3], st));
         HIPCHK(c, hipEventRecord(c->done[s], st));
         if (h_src && !stream_in && bnext < nchunks) HIPCHK(c, send(k + 1, bnext));
@@ -715,11 +735,19 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         uint64_t off = 0, done_to = 0, ends[QZD_NBUF + 1] = {0};
         hipError_t e = hipSuccess;
         uint32_t i = 0;
+        const bool trace = getenv("QATZIP_AMD_STREAM_TRACE") != NULL;
+        struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
         auto landed = [&](uint64_t upto) {
             __atomic_store_n(&c->h_wm[0], upto >= n ? nchunks : (uint32_t)(upto / chunk_sz), __ATOMIC_RELEASE);
+            if (trace) {
+                struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+                fprintf(stderr, "[stream] %8.3f ms  %6.1f MiB landed\n", (t.tv_sec - ts0.tv_sec) * 1e3 + (t.tv_nsec - ts0.tv_nsec) / 1e6, upto / 1048576.0);
+            }
         };
         for (; off < n && e == hipSuccess; i++) {
-            const uint64_t want = i < 2 ? (4ull << 20) : i < 6 ? (4ull << 20) << (i - 1) : (64ull << 20);
+            /* every wave of the launch has pulled a chunk and waits for it: fine steps while they start (the first
+             * 256 MiB feed the first chunk of each of 4096 waves), coarse ones once the copy is ahead of the parse */
+            const uint64_t want = i < 2 ? (4ull << 20) : off < (256ull << 20) ? (8ull << 20) : (64ull << 20);
             const uint64_t len = std::min<uint64_t>(want, n - off);
             e = hipMemcpyAsync((void *)(d_src + off), h_src + off, len, hipMemcpyHostToDevice, c->st_copy);
             if (e == hipSuccess) e = hipEventRecord(c->cp_ev[i % (QZD_NBUF + 1)], c->st_copy);
@@ -769,7 +797,7 @@ static int deflate_lazy_path(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint3
         c->d_len = NULL; c->d_crc = NULL; c->d_offs = NULL; c->call_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_len, (size_t)nchunks * 4));
         HIPCHK(c, hipMalloc(&c->d_crc, (size_t)nchunks * 4));
-        HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nchunks * 8));
+        HIPCHK(c, hipMalloc(&c->d_offs, QZD_OFFS_BYTES(nchunks)));
         c->call_cap = nchunks;
     }
     uint8_t *pb = c->d_lane;
@@ -892,6 +920,7 @@ extern "C" int qzd_k1_stats(qzd_ctx *c, double *ms, uint64_t *launches, uint64_t
 extern "C" int qzd_result(qzd_ctx *c, uint64_t *h_out_len, uint32_t *h_chunk_crc, uint32_t nchunks)
 {
     if (!c) return QZD_ERR_PARAM;
+    if (*c->h_overflow & 2u) { snprintf(c->err, sizeof(c->err), "a wave waited in vain for the chunks before its own"); return QZD_ERR_HIP; }
     if (*c->h_overflow) { snprintf(c->err, sizeof(c->err), "destination too small"); return QZD_ERR_DSTCAP; }
     if (h_out_len) *h_out_len = *c->h_running;
     if (h_chunk_crc) {

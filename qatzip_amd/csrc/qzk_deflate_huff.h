@@ -632,25 +632,26 @@ QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t
  * pinned HOST memory.  avail[0] = chunks of this launch whose bytes have landed in HBM - the host raises it as the
  * pieces of its copy complete (a copy engine moves them, no compute unit is needed for it; these workgroups fill the
  * register files, so nothing else could run beside them anyway).  A wave that has pulled chunk k waits until chunk k+1
- * has landed too (the ring reads a few hundred bytes past the window, never more), asleep for about as long as the
+ * has landed too (the ring reads a few hundred bytes past the window, never 1 KiB), asleep for about as long as the
  * missing chunks take on the link, then drops its L1: the lines it is about to read have never been touched by this
  * launch, so no L2 holds an older copy of them.  A wave that waits for a second in vain (the host is gone) says so in
  * avail[1] and leaves; 0xffffffff in avail[0] is the host giving up. */
-QZ_DEV bool qzk_wait_input(const uint32_t *avail, uint32_t need)
+QZ_DEV bool qzk_wait_input(const uint32_t *avail, uint32_t need, uint32_t chunk_sz)
 {
 #ifdef QZ_SIM
-    (void)avail; (void)need;
+    (void)avail; (void)need; (void)chunk_sz;
     return true;
 #else
+    const uint32_t per = chunk_sz >> 14 ? chunk_sz >> 14 : 1u;             /* naps of ~0.27 us: about 1 us per missing 64 KiB */
     uint32_t slept = 0;
     for (;;) {
         const uint32_t wm = qz_readfirstlane(__hip_atomic_load(avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         if (wm == 0xffffffffu) return false;
         if (wm >= need) break;
-        const uint32_t miss = need - wm < 4096u ? need - wm : 4096u;       /* ~1 us of sleep per missing 64 KiB chunk */
-        for (uint32_t k = 0; k < miss; k++) __builtin_amdgcn_s_sleep(38);
-        slept += miss;
-        if (slept > (1u << 20)) {
+        const uint32_t naps = (need - wm < 4096u ? need - wm : 4096u) * per;
+        for (uint32_t k = 0; k < naps; k++) __builtin_amdgcn_s_sleep(10);
+        slept += naps;
+        if (slept > (4u << 20)) {                                           /* more than a second asleep */
             __hip_atomic_store((uint32_t *)avail + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;
         }
@@ -660,20 +661,111 @@ QZ_DEV bool qzk_wait_input(const uint32_t *avail, uint32_t need)
 #endif
 }
 
+/* ------------------------------------------------------------------ the stream leaves from inside the launch
+ * When one launch covers the whole call, the wave that coded a chunk also moves its bytes from the chunk's slot to their
+ * place in the destination - HBM, or the caller's pinned buffer across PCIe, which then carries the stream while the
+ * parse is still running instead of for 7 ms after it (1 GiB call).  A chunk's place is the sum of the lengths before
+ * it, so:
+ *   pub[c]   stream length of chunk c + 1, stored (agent scope) by the wave that coded it; 0 = not yet
+ *   front    chunks << 40 | bytes: every chunk below `chunks` has its offset; bytes = their total
+ *   offs[c]  offset of chunk c + 1, written by whoever moved the front past c
+ * Any wave that has just published a length tries to move the front: sixty-four lanes look at pub[front ..], the run of
+ * coded chunks from the front on gets its offsets from one wave prefix sum, one atomic maximum publishes the new front
+ * (a wave that was overtaken has computed and stored the very same offsets).  A wave copies its own chunks only (bytes it stored itself, so
+ * its own L2 has them - no fence), oldest first, as soon as the front has passed them; what is still behind an unfinished
+ * older chunk waits in a list of eight (LDS) while the wave parses on, and is waited for when the list is full or the
+ * chunks have run out.  The wave that moves the front to the end stores the total.  overflow: 1 = destination too small,
+ * 2 = a wave waited two seconds in vain (some other wave is gone). */
+typedef struct {
+    uint8_t *dst; uint64_t cap;          /* dst NULL: a scan and a gather kernel behind the launch do it */
+    uint64_t *front; uint32_t *pub; uint64_t *offs;
+    uint64_t *running; uint32_t *overflow;
+} qzk_outp;
+#define QZK_OUT_PEND 8
+
+#ifndef QZ_SIM
+QZ_DEV uint64_t qzk_out_advance(const qzk_outp O, uint32_t nchunks, int lane)
+{
+    for (;;) {
+        const uint64_t f0 = __hip_atomic_load(O.front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t f = (uint64_t)qz_readfirstlane((uint32_t)f0) | (uint64_t)qz_readfirstlane((uint32_t)(f0 >> 32)) << 32;
+        const uint32_t F = (uint32_t)(f >> 40);
+        const uint64_t B = f & ((1ull << 40) - 1);
+        if (F >= nchunks) return f;
+        const uint32_t idx = F + (uint32_t)lane;
+        const uint32_t p = idx < nchunks ? __hip_atomic_load(O.pub + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint64_t ok = qz_ballot(p != 0);
+        const int k = ~ok ? qz_ctz64(~ok) : 64;
+        if (k == 0) return f;
+        const uint32_t l = lane < k ? p - 1 : 0u;
+        const uint32_t incl = qzk_wave_incl_scan(l, lane);
+        if (lane < k) __hip_atomic_store(O.offs + idx, B + incl - l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t tot = qz_readlane(incl, 63);
+        const uint64_t nf = (uint64_t)(F + (uint32_t)k) << 40 | (B + tot);
+        /* the front only grows and a later front is a larger word: a maximum publishes it, whoever else got there first.
+         * A wave-uniform operand: the compiler issues ONE atomic for the wave, as for the chunk counter */
+        __hip_atomic_fetch_max(O.front, nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (F + (uint32_t)k >= nchunks) *O.running = B + tot;          /* every wave that gets here stores the same total */
+    }
+}
+
+/* copy out what the front has passed; block: until nothing is pending (ph == pt on return unless a wave is gone) */
+QZ_DEV void qzk_out_drain(const qzk_outp O, const uint8_t *slots, uint32_t slot_stride, const uint32_t *pend, uint32_t *ph,
+                          uint32_t pt, uint32_t nchunks, bool block, int lane)
+{
+    uint32_t naps = 0;
+    while (*ph != pt) {
+        const uint64_t f = qzk_out_advance(O, nchunks, lane);
+        const uint32_t c0 = pend[*ph % QZK_OUT_PEND];
+        if ((uint32_t)(f >> 40) > c0) {
+            uint64_t o1 = 0;
+            for (uint32_t t = 0; t < (1u << 20) && o1 == 0; t++) {                     /* stored before the front moved; a few turns at worst */
+                const uint64_t v = __hip_atomic_load(O.offs + c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                o1 = (uint64_t)qz_readfirstlane((uint32_t)v) | (uint64_t)qz_readfirstlane((uint32_t)(v >> 32)) << 32;
+            }
+            const uint32_t n = qz_readfirstlane(__hip_atomic_load(O.pub + c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - 1;
+            const uint64_t o = o1 - 1;
+            if (o1 == 0) atomicOr(O.overflow, 2u);
+            else if (o + n > O.cap) atomicOr(O.overflow, 1u);
+            else {
+                const uint8_t *s = slots + (uint64_t)c0 * slot_stride;
+                uint8_t *d = O.dst + o;
+                const uint32_t nw = n >> 2;
+                uint32_t i = (uint32_t)lane;
+                for (; i + 192 < nw; i += 256) {                                        /* four loads in flight per lane */
+                    const uint32_t a = ((const uint32_t *)s)[i], b = ((const uint32_t *)s)[i + 64], c = ((const uint32_t *)s)[i + 128],
+                                   e = ((const uint32_t *)s)[i + 192];
+                    ((qz_u32u *)d)[i].v = a; ((qz_u32u *)d)[i + 64].v = b; ((qz_u32u *)d)[i + 128].v = c; ((qz_u32u *)d)[i + 192].v = e;
+                }
+                for (; i < nw; i += 64) ((qz_u32u *)d)[i].v = ((const uint32_t *)s)[i];
+                for (uint32_t j = (nw << 2) + (uint32_t)lane; j < n; j += 64) d[j] = s[j];
+            }
+            (*ph)++;
+            continue;
+        }
+        if (!block) return;
+        __builtin_amdgcn_s_sleep(38);
+        if (++naps > (2u << 20)) { atomicOr(O.overflow, 2u); return; }
+    }
+}
+#endif
+
 #define QZK_K1_LDSW (QZK_K1_PARSEW > (sizeof(qzk_huff_lds) + 3) / 4 ? QZK_K1_PARSEW : (sizeof(qzk_huff_lds) + 3) / 4)
 QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                                                      uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tables,
                                                      uint32_t *counter, const uint32_t *cdesc, uint32_t epoch_base,
                                                      uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk, uint32_t *out_len,
                                                      uint32_t *crc_out /* per chunk, or NULL */,
-                                                     const uint32_t *avail /* NULL: the input is all there */)
+                                                     const uint32_t *avail /* NULL: the input is all there */, const qzk_outp O)
 {
-    QZ_LDS uint32_t lds_all[QZK_K1_WAVES][QZK_K1_LDSW];
+    QZ_LDS uint32_t lds_all[QZK_K1_WAVES][QZK_K1_LDSW + QZK_OUT_PEND];
     QZ_LDS qzk_k1crc_lds crcT;
     if (crc_out) qzk_k1crc_init(&crcT);             /* kernel argument: the whole workgroup takes the same way */
     const int wv = (int)(threadIdx.x >> 6);
     uint32_t *const lds = lds_all[wv];
     qzk_bkt *tab = tables + (size_t)blockIdx.x * QZK_HSIZE * QZK_K1_WAVES + wv;
+    uint32_t *const pend = lds + QZK_K1_LDSW;       /* chunks coded by this wave whose bytes have not left their slots yet */
+    uint32_t ph = 0, pt = 0;
     for (;;) {
         /* no `if (lane == 0)` block at the start or the end of this loop's body: the compiler threads lane-0-only blocks
          * of consecutive iterations together, after which the other 63 lanes would run readfirstlane without lane 0 (seen
@@ -681,7 +773,10 @@ QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_p
         uint32_t chunk = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);
         chunk = qz_readfirstlane(chunk);
         if (chunk >= nchunks) break;
-        if (avail && !qzk_wait_input(avail, chunk + 2 < nchunks ? chunk + 2 : nchunks)) break;    /* kernel argument + wave-uniform values */
+        if (avail) {                                   /* kernel argument, wave-uniform values */
+            const uint32_t ahead = 1u + 1024u / chunk_sz;                   /* whole chunks the ring's read-ahead may touch */
+            if (!qzk_wait_input(avail, chunk + 1 + ahead < nchunks ? chunk + 1 + ahead : nchunks, chunk_sz)) break;
+        }
         /* symbols: with K2 in the wave they only live until the wave has coded them - one chunk's worth per WAVE (read
          * back at the L2: the same addresses carried the previous chunk's symbols); without, one per chunk of the launch */
         const uint64_t soff = slots ? (uint64_t)(blockIdx.x * QZK_K1_WAVES + (uint32_t)wv) * chunk_sz : (uint64_t)chunk * chunk_sz;
@@ -705,8 +800,21 @@ QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_p
                                  slots + (uint64_t)chunk * slot_stride, is_final, out_len + chunk);
 #endif
             qz_lds_sync();
+#ifndef QZ_SIM
+            if (O.dst) {                            /* kernel argument */
+                const uint32_t n1 = qz_readfirstlane(__hip_atomic_load(out_len + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1;
+                __hip_atomic_store(O.pub + chunk, n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* every lane, the same word */
+                pend[pt % QZK_OUT_PEND] = chunk;
+                pt++;
+                qz_lds_sync();
+                qzk_out_drain(O, slots, slot_stride, pend, &ph, pt, nchunks, pt - ph == QZK_OUT_PEND, qz_lane());
+            }
+#endif
         }
     }
+#ifndef QZ_SIM
+    if (O.dst && slots) qzk_out_drain(O, slots, slot_stride, pend, &ph, pt, nchunks, true, qz_lane());
+#endif
 }
 
 #endif

@@ -38,7 +38,7 @@ static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_
     }
     uint32_t counter = 0;
     sim::launch(wgs, 64 * waves, 0, [&] { qzk_lz77_pull_kernel(src, n, chunk_sz, nchunks, lc, dist, meta, tables.data(), &counter, cdesc, g_k1_epoch,
-                                                                slots, stride, final_chunk, olen, ocrc, (const uint32_t *)nullptr); });
+                                                                slots, stride, final_chunk, olen, ocrc, (const uint32_t *)nullptr, qzk_outp{}); });
     g_k1_epoch += nchunks;
 }
 

@@ -853,6 +853,47 @@ def test_pinned_destination_receives_the_stream_directly(fmt):
     s.close()
 
 
+@pytest.mark.parametrize("hw,pinned", [(65536, True), (65536, False), (16384, True), (131072, True)])
+def test_large_host_input_feeds_a_launch_that_is_already_running(hw, pinned):
+    """qzCompress of 64 MiB and more from host memory: ONE launch starts at once and takes its chunks as the pieces of the
+    copy land (qzk_wait_input; the host raises the watermark).  The same source buffer is filled three times with different
+    data, so a wave that read a chunk before it had landed - or a line of an earlier round left in a cache - would show:
+    every round must equal the software path's bytes (src/qatzip_sw.c:77-256), and the batched pipeline's
+    (QATZIP_AMD_HOST_BATCHED=1) once."""
+    L = A.lib()
+    s = A.Session(data_fmt=A.QZ_DEFLATE_GZIP_EXT, hw_buff_sz=hw)
+    n = (80 << 20) + 12345
+    cap = L.qzMaxCompressedLength(n, C.byref(s.s)) + 64
+    if pinned:
+        psrc = L.qzMalloc(n, -1, A.PINNED_MEM); pdst = L.qzMalloc(cap, -1, A.PINNED_MEM)
+        assert psrc and pdst
+    else:
+        hold = (C.create_string_buffer(n), C.create_string_buffer(cap))
+        psrc, pdst = C.addressof(hold[0]), C.addressof(hold[1])
+
+    def once():
+        sl, dl = C.c_uint(n), C.c_uint(cap)
+        rc = L.qzCompress(C.byref(s.s), C.cast(psrc, C.c_char_p), C.byref(sl), C.c_void_p(pdst), C.byref(dl), 1)
+        assert rc == A.QZ_OK and sl.value == n, rc
+        return C.string_at(pdst, dl.value)
+
+    for rnd, kind in enumerate(("silesia", "rand", "lzmix")):
+        src = datagen.gen_bytes(kind, n, 300 + rnd)
+        C.memmove(psrc, src, n)
+        got = once()
+        exp = O.sw_compress("GZIP_EXT", src, hw, 1, cap=cap)[2]
+        assert got == exp, (kind, hw, pinned, len(got), len(exp))
+        if rnd == 0:
+            os.environ["QATZIP_AMD_HOST_BATCHED"] = "1"
+            try:
+                assert once() == exp
+            finally:
+                del os.environ["QATZIP_AMD_HOST_BATCHED"]
+    if pinned:
+        L.qzFree(psrc); L.qzFree(pdst)
+    s.close()
+
+
 def test_async_requests_of_a_hardware_framing_session_keep_their_framing():
     """advisor (round 2): qzCompress2 requests of a qzamd_set_hw_framing session that wait in the queue together must come
     out framed exactly like one running alone - one complete member per chunk, XFL 0, OS 255 - not in the software path's

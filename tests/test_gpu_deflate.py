@@ -182,3 +182,38 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_stream_moved_by_the_parse_waves_themselves(ctx):
+    """QATZIP_AMD_K1_OUT=launch: the waves of the one launch also put every chunk's stream in its place (front word,
+    published lengths, offsets by wave prefix sums - qzk_out_advance / qzk_out_drain) instead of a scan and a gather kernel
+    behind it; the product does so for calls fed from host memory.  Same bytes as the software path, chunks of very
+    different cost next to each other so that the front stalls behind slow ones, a destination that is too small"""
+    import os
+    import qatzip_amd
+    old = os.environ.get("QATZIP_AMD_K1_OUT"), os.environ.get("QATZIP_AMD_K1")
+    os.environ["QATZIP_AMD_K1_OUT"] = "launch"; os.environ["QATZIP_AMD_K1"] = "pull"
+    try:
+        parts = []
+        for i in range(400):                                   # 400 pieces of 5 kinds, 40 KiB - 104 KiB each: ~28 MiB
+            kind = ("rand", "allA", "silesia", "runs", "text")[i % 5]
+            parts.append(datagen.gen_bytes(kind, 40960 + 163 * i, 1000 + i))
+        src = b"".join(parts)
+        for chunk in (65536, 16384):
+            got, crcs = _gpu_raw(ctx, src, chunk)
+            exp = O.sw_compress("RAW", src, chunk, 1, cap=len(src) * 9 // 8 + (1 << 20))[2]
+            assert got == exp, (chunk, len(got), len(exp))
+        for n in (0, 1, 65536, 65537, 5 * 65536 + 1):
+            got, _ = _gpu_raw(ctx, src[:n], 65536, last=0)
+            assert got == O.sw_compress("RAW", src[:n], 65536, 1, last=0, cap=n * 9 // 8 + 65536)[2], n
+        d_src = ctx.alloc(len(src)); d_src.upload(src)
+        d_small = ctx.alloc(len(exp) // 2)
+        with pytest.raises(qatzip_amd.QzdError):
+            ctx.deflate_raw(d_src, len(src), 16384, 1, 1, d_small)
+        d_src.free(); d_small.free()
+    finally:
+        for k, v in zip(("QATZIP_AMD_K1_OUT", "QATZIP_AMD_K1"), old):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
