@@ -10,11 +10,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 
 def load(d, name):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)     # gpurun merges into a directory that may hold an older pass
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name:
