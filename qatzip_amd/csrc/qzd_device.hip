@@ -8,8 +8,11 @@
  * its CRC-32 along the input reads; then
  *   scan of the lengths (running total carried in HBM, no host round trip)
  *   gather of the slots into the contiguous destination.
- * Input still on the host (qzd_deflate_raw_from_host): batches of qzd_ctx::batch_chunks chunks alternating over two
- * streams, batch k+1's copy (third stream) beside batch k's kernels.  Many small requests in one launch: per-slot lengths
+ * Input still on the host (qzd_deflate_raw_from_host), 64 MiB and more: the same one launch, started at once and fed while
+ * it runs - the host raises a watermark in pinned memory as the pieces of its copy land (qzk_wait_input) - and its waves
+ * move the coded chunks to the destination themselves, in stream order (qzk_outp: no scan, no gather behind it).  Smaller
+ * host calls: batches of qzd_ctx::batch_chunks chunks alternating over two streams, batch k+1's copy (third stream)
+ * beside batch k's kernels.  Many small requests in one launch: per-slot lengths
  * (qzd_deflate_slots).  comp_lvl 2-9: K1b qzk_lz77_lane_kernel / the lazy kernels in place of K1, then qzk_huff_kernel and
  * qzk_crc_chunks_kernel as launches of their own (also level 1 with QATZIP_AMD_FUSE=0, round 1's pipeline).
  */
