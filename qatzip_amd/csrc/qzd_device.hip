@@ -226,6 +226,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     hipFree(c->k1_counter);
     hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs); hipFree(c->d_running); hipFree(c->d_overflow);
     hipHostFree(c->h_running); hipHostFree(c->h_overflow); if (c->h_wm) hipHostFree(c->h_wm);
+    if (c->d_lz4tab) hipFree(c->d_lz4tab);
     if (c->d_aux) hipFree(c->d_aux);
     if (c->h_aux) hipHostFree(c->h_aux);
     if (c->d_big) hipFree(c->d_big);
@@ -1014,7 +1015,26 @@ static int lz4_compress_frames_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n
     for (uint32_t b = 0; b < nfr; b += batch) {
         const uint32_t bn = nfr - b < batch ? nfr - b : batch;
         const uint64_t boff = (uint64_t)b * frame_sz;
-        hipLaunchKernelGGL(qzk_lz4c_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, bn, c->slots[0], stride, c->d_len + b, hw_hdr);
+        /* many frames: persistent waves with their hash tables in device memory, as many per CU as it has wave slots
+         * (QATZIP_AMD_LZ4_WPC=<waves per CU>, 0 = the one-launch-per-frame kernel with the table in LDS) */
+        uint32_t wpc = 24;          /* measured 8 / 16 / 24 / 32: 10.4 / 15.2 / 17.1 / 17.2 GB/s (table in LDS, 8 waves: 13.2) */
+        if (const char *e = getenv("QATZIP_AMD_LZ4_WPC")) wpc = (uint32_t)atoi(e);
+        if (wpc > 32) wpc = 32;
+        const uint32_t cus = c->cus ? c->cus : 256u;
+        if (wpc && bn > 8 * cus) {
+            const uint32_t waves = std::min<uint32_t>(bn, wpc * cus);
+            if (waves > c->lz4tab_waves) {
+                hipDeviceSynchronize();
+                if (c->d_lz4tab) hipFree(c->d_lz4tab);
+                c->d_lz4tab = NULL; c->lz4tab_waves = 0;
+                HIPCHK(c, hipMalloc(&c->d_lz4tab, 256 + (size_t)waves * QZK_LZ4_HASHSZ * 2));
+                c->lz4tab_waves = waves;
+            }
+            HIPCHK(c, hipMemsetAsync(c->d_lz4tab, 0, 4, st));
+            hipLaunchKernelGGL(qzk_lz4c_pull_kernel, dim3(waves), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, bn, c->slots[0], stride,
+                               c->d_len + b, hw_hdr, (uint16_t *)(c->d_lz4tab + 256), (uint32_t *)c->d_lz4tab);
+        } else
+            hipLaunchKernelGGL(qzk_lz4c_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, bn, c->slots[0], stride, c->d_len + b, hw_hdr);
         hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);
         hipLaunchKernelGGL(qzk_gather_kernel, dim3(bn), dim3(256), 0, st, c->slots[0], stride, c->d_len + b, c->d_offs + b, bn, d_dst, dst_cap, c->d_overflow);
     }

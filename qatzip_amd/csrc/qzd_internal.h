@@ -38,6 +38,7 @@ struct qzd_ctx {
     uint32_t *d_len, *d_crc; uint64_t *d_offs; uint32_t call_cap;
     uint64_t *d_running; uint32_t *d_overflow;
     uint64_t *h_running; uint32_t *h_overflow;      /* pinned */
+    uint8_t *d_lz4tab; uint32_t lz4tab_waves;       /* qzk_lz4c_pull_kernel: frame counter (256 B) + one 16 KiB hash table per resident wave */
     uint32_t *h_wm;                                 /* pinned, read by qzk_lz77_pull_kernel: [0] chunks of host input landed, [1] a wave gave up waiting */
     /* timing */
     hipEvent_t ev[QZD_NBUF][4]; hipEvent_t ev_begin, ev_end;

@@ -105,13 +105,34 @@ QZ_DEV uint32_t qzk_lz4_hash5(const uint8_t *p)
  * in LDS, zeroed here).  LINKED = true: one block of a linked frame that starts at in[0] (LZ4_compress_fast_continue:
  * the frame's table - 4096 u32, 12-bit hash of 5 bytes - comes in and goes out with everything earlier blocks and this
  * one inserted, also when this block does not fit; candidates up to 65535 bytes back, across block borders). */
-template <bool LINKED, typename TAB>
+/* GTAB: the (16-bit, independent-block) table lives in device memory instead of LDS - 16 KiB per wave that then do not
+ * decide how many waves a CU holds (qzk_lz4c_pull_kernel).  A lookup is served by the L2 (`sc1`: this CU's L1 may hold the
+ * line from before one of this wave's own stores, which write through and do not refresh it); a wave's loads follow its
+ * stores to the L2 in issue order. */
+typedef uint32_t qzk_lz4_u32x4 __attribute__((vector_size(16)));
+template <bool GTAB, typename TAB>
+QZ_DEV uint32_t qzk_lz4_tld(const TAB *table, uint32_t h)
+{
+#ifndef QZ_SIM
+    if (GTAB) {
+        uint32_t v;
+        asm volatile("global_load_ushort %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(table + h) : "memory");
+        return v;
+    }
+#endif
+    return table[h];
+}
+
+template <bool LINKED, typename TAB, bool GTAB = false>
 QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint8_t *out, uint32_t cap, TAB *table,
                                 uint32_t *slot, int lane)
 {
 #define QZK_LZ4H(pos, v4) (LINKED ? qzk_lz4_hash5(in + (pos)) : QZK_LZ4HASH(v4))
 #define QZK_LZ4NEAR(cand, cur) (!LINKED || (cand) + 65535u >= (cur))
-    if (!LINKED) { for (int i = lane; i < QZK_LZ4_HASHSZ; i += 64) table[i] = 0; }
+    if (!LINKED) {
+        if (GTAB) { for (int i = lane; i < (int)(QZK_LZ4_HASHSZ * sizeof(TAB) / 16); i += 64) { qzk_lz4_u32x4 z = {0, 0, 0, 0}; ((qzk_lz4_u32x4 *)table)[i] = z; } }
+        else { for (int i = lane; i < QZK_LZ4_HASHSZ; i += 64) table[i] = 0; }
+    }
     qz_wave_sync();
     const uint32_t be = bs + n;
     uint32_t op = 0, anchor = bs, ip;
@@ -133,7 +154,7 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                 const uint32_t f = ip + (j ? 1 + 32 * b * (b + 1) + (b + 1) * r : 0), step = j ? (63 + j) >> 6 : 1;
                 const bool live = (int32_t)(f + step) <= mfl1;       /* else this probe is the `goto _last_literals` */
                 uint32_t v = 0, h = 0, cand = 0;
-                if (live) { v = qz_ld32(in + f); h = QZK_LZ4H(f, v); cand = table[h]; }
+                if (live) { v = qz_ld32(in + f); h = QZK_LZ4H(f, v); cand = qzk_lz4_tld<GTAB>(table, h); }
                 const uint32_t key = h & 1023;
                 if (live) slot[key] = 64;
                 qz_wave_sync();
@@ -235,7 +256,7 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                 uint32_t h2 = QZK_LZ4H(mip - 2, v2), h0 = QZK_LZ4H(mip, v0);
                 if (lane == 0) table[h2] = (TAB)(mip - 2);
                 qz_wave_sync();
-                uint32_t mi = table[h0];
+                uint32_t mi = qzk_lz4_tld<GTAB>(table, h0);
                 qz_wave_sync();
                 if (lane == 0) table[h0] = (TAB)mip;
                 qz_wave_sync();
@@ -264,22 +285,19 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
 #undef QZK_LZ4H
 #undef QZK_LZ4NEAR
 }
+template <bool GTAB>
 QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap, uint16_t *table, uint32_t *slot, int lane)
-{ return qzk_lz4_block_t<false, uint16_t>(in, 0, n, out, cap, table, slot, lane); }
+{ return qzk_lz4_block_t<false, uint16_t, GTAB>(in, 0, n, out, cap, table, slot, lane); }
 
 /* K4: one LZ4 frame (<= 64 KB of content, one independent block) per wave, written to its slot:
  * LZ4F_compressFrame with {contentChecksum, contentSize, autoFlush, level < 3}. */
 /* hw_hdr: the header the reference's HARDWARE path puts in front of a chunk's frame (qzLZ4HeaderGen, src/qatzip_lz4.c:104-132):
  * FLG 0x4C - version 1, blocks NOT marked independent, content size always present, content checksum - instead of
  * liblz4's 0x6C (or 0x64 for an empty call); everything behind the header checksum byte is the same frame */
-QZ_KERNEL_MAX(64) qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
-                          uint8_t *slots, uint32_t stride, uint32_t *out_len, uint32_t hw_hdr)
+template <bool GTAB>
+QZ_DEV void qzk_lz4c_frame(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t fr, uint8_t *slots, uint32_t stride,
+                           uint32_t *out_len, uint32_t hw_hdr, uint16_t *table, uint32_t *slot, int lane)
 {
-    QZ_LDS uint16_t table[QZK_LZ4_HASHSZ];
-    QZ_LDS uint32_t slot[1024];
-    const int lane = qz_lane();
-    const uint32_t fr = blockIdx.x;
-    if (fr >= nframes) return;
     const uint64_t off = (uint64_t)fr * frame_sz;
     const uint32_t n = (uint32_t)((src_len - off) < frame_sz ? (src_len - off) : frame_sz);
     const uint8_t *in = src + off;
@@ -300,7 +318,7 @@ QZ_KERNEL_MAX(64) qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t
         pos++;
     }
     if (n) {
-        uint32_t c = qzk_lz4_block(in, n, o + pos + 4, n - 1, table, slot, lane);
+        uint32_t c = qzk_lz4_block<GTAB>(in, n, o + pos + 4, n - 1, table, slot, lane);
         uint32_t bh = c ? c : (n | 0x80000000u);
         if (c == 0) { qzk_wave_copy(o + pos + 4, in, n, lane); c = n; }
         if (lane == 0) { o[pos] = (uint8_t)bh; o[pos + 1] = (uint8_t)(bh >> 8); o[pos + 2] = (uint8_t)(bh >> 16); o[pos + 3] = (uint8_t)(bh >> 24); }
@@ -310,7 +328,37 @@ QZ_KERNEL_MAX(64) qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t
     if (lane == 0) {
         o[pos] = o[pos + 1] = o[pos + 2] = o[pos + 3] = 0;
         o[pos + 4] = (uint8_t)xx; o[pos + 5] = (uint8_t)(xx >> 8); o[pos + 6] = (uint8_t)(xx >> 16); o[pos + 7] = (uint8_t)(xx >> 24);
-        out_len[fr] = pos + 8;
+    }
+    out_len[fr] = pos + 8;          /* wave-uniform: every lane stores the same word */
+}
+
+QZ_KERNEL_MAX(64) qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
+                          uint8_t *slots, uint32_t stride, uint32_t *out_len, uint32_t hw_hdr)
+{
+    QZ_LDS uint16_t table[QZK_LZ4_HASHSZ];
+    QZ_LDS uint32_t slot[1024];
+    const uint32_t fr = blockIdx.x;
+    if (fr >= nframes) return;
+    qzk_lz4c_frame<false>(src, src_len, frame_sz, fr, slots, stride, out_len, hw_hdr, table, slot, qz_lane());
+}
+
+/* K4 for calls of many frames: the same frames by PERSISTENT single-wave workgroups that pull frame numbers, with the hash
+ * table of the wave in device memory (tables + wave * QZK_LZ4_HASHSZ) - only the 4 KiB slot table is left in LDS, so a CU
+ * holds as many of these waves as it has wave slots instead of the eight that 20 KiB each allow.  The compressor is one
+ * latency chain per frame (probes' words, table, candidates' words, extension, count - global round trips all of them;
+ * profiles/r3_lz4_ring_experiment.txt: its rate follows the waves in flight, not the latency of one), so the extra round
+ * trip to the L2 per lookup is paid back several times by the waves that now fit. */
+QZ_KERNEL_OCC(64, 8) qzk_lz4c_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
+                          uint8_t *slots, uint32_t stride, uint32_t *out_len, uint32_t hw_hdr, uint16_t *tables, uint32_t *counter)
+{
+    QZ_LDS uint32_t slot[1024];
+    uint16_t *const table = tables + (size_t)blockIdx.x * QZK_LZ4_HASHSZ;
+    for (;;) {
+        uint32_t fr = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);       /* every lane takes part, lane 0 adds (see qzk_lz77_pull_kernel) */
+        fr = qz_readfirstlane(fr);
+        if (fr >= nframes) break;
+        qzk_lz4c_frame<true>(src, src_len, frame_sz, fr, slots, stride, out_len, hw_hdr, table, slot, qz_lane());
+        qz_wave_sync();
     }
 }
 

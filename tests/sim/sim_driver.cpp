@@ -261,6 +261,16 @@ int sim_lz4c(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, 
     sim::launch(nframes, 64, 0, [&] { qzk_lz4c_kernel(src, n, frame_sz, nframes, slots, stride, out_len, 0); });
     return (int)nframes;
 }
+/* the same frames by persistent waves that pull frame numbers, hash tables outside LDS (qzk_lz4c_pull_kernel): fewer waves than frames */
+int sim_lz4c_pull(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, uint32_t stride, uint32_t *out_len, uint32_t waves)
+{
+    uint32_t nframes = n ? (uint32_t)((n + frame_sz - 1) / frame_sz) : 1;
+    std::vector<uint16_t> tables((size_t)waves * QZK_LZ4_HASHSZ + 8, (uint16_t)0xabcd);      /* junk: every frame clears its own */
+    uint16_t *tab = (uint16_t *)(((uintptr_t)tables.data() + 15) & ~(uintptr_t)15);
+    uint32_t counter = 0;
+    sim::launch(waves, 64, 0, [&] { qzk_lz4c_pull_kernel(src, n, frame_sz, nframes, slots, stride, out_len, 0, tab, &counter); });
+    return (int)nframes;
+}
 /* the same frames behind the hardware path's header (FLG 0x4C, content size always there) */
 int sim_lz4c_hw(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, uint32_t stride, uint32_t *out_len)
 {

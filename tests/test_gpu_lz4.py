@@ -105,6 +105,45 @@ def test_lz4_throughput_smoke(ctx):
     assert total < base.size
 
 
+def test_many_frames_by_persistent_waves_with_tables_in_device_memory(ctx):
+    """calls of more than eight frames per CU go through qzk_lz4c_pull_kernel (persistent waves pull frame numbers, each
+    wave's 16-bit hash table in device memory instead of LDS): every frame byte-identical to the one-wave-per-frame kernel
+    with its table in LDS (QATZIP_AMD_LZ4_WPC=0), a sample of them to liblz4's (the oracle, src/qatzip_sw.c:443-471), ragged
+    last frame, 16 KB frames too"""
+    import os
+    import numpy as np
+    parts = [datagen.gen(k, 16 << 20, 500 + i) for i, k in enumerate(("silesia", "text", "rand", "runs", "records", "lzmix",
+                                                                      "silesia", "text", "mod200", "allA"))]
+    src = np.concatenate(parts)[:(150 << 20) + 4321]
+    d_src = ctx.alloc(src.size); d_src.upload(src)
+    for fs in (65536, 16384):
+        n = src.size if fs == 65536 else (40 << 20) + 77
+        nfr = (n + fs - 1) // fs
+        d_a = ctx.alloc(n + nfr * 64 + 4096); d_b = ctx.alloc(n + nfr * 64 + 4096)
+        old = os.environ.get("QATZIP_AMD_LZ4_WPC")
+        try:
+            os.environ.pop("QATZIP_AMD_LZ4_WPC", None)
+            ta, la = ctx.lz4_compress_frames(d_src, n, d_a, fs)
+            os.environ["QATZIP_AMD_LZ4_WPC"] = "0"
+            tb, lb = ctx.lz4_compress_frames(d_src, n, d_b, fs)
+        finally:
+            if old is None:
+                os.environ.pop("QATZIP_AMD_LZ4_WPC", None)
+            else:
+                os.environ["QATZIP_AMD_LZ4_WPC"] = old
+        assert ta == tb and (la == lb).all()
+        a = d_a.download(ta); b = d_b.download(tb)
+        assert np.array_equal(a, b), fs
+        offs = np.concatenate([[0], np.cumsum(la.astype(np.int64))])
+        rng = np.random.default_rng(7)
+        for i in list(rng.integers(0, nfr, 40)) + [0, nfr - 1]:
+            piece = src[i * fs:min((i + 1) * fs, n)].tobytes()
+            exp = O.sw_compress("LZ4", piece, 65536, 1, cap=len(piece) + len(piece) // 255 + 200)[2]
+            assert a[offs[i]:offs[i + 1]].tobytes() == exp, (fs, i)
+        d_a.free(); d_b.free()
+    d_src.free()
+
+
 def test_lz4_session_in_hardware_path_framing():
     """qzamd_set_hw_framing on an LZ4 session: one frame per hw_buff_sz chunk behind qzLZ4HeaderGen's header (FLG 0x4C,
     content size = consumed, src/qatzip_lz4.c:104-132) with qzLZ4FooterGen's end mark + XXH32 (:134-143); hw_buff_sz above

@@ -322,6 +322,7 @@ def test_lz4_frames_match_oracle(sim):
     the kernel's 16-bit hash table and its elected last writer against the oracle, every kind, sizes around the limits of
     lz4's loop (MFLIMIT, 64 KB) and incompressible input (stored block)"""
     sim.sim_lz4c.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    sim.sim_lz4c_pull.argtypes = sim.sim_lz4c.argtypes + [C.c_uint32]
     for kind in datagen.KINDS:
         for n, fs in ((0, 65536), (1, 65536), (12, 65536), (13, 65536), (14, 65536), (300, 65536), (65535, 65536), (65536, 65536),
                       (200000, 65536), (70000, 16384), (9000, 1024)):
@@ -332,11 +333,19 @@ def test_lz4_frames_match_oracle(sim):
             stride = (fs + 15 + 4 + 8 + 64 + 15) & ~15
             slots = np.zeros(nfr * stride, np.uint8); lens = np.zeros(nfr, np.uint32)
             sim.sim_lz4c(src, n, fs, slots.ctypes.data, stride, lens.ctypes.data)
+            exps = []
             for i in range(nfr):
                 piece = src[i * fs:(i + 1) * fs]
                 exp = O.sw_compress("LZ4", piece, 65536, 1, cap=len(piece) + len(piece) // 255 + 200)[2]
+                exps.append(exp)
                 got = bytes(slots[i * stride:i * stride + int(lens[i])])
                 assert got == exp, (kind, n, fs, i, int(lens[i]), len(exp))
+            if nfr > 1 or n in (0, 300, 65536):
+                # the persistent form (qzk_lz4c_pull_kernel): two waves pull the frames, their tables live outside LDS
+                slots[:] = 0; lens[:] = 0
+                sim.sim_lz4c_pull(src, n, fs, slots.ctypes.data, stride, lens.ctypes.data, 2)
+                for i in range(nfr):
+                    assert bytes(slots[i * stride:i * stride + int(lens[i])]) == exps[i], (kind, n, fs, i, "pull")
 
 
 def test_wide_window_parse_is_exact(sim):
