@@ -1017,7 +1017,7 @@ static int lz4_compress_frames_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n
         const uint64_t boff = (uint64_t)b * frame_sz;
         /* many frames: persistent waves with their hash tables in device memory, as many per CU as it has wave slots
          * (QATZIP_AMD_LZ4_WPC=<waves per CU>, 0 = the one-launch-per-frame kernel with the table in LDS) */
-        uint32_t wpc = 24;          /* measured 8 / 16 / 24 / 32: 10.4 / 15.2 / 17.1 / 17.2 GB/s (table in LDS, 8 waves: 13.2) */
+        uint32_t wpc = 32;          /* measured 24 / 32: 19.6 / 21.6 GB/s (table in LDS, 8 waves: 13.2) - profiles/r3_lz4_ring_experiment.txt */
         if (const char *e = getenv("QATZIP_AMD_LZ4_WPC")) wpc = (uint32_t)atoi(e);
         if (wpc > 32) wpc = 32;
         const uint32_t cus = c->cus ? c->cus : 256u;

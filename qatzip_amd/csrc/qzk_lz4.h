@@ -27,6 +27,9 @@
 #define QZK_LZ4_LASTLIT 5
 #define QZK_LZ4_HASHSZ 8192
 #define QZK_LZ4_MAXBLK 65536
+#ifndef QZK_LZ4_W0
+#define QZK_LZ4_W0 16u             /* probes in the first window of a search streak */
+#endif
 
 #define QZK_XP1 2654435761u
 #define QZK_XP2 2246822519u
@@ -150,9 +153,15 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
             for (;;) {
                 /* probe j of a streak sits at ip + S(j): lz4 advances by step = 1 for the first probe and then by
                  * (searchMatchNb++ >> 6) with searchMatchNb starting at 64, i.e. step_j = (63 + j) >> 6 for j >= 1 */
+                /* a streak's first window is QZK_LZ4_W0 probes wide: on data that compresses the hit is usually among
+                 * them, and every probe costs a table lookup and a candidate compare at an address of its own (the CU's
+                 * address path is what this kernel runs into); streaks that go on take the whole wave */
+                const uint32_t W = j0 == 0 ? QZK_LZ4_W0 : 64u;
+                const bool inw = (uint32_t)lane < W;
                 const uint32_t j = j0 + (uint32_t)lane, t = j ? j - 1 : 0, b = t >> 6, r = t & 63;
                 const uint32_t f = ip + (j ? 1 + 32 * b * (b + 1) + (b + 1) * r : 0), step = j ? (63 + j) >> 6 : 1;
-                const bool live = (int32_t)(f + step) <= mfl1;       /* else this probe is the `goto _last_literals` */
+                const bool can = (int32_t)(f + step) <= mfl1;        /* else this probe is the `goto _last_literals` */
+                const bool live = inw && can;
                 uint32_t v = 0, h = 0, cand = 0;
                 if (live) { v = qz_ld32(in + f); h = QZK_LZ4H(f, v); cand = qzk_lz4_tld<GTAB>(table, h); }
                 const uint32_t key = h & 1023;
@@ -163,11 +172,11 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                 const bool suspect = live && slot[key] != (uint32_t)lane;
                 bool hit = false;
                 if (live && !suspect) hit = QZK_LZ4NEAR(cand, f) && qz_ld32(in + cand) == v;
-                const uint64_t LIVE = qz_ballot(live);
+                const uint64_t DEAD = qz_ballot(inw && !can);
                 uint64_t HIT = qz_ballot(hit);
                 const uint64_t SUS = qz_ballot(suspect);
-                const int first_dead = ~LIVE ? qz_ctz64(~LIVE) : 64;
-                int bound = HIT ? qz_ctz64(HIT) : 64;
+                const int first_dead = DEAD ? qz_ctz64(DEAD) : (int)W;
+                int bound = HIT ? qz_ctz64(HIT) : (int)W;
                 if (bound > first_dead) bound = first_dead;
                 /* replay colliding lanes that come before the first clean hit */
                 uint64_t todo = SUS & qz_below(bound);
@@ -183,9 +192,9 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                     if (near && cv == vs) { fl = s; fcand = cs; break; }
                 }
                 if (fl == bound && bound < first_dead && HIT) fcand = qz_readlane(cand, bound);
-                const bool got = fl < first_dead && (fl < bound || (HIT && bound < 64 && fl == bound));
+                const bool got = fl < first_dead && (fl < bound || (HIT && bound < (int)W && fl == bound));
                 /* insert every probed position up to and including the hit (or the whole window) */
-                const int last_ins = got ? fl : (first_dead < 64 ? first_dead - 1 : 63);
+                const int last_ins = got ? fl : (first_dead < (int)W ? first_dead - 1 : (int)W - 1);
                 if (sizeof(TAB) == 4) {
                     if (live && lane <= last_ins) atomicMax((uint32_t *)&table[h], f);
                     qz_wave_sync();
@@ -207,8 +216,8 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                     }
                 }
                 if (got) { found = true; mpos = qz_readlane(f, fl); mcand = fcand; break; }
-                if (first_dead < 64) break;                          /* ran into the end: last literals */
-                j0 += 64;
+                if (first_dead < (int)W) break;                      /* ran into the end: last literals */
+                j0 += W;
             }
             if (!found) break;
             /* ---------------- catch up + sequence(s) ---------------- */
