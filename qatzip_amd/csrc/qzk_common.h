@@ -61,6 +61,32 @@ static inline void qz_lds_sync() { qz_wave_sync(); }
 static inline uint8_t qz_ld8_l2(const uint8_t *p) { return *p; }
 #endif
 
+/* inclusive prefix sum over the 64 lanes of a wave (every lane active).  On the GPU: six DPP adds - shifts by 1, 2, 4, 8 inside
+ * the rows of sixteen, then the last lane of row 0 / 2 into the row behind it and of the lower half into the upper one - with no trip
+ * through the LDS crossbar (six ds_bpermute round trips the other way). */
+#ifndef QZ_SIM
+QZ_DEV uint32_t qz_wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      /* row_shr:1 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      /* row_shr:2 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      /* row_shr:4 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      /* row_shr:8 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      /* row_bcast:15 -> rows 1 and 3 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      /* row_bcast:31 -> rows 2 and 3 */
+    return v;
+}
+#else
+static inline uint32_t qz_wave_incl_scan(uint32_t v)
+{
+    const int lane = qz_lane();
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = qz_shfl(v, lane - d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+#endif
+
 QZ_DEV int qz_popc64(uint64_t v) { return __builtin_popcountll(v); }
 QZ_DEV int qz_ctz64(uint64_t v) { return __builtin_ctzll(v); }      /* v != 0 */
 QZ_DEV int qz_ctz32(uint32_t v) { return __builtin_ctz(v); }        /* v != 0 */

@@ -329,14 +329,7 @@ QZ_DEV void qzk_plan_block(qzk_huff_lds *S, uint32_t stored_len, bool can_store,
 }
 
 /* ------------------------------------------------------------------ wave helpers */
-QZ_DEV uint32_t qzk_wave_incl_scan(uint32_t v, int lane)
-{
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = qz_shfl(v, lane - d);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
+QZ_DEV uint32_t qzk_wave_incl_scan(uint32_t v, int lane) { (void)lane; return qz_wave_incl_scan(v); }
 
 /* symbol -> (bits, nbits) with the current code tables */
 QZ_DEV void qzk_sym_bits(const qzk_huff_lds *S, uint32_t lc, uint32_t dist, uint64_t *val, uint32_t *nb)

@@ -595,14 +595,7 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
 }
 
 /* ------------------------------------------------------------------ phase B */
-QZ_DEV uint32_t qzk_wave_scan_incl(uint32_t v, int lane)
-{
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = qz_shfl(v, lane - d);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
+QZ_DEV uint32_t qzk_wave_scan_incl(uint32_t v, int lane) { (void)lane; return qz_wave_incl_scan(v); }
 
 /* Phase B reads back bytes its own wave stored a moment ago (a match's source is earlier output): the stores are made
  * visible by a workgroup-scope fence (s_waitcnt vmcnt(0): the wave waits for its stores to reach the L2 at every
@@ -663,12 +656,27 @@ QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
 #ifndef QZK_COOP_LEN
 #define QZK_COOP_LEN 32            /* matches at least this long are copied by the whole wave */
 #endif
+/* A batch of 64 sequences is ~350 bytes of output on the bench data, and copying it as it stands is address-bound: every
+ * match is a per-lane load and a per-lane store at an address of its own (64 lanes, 64 lines, per dependency level), every
+ * 64 literals a store scattered over the batch.  Batches whose output fits QZK_RES_LIM bytes are therefore put together in
+ * LDS and leave as whole 16-byte rows: literals land in the wave's buffer, matches whose source lies before the batch read
+ * it from memory once (8 bytes a trip, no dependency between them: everything before the batch is final), matches inside
+ * the batch are byte copies within LDS in dependency order, and the finished batch goes out row by row.  The buffer is laid
+ * out with the destination's own 16-byte phase, so a row of LDS is a row of memory. */
+#ifndef QZK_RES_LIM
+#define QZK_RES_LIM 3072
+#endif
+#define QZK_RES_BUF (QZK_RES_LIM + 32)
+typedef uint32_t qzk_res_u32x4 __attribute__((vector_size(16)));
+
 QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                 const qzk_tokseg *ts, uint32_t ts_stride, const uint8_t *lits, const qzk_seq *seqs,
                                 const qzk_chain *chains, const uint32_t *order /* or NULL */, uint32_t count)
 {
     /* `order`: the launch covers `count` segments picked by index (a range of the OUTPUT, so that it can leave for the
      * host while the next range is resolved); NULL: all nsegs in array order */
+    QZ_LDS __attribute__((aligned(16))) uint8_t obuf_all[QZK_RES_WAVES][QZK_RES_BUF];
+    uint8_t *const ob = obuf_all[threadIdx.x >> 6];
     const int lane = qz_lane();
     const uint32_t widx = blockIdx.x * QZK_RES_WAVES + (threadIdx.x >> 6);
     if (widx >= (order ? count : nsegs)) return;
@@ -709,6 +717,112 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8
             if ((uint64_t)obase + Tb > sg.out_cap) err = QZK_INF_EOUT;
             else if (qz_ballot(mlen != 0 && (uint64_t)dist > (uint64_t)my_m + hist) != 0) err = QZK_INF_EHIST;
             if (err) break;
+            if (Tb <= QZK_RES_LIM) {                                        /* wave-uniform */
+                /* ---- the batch in LDS: position p of the segment's output sits at ob[p - obase + sh] ---- */
+                const uint32_t sh = (uint32_t)((uintptr_t)(o + obase) & 15);
+#define QZK_OBI(p) ((uint32_t)(p) - obase + sh)                             /* index in ob of output position p >= obase (plain LDS indices: a
+                                                                             * biased LDS pointer does not survive a cast to a flat one) */
+                for (uint32_t k0 = 0; k0 < Lb; k0 += 64) {
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    int j = 0;
+                    for (int step = 32; step; step >>= 1) if (qz_shfl(s_lit, j + step - 1) <= k) j += step;
+                    const uint32_t oj = qz_shfl(my_o, j), lj = qz_shfl(my_l0, j);
+                    if (k < Lb) ob[QZK_OBI(oj + (k - lj))] = lp[lbase + k];
+                }
+                /* no wait for the rows of earlier batches: a source before the batch is read by loads issued behind the
+                 * stores that wrote it, and a wave's memory operations reach the L2 in issue order */
+                qz_lds_sync();
+                /* matches whose (first period of) source ends before the batch: read from memory, nothing to wait for */
+                const int64_t sp0 = (int64_t)my_m - (int64_t)dist;
+                const uint32_t per = mlen < dist ? mlen : dist;
+                const bool outside = mlen != 0 && sp0 + (int64_t)per <= (int64_t)obase;
+                if (outside && mlen < QZK_COOP_LEN) {
+                    const uint8_t *sp = o + sp0;
+                    uint8_t *d = ob + QZK_OBI(my_m);
+                    if (dist >= mlen) {
+                        if (mlen >= 8) {
+                            uint32_t i = 0;
+                            for (; i + 8 <= mlen; i += 8) qzk_st64u(d + i, qzk_ld64u(sp + i));
+                            if (i < mlen) qzk_st64u(d + mlen - 8, qzk_ld64u(sp + mlen - 8));
+                        } else {
+                            uint32_t i = 0;
+                            if (mlen & 4) { ((qz_u32u *)d)->v = qz_ld32(sp); i = 4; }
+                            if (mlen & 2) { ((qz_u16u *)(d + i))->v = (uint16_t)qz_ld16(sp + i); i += 2; }
+                            if (mlen & 1) d[i] = sp[i];
+                        }
+                    } else {                                                /* a short period from before the batch, repeated */
+                        for (uint32_t i = 0, ph = 0; i < mlen; i++) { d[i] = sp[ph]; if (++ph == dist) ph = 0; }
+                    }
+                }
+                {
+                    uint64_t wide = qz_ballot(outside && mlen >= QZK_COOP_LEN);
+                    while (wide) {
+                        const int g = qz_ctz64(wide);
+                        wide &= wide - 1;
+                        const uint32_t M = qz_readlane(my_m, g), D = qz_readlane(dist, g), L = qz_readlane(mlen, g);
+                        const uint32_t stp = 64u % D;
+                        uint32_t r = (uint32_t)lane % D;
+                        const uint8_t *sp = o + ((int64_t)M - (int64_t)D);
+                        for (uint32_t i = (uint32_t)lane; i < L; i += 64) {
+                            ob[QZK_OBI(M + i)] = sp[r];
+                            r += stp; if (r >= D) r -= D;
+                        }
+                    }
+                }
+                qz_lds_sync();
+                /* matches that read from the batch itself: dependency order, bytes from LDS (from memory where a source
+                 * starts before the batch) */
+                const uint32_t src_end = my_m - dist + per;
+                uint64_t pending = qz_ballot(mlen != 0 && !outside);
+                while (pending) {
+                    const int f = qz_ctz64(pending);
+                    const uint32_t m_f = qz_readlane(my_m, f);
+                    const bool ready = ((pending >> lane) & 1) && (lane == f || src_end <= m_f);
+                    uint64_t wide = qz_ballot(ready && mlen >= QZK_COOP_LEN);
+                    if (ready && mlen < QZK_COOP_LEN) {
+                        if (sp0 >= (int64_t)obase) qzk_copy_match(ob + QZK_OBI(my_m), dist, mlen);    /* source and match in the buffer: 8 bytes a step */
+                        else for (uint32_t i = 0; i < mlen; i++) {                                   /* the source starts before the batch (rare) */
+                            const int64_t q = sp0 + (int64_t)i;
+                            uint8_t v;
+                            if (q >= (int64_t)obase) v = ob[QZK_OBI((uint32_t)q)]; else v = o[q];
+                            ob[QZK_OBI(my_m + i)] = v;
+                        }
+                    }
+                    while (wide) {
+                        const int g = qz_ctz64(wide);
+                        wide &= wide - 1;
+                        const uint32_t M = qz_readlane(my_m, g), D = qz_readlane(dist, g), L = qz_readlane(mlen, g);
+                        /* the source period [M - D, M) is final (below the first unfinished match, or this is it): byte i of
+                         * the match is byte i mod D of the period */
+                        const uint32_t stp = 64u % D;
+                        uint32_t r = (uint32_t)lane % D;
+                        const int64_t s0 = (int64_t)M - (int64_t)D;
+                        for (uint32_t i = (uint32_t)lane; i < L; i += 64) {
+                            const int64_t q = s0 + (int64_t)r;
+                            uint8_t v;
+                            if (q >= (int64_t)obase) v = ob[QZK_OBI((uint32_t)q)]; else v = o[q];
+                            ob[QZK_OBI(M + i)] = v;
+                            r += stp; if (r >= D) r -= D;
+                        }
+                    }
+                    pending &= ~qz_ballot(ready);
+                    qz_lds_sync();
+                }
+                /* out: whole 16-byte rows where the batch fills them, bytes at its two ends */
+                {
+                    uint8_t *const g0 = o + obase - sh;                     /* 16-byte aligned */
+                    const uint32_t rows = (sh + Tb + 15) >> 4;
+                    for (uint32_t rw = (uint32_t)lane; rw < rows; rw += 64) {
+                        const uint32_t lo = rw << 4;
+                        if (lo >= sh && lo + 16 <= sh + Tb) *(qzk_res_u32x4 *)(g0 + lo) = *(const qzk_res_u32x4 *)(ob + lo);
+                        else for (uint32_t t = 0; t < 16; t++) if (lo + t >= sh && lo + t < sh + Tb) g0[lo + t] = ob[lo + t];
+                    }
+                }
+                qz_lds_sync();                                              /* the next batch writes the buffer again */
+                obase += Tb; lbase += Lb;
+                continue;
+#undef QZK_OBI
+            }
             /* literal k of the batch belongs to the first sequence whose inclusive literal count exceeds k */
             for (uint32_t k0 = 0; k0 < Lb; k0 += 64) {
                 const uint32_t k = k0 + (uint32_t)lane;
