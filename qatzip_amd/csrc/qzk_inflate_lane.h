@@ -295,118 +295,55 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
     S->state = QZK_LS_SYM;
 }
 
-/* What phase A writes, per lane.  Vector memory operations of a wave complete in order, so a lane's store delays the
- * next input load of EVERY lane of its wave until the store has reached memory - and lanes that decode different data
- * fill their buffers at different moments: with sixteen segments per wave nearly every trip of the hot loop had one
- * (measured on data without duplicate chunks: 2.6 us per trip, five times what identical segments took).  So symbols are
- * only STAGED in registers, and the whole wave stores together at the end of a round of QZK_TOK_ROUND trips (a trip
- * appends at most QZK_LIT_RUN literals or one sequence): one queue of stores per round instead of one per lane and buffer. */
+/* What phase A writes, per lane: literal bytes and 8-byte sequence records, each straight to its place in memory in the
+ * trip that produced it - one dword store for the (at most QZK_LIT_RUN = 4) literals of a trip, whatever their number and
+ * alignment (the bytes above them are overwritten by the next trip; the literal area has the slack), one 8-byte store for
+ * a sequence.  Vector memory operations of a wave complete in order, so a store that is still on its way delays every
+ * later load - but the only load of the hot loop is the input word of the NEXT trip, asked for a whole trip ahead and
+ * issued before this trip's stores: by the time anything waits for it, the stores of the trip before are long done.
+ * (Rounds 1-2 staged eight trips' worth in registers - 26 of them, two chains of selects per trip - and stored in rounds,
+ * because their refill was a load on demand that queued behind every store; with the refill a trip ahead the staging only
+ * cost instructions: profiles/r3_inflate_direct_stores.txt.) */
 #define QZK_TOK_ROUND 8
 typedef struct {
     uint8_t *lp; qzk_seq *sq;
-    uint32_t lrun, nseq;                /* literals since the last sequence, sequences so far (staged ones included) */
-    uint32_t lw, ln;                    /* literal bytes in HBM, bytes staged in l0..l4 (< 8 after a round's flush, <= 39 within one) */
-    uint64_t l0, l1, l2, l3, l4;
-    uint32_t sk;                        /* sequences staged in s0..s7 */
-    uint64_t s0, s1, s2, s3, s4, s5, s6, s7;
+    uint32_t lrun, nseq;                /* literals since the last sequence, sequences so far */
+    uint32_t lw;                        /* literal bytes so far */
     bool count_only;
 } qzk_tok_out;
-#define QZK_NLIT(O_) ((O_).lw + (O_).ln)    /* literal bytes appended so far */
+#define QZK_NLIT(O_) ((O_).lw)              /* literal bytes appended so far */
 
 QZ_DEV void qzk_tok_init(qzk_tok_out *O, uint8_t *lp, qzk_seq *sq, bool count_only)
 {
     O->lp = lp; O->sq = sq; O->count_only = count_only;
-    O->lrun = 0; O->nseq = 0; O->lw = 0; O->ln = 0; O->sk = 0;
-    O->l0 = O->l1 = O->l2 = O->l3 = O->l4 = 0;
-    O->s0 = O->s1 = O->s2 = O->s3 = O->s4 = O->s5 = O->s6 = O->s7 = 0;
+    O->lrun = 0; O->nseq = 0; O->lw = 0;
 }
 /* append k (1..QZK_LIT_RUN) literals packed in v, lowest byte first, nothing above them */
 QZ_DEV void qzk_tok_lits(qzk_tok_out *O, uint64_t v, uint32_t k)
 {
-    if (!O->count_only) {
-        const uint32_t w = O->ln >> 3, sh = 8 * (O->ln & 7);
-        const uint64_t lo = v << sh, hi = sh ? v >> (64 - sh) : 0;       /* bytes that spill into the next word */
-        O->l0 |= w == 0 ? lo : 0;
-        O->l1 |= w == 1 ? lo : w == 0 ? hi : 0;
-        O->l2 |= w == 2 ? lo : w == 1 ? hi : 0;
-        O->l3 |= w == 3 ? lo : w == 2 ? hi : 0;
-        O->l4 |= w == 4 ? lo : w == 3 ? hi : 0;
-        O->ln += k;
-    }
+    if (!O->count_only) { ((qz_u32u *)(O->lp + O->lw))->v = (uint32_t)v; O->lw += k; }
     O->lrun += k;
 }
 QZ_DEV void qzk_tok_byte(qzk_tok_out *O, uint32_t byte) { qzk_tok_lits(O, byte, 1); }
-/* append the low k (1..8) bytes of v; the caller flushes after every call (ln < 8 on entry) */
+/* append the low k (1..8) bytes of v */
 QZ_DEV void qzk_tok_bytes(qzk_tok_out *O, uint64_t v, uint32_t k)
 {
-    if (!O->count_only) {
-        if (k < 8) v &= (1ull << (8 * k)) - 1;
-        const uint32_t sh = 8 * (O->ln & 7);
-        O->l0 |= v << sh;
-        O->l1 |= sh ? v >> (64 - sh) : 0;
-        O->ln += k;
-    }
+    if (!O->count_only) { qzk_st64u(O->lp + O->lw, v); O->lw += k; }
     O->lrun += k;
 }
-QZ_DEV void qzk_tok_round_flush(qzk_tok_out *O);
 QZ_DEV void qzk_tok_seq(qzk_tok_out *O, uint32_t mlen, uint32_t dm1)
 {
-    if (!O->count_only) {
-        if (O->sk == 8) qzk_tok_round_flush(O);       /* never a ninth staged sequence (callers flush in time; belt and braces) */
-        const uint64_t w = (uint64_t)O->lrun | (uint64_t)mlen << 32 | (uint64_t)dm1 << 48;
-        const uint32_t k = O->sk;
-        O->s0 = k == 0 ? w : O->s0; O->s1 = k == 1 ? w : O->s1; O->s2 = k == 2 ? w : O->s2; O->s3 = k == 3 ? w : O->s3;
-        O->s4 = k == 4 ? w : O->s4; O->s5 = k == 5 ? w : O->s5; O->s6 = k == 6 ? w : O->s6; O->s7 = k == 7 ? w : O->s7;
-        O->sk = k + 1;
-    }
+    if (!O->count_only) ((uint64_t *)O->sq)[O->nseq] = (uint64_t)O->lrun | (uint64_t)mlen << 32 | (uint64_t)dm1 << 48;
     O->nseq++; O->lrun = 0;
 }
-/* end of a round: the whole words of the staged literals and all staged sequences leave, every lane at the same point
- * of the instruction stream */
-QZ_DEV void qzk_tok_round_flush(qzk_tok_out *O)
-{
-    if (O->count_only) return;
-    const uint32_t nw = O->ln >> 3;              /* 0..4 whole words */
-    uint8_t *d = O->lp + O->lw;
-    if (nw >= 1) qzk_st64u(d, O->l0);
-    if (nw >= 2) qzk_st64u(d + 8, O->l1);
-    if (nw >= 3) qzk_st64u(d + 16, O->l2);
-    if (nw >= 4) qzk_st64u(d + 24, O->l3);
-    const uint64_t a0 = O->l0, a1 = O->l1, a2 = O->l2, a3 = O->l3, a4 = O->l4;
-    O->l0 = nw == 0 ? a0 : nw == 1 ? a1 : nw == 2 ? a2 : nw == 3 ? a3 : a4;
-    O->l1 = nw == 0 ? a1 : nw == 1 ? a2 : nw == 2 ? a3 : nw == 3 ? a4 : 0;
-    O->l2 = nw == 0 ? a2 : nw == 1 ? a3 : nw == 2 ? a4 : 0;
-    O->l3 = nw == 0 ? a3 : nw == 1 ? a4 : 0;
-    O->l4 = nw == 0 ? a4 : 0;
-    O->lw += 8 * nw; O->ln &= 7;
-    const uint32_t k = O->sk;
-    uint64_t *q = (uint64_t *)(O->sq + (O->nseq - k));
-    if (k > 0) q[0] = O->s0;
-    if (k > 1) q[1] = O->s1;
-    if (k > 2) q[2] = O->s2;
-    if (k > 3) q[3] = O->s3;
-    if (k > 4) q[4] = O->s4;
-    if (k > 5) q[5] = O->s5;
-    if (k > 6) q[6] = O->s6;
-    if (k > 7) q[7] = O->s7;
-    O->sk = 0;
-}
-/* make everything appended so far visible in memory and leave the stream ready for more (used between the rounds
- * of the speculative phase A, and at the end); after it the literal position is no longer 8-byte aligned, which only
- * costs speed */
-QZ_DEV void qzk_tok_flush(qzk_tok_out *O)
-{
-    if (O->count_only) return;
-    qzk_tok_round_flush(O);
-    for (uint32_t i = 0; i < O->ln; i++) O->lp[O->lw + i] = (uint8_t)(O->l0 >> (8 * i));
-    O->lw += O->ln; O->ln = 0; O->l0 = 0;
-}
+/* everything is in memory as soon as it is appended: the round / flush points of the callers are kept as names */
+QZ_DEV void qzk_tok_round_flush(qzk_tok_out *O) { (void)O; }
+QZ_DEV void qzk_tok_flush(qzk_tok_out *O) { (void)O; }
 
 QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
 {
     if (O->count_only) return;
     if (O->lrun) qzk_tok_seq(O, 0u, 0u);
-    qzk_tok_flush(O);
 }
 
 /* one symbol from an already refilled bit buffer; structured (no early exits) so that it compiles to predicated
