@@ -184,17 +184,21 @@ QZ_DEV void qzk_longtab_load_t(uint32_t *LR, const uint16_t *first_, const uint1
         if (k & 1) LR[N + (k >> 1)] |= d << 16; else LR[N + (k >> 1)] = d;
     }
 }
-template <int ROOT>
+/* CHECKBC: the reader may hold fewer valid bits than the code is long (the careful reader at the end of the input; the hot
+ * loop's trips start with >= 56).  Lengths above the block's longest code have an empty interval (qzk_longtab_load_t), so
+ * they need no test of their own. */
+template <int ROOT, bool CHECKBC = true>
 QZ_DEV int qzk_ldecode_long_reg_t(qzk_lbits *b, const uint32_t *LR, const uint16_t *sorted, int maxlen)
 {
     constexpr int N = 15 - ROOT;
+    (void)maxlen;
     const uint32_t V = qzk_rev((uint32_t)b->bb & 0x7fffu, 15);
     uint32_t sel_l = 0, sel_i = 0;
     for (int k = N - 1; k >= 0; k--) {                          /* longest first: the shortest hit is kept */
         const int l = ROOT + 1 + k;
         const uint32_t first = LR[k] & 0x7fffu, limit = LR[k] >> 15, c = V >> (15 - l);
         const uint32_t d = (LR[N + (k >> 1)] >> (16 * (k & 1))) & 0xffffu;
-        if (l <= maxlen && l <= b->bc && c >= first && c < limit) { sel_l = (uint32_t)l; sel_i = (c + d) & 0xffffu; }
+        if ((!CHECKBC || l <= b->bc) && c >= first && c < limit) { sel_l = (uint32_t)l; sel_i = (c + d) & 0xffffu; }
     }
     int sym = -1;
     if (sel_l) { QZK_DROP(b, sel_l); sym = sorted[sel_i]; }
@@ -355,9 +359,9 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
     qzk_lbits *b = &S->b;
     const uint32_t e = lroot[(uint32_t)b->bb & ((1u << QZK_LLROOT) - 1)];
     int sym;
-    if (e != 0 && (int)(e & 15) <= b->bc) { QZK_DROP(b, e & 15); sym = (int)(e >> 4); }
+    if (e != 0 && (!MIDREFILL || (int)(e & 15) <= b->bc)) { QZK_DROP(b, e & 15); sym = (int)(e >> 4); }     /* a trip of the hot loop starts with >= 56 bits */
     else if (e) sym = -1;
-    else if (LR) sym = qzk_ldecode_long_reg_t<QZK_LLROOT>(b, LR, T->lsorted, S->lmax);
+    else if (LR) sym = qzk_ldecode_long_reg_t<QZK_LLROOT, MIDREFILL>(b, LR, T->lsorted, S->lmax);
     else sym = qzk_ldecode_long(b, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, S->lmax);
     uint64_t lv = 0; uint32_t lk = 0;       /* literals of this trip (packed), their number */
     bool run = false;                       /* the trip may go on with literals out of the root table */
@@ -378,7 +382,7 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
         int ds;
         if (de != 0 && (int)(de & 15) <= b->bc) { QZK_DROP(b, de & 15); ds = (int)(de >> 4); }
         else if (de) ds = -1;
-        else if (DR) ds = qzk_ldecode_long_reg_t<QZK_LDROOT>(b, DR, T->dsorted, S->dmax);
+        else if (DR) ds = qzk_ldecode_long_reg_t<QZK_LDROOT, MIDREFILL>(b, DR, T->dsorted, S->dmax);
         else ds = qzk_ldecode_long(b, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, S->dmax);
         if (!err && (ds < 0 || ds >= 30)) err = b->pos >= b->end && b->bc < 15 ? QZK_INF_EIN : QZK_INF_EDATA;
         if (ds < 0 || ds >= 30) ds = 0;
