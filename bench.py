@@ -524,7 +524,7 @@ def main():
                     box["one"] = {"error": str(e)[:200]}
             th = threading.Thread(target=leg, daemon=True)
             th.start()
-            th.join(float(os.environ.get("QATZIP_AMD_BENCH_LEG_TIMEOUT", "240")))
+            th.join(float(os.environ.get("QATZIP_AMD_BENCH_LEG_TIMEOUT", "150")))
             if th.is_alive():
                 one = {"error": "the one-member leg did not finish in time on rank %d (a transport is waiting for a rank that is not coming)" % rank}
                 hard_exit = True
