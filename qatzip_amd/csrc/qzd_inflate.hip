@@ -31,10 +31,11 @@
 #include "qzk_inflate_spec.h"
 #include "qzk_checksum.h"
 
-/* the two-phase path needs ~24 + 12 ms whatever the segment count (phase A is bound by a lone wave's instruction
- * latency), the wave kernel ~12-17 ms per round of up to 6144 resident segments (bound by the CUs' scalar units): the
- * two phases win from ~10 500 segments on (measured: 640 MiB 31.9 ms against 32.6) */
-#define QZD_LANE_MIN_SEGS 10500u
+/* the two-phase path needs ~21 + 1-2 ms whatever the segment count up to one round of lanes (phase A is one lane's chain
+ * through its segment), the wave kernel ~12-17 ms per round of up to 6144 resident segments (bound by the CUs' scalar
+ * units): the two phases win from ~6200 segments on (round 3, 64 KB segments: 384 MiB 22.9 ms both ways, 512 MiB 22.8
+ * against 27.3; round 2's phases, 26 + 12 ms, crossed at 10 500) */
+#define QZD_LANE_MIN_SEGS 6200u
 #define QZD_LANE_SEGS_PER_WAVE 16u
 /* sub-decoders per segment of phase A.  1 = the serial phase A.  The speculative one (2, 4, 8; QATZIP_AMD_INFLATE_K)
  * decodes compressible segments K times faster, but blocks of near-equal code lengths (incompressible data that still
