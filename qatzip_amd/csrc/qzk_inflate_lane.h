@@ -452,7 +452,7 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
             /* ---- the hot loop.  Branch-free refill: the 8 bytes at the read position are always already in flight
              * (pw), each trip ORs them in above the valid bits, steps over the bytes that fitted and issues the load
              * for the next trip, whose latency the symbol decode then covers; >= 56 valid bits per trip is a whole
-             * symbol (15 + 5 + 15 + 13).  Rounds of QZK_TOK_ROUND trips, the stores of a round at its end; bounded so
+             * symbol (15 + 5 + 15 + 13).  Rounds of QZK_TOK_ROUND trips (the inner loop's bound, kept from the staging days); bounded so
              * that lanes parked in a cold state get their turn. ---- */
             b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;     /* hand whole bytes back */
             uint64_t pw = qzk_ld64u(b->p + b->pos);
@@ -491,10 +491,8 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
                 /* a stored block never enters the literal stream: phase B copies it straight from the input.  The
                  * sequences so far become a piece of their own (their pending literals end it) */
                 if (O.lrun) qzk_tok_seq(&O, 0u, 0u);
-                /* that sequence leaves now: the staging registers hold eight, a round of the hot loop may add eight, and
-                 * one left over from here would make nine (the ninth was dropped and the round's flush then wrote the
-                 * other eight one slot too low: wrong bytes with status 0 behind literals + stored block + eight matches) */
-                qzk_tok_round_flush(&O);
+                /* (round 2 staged sequences in registers and lost one here - literals + stored block + eight matches;
+                 * tests/test_sim_kernels.py keeps the case.  Since round 3 a sequence is in memory when it is appended.) */
                 if (O.nseq > piece_seq0) {
                     qzk_chain_el e; e.sub = 0; e.seq_first = piece_seq0; e.seq_count = O.nseq - piece_seq0; e.lit_first = piece_lit0; e.lrun_skip = 0;
                     C->el[nel++] = e;
