@@ -36,6 +36,10 @@
  * units): the two phases win from ~6200 segments on (round 3, 64 KB segments: 384 MiB 22.9 ms both ways, 512 MiB 22.8
  * against 27.3; round 2's phases, 26 + 12 ms, crossed at 10 500) */
 #define QZD_LANE_MIN_SEGS 6200u
+/* segments above 64 KB: a lane's chain grows with its segment, a wave's time by less - 8192 segments of 128 KB take
+ * 54 ms with a wave each and 66 ms in two phases; round 2's crossover stays for them */
+#define QZD_LANE_MIN_SEGS_BIG 10500u
+#define QZD_LANE_MIN(seg_bytes) ((seg_bytes) <= 65536u + 64u ? QZD_LANE_MIN_SEGS : QZD_LANE_MIN_SEGS_BIG)
 #define QZD_LANE_SEGS_PER_WAVE 16u
 /* sub-decoders per segment of phase A.  1 = the serial phase A.  The speculative one (2, 4, 8; QATZIP_AMD_INFLATE_K)
  * decodes compressible segments K times faster, but blocks of near-equal code lengths (incompressible data that still
@@ -281,7 +285,7 @@ extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *
     /* few segments: one wave each; thousands: the two-phase path (the wave-per-segment kernel is bound by the CU's
      * scalar unit, the lane kernels spread the serial work over the vector lanes) */
     const char *force = getenv("QATZIP_AMD_INFLATE");
-    const bool lanes = force ? force[0] == 'l' : nsegs >= QZD_LANE_MIN_SEGS;
+    const bool lanes = force ? force[0] == 'l' : nsegs >= QZD_LANE_MIN(hs[0].out_cap);
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
     if (lanes) {
         /* speculative sub-segment decoding needs a length hint (qzd_infseg.pad) and segments that write output */
@@ -514,7 +518,7 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
      * boundary (00 00 FF FF inside compressed data or a stored block) simply drops out - gives each real segment its
      * output offset, and phase B writes only those.  One pass whatever the candidates look like. --- */
     const char *force_path = getenv("QATZIP_AMD_INFLATE");
-    const bool lanes = force_path ? force_path[0] == 'l' : ns >= QZD_LANE_MIN_SEGS;
+    const bool lanes = force_path ? force_path[0] == 'l' : ns >= QZD_LANE_MIN(seg_hint ? seg_hint : 65536u);
     {
         if (scan_ok && seg_hint && ns > 1 && lanes) {
             auto clen = [&](uint32_t k) { return (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k]; };
