@@ -699,10 +699,16 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         uint8_t *const slots_b = fuse ? pool->slots[0] + (size_t)b * stride : pool->slots[s];
         qzk_lzmeta *const meta_b = fuse ? pool->meta[0] + b : pool->meta[s];
         const int sb = fuse ? 0 : s;
-        hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64 * wpw), 0, st, d_src + boff, blen, chunk_sz, bn,
-                           pool->sym_lc[sb], pool->sym_dist[sb], meta_b, pool->tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
-                           pool->epoch, fuse ? slots_b : (uint8_t *)NULL, stride, final_chunk, c->d_len + b,
-                           fuse ? c->d_crc + b : (uint32_t *)NULL, stream_in ? (const uint32_t *)c->h_wm : (const uint32_t *)NULL, outp);
+        if (stream_in || out_in_launch)
+            hipLaunchKernelGGL(qzk_lz77_pull_fed_kernel, dim3(wgs), dim3(64 * wpw), 0, st, d_src + boff, blen, chunk_sz, bn,
+                               pool->sym_lc[sb], pool->sym_dist[sb], meta_b, pool->tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
+                               pool->epoch, fuse ? slots_b : (uint8_t *)NULL, stride, final_chunk, c->d_len + b,
+                               fuse ? c->d_crc + b : (uint32_t *)NULL, stream_in ? (const uint32_t *)c->h_wm : (const uint32_t *)NULL, outp);
+        else
+            hipLaunchKernelGGL(qzk_lz77_pull_kernel, dim3(wgs), dim3(64 * wpw), 0, st, d_src + boff, blen, chunk_sz, bn,
+                               pool->sym_lc[sb], pool->sym_dist[sb], meta_b, pool->tables, c->k1_counter + s, cdesc ? cdesc + b : NULL,
+                               pool->epoch, fuse ? slots_b : (uint8_t *)NULL, stride, final_chunk, c->d_len + b,
+                               fuse ? c->d_crc + b : (uint32_t *)NULL, (const uint32_t *)NULL, outp);
         pool->epoch += bn;
         HIPCHK(c, hipEventRecord(c->k1done[s], st));
         if (k < QZD_K1EV) { HIPCHK(c, hipEventRecord(c->k1ev[k][1], st)); c->k1ev_chunks[k] = bn; c->k1ev_n = k + 1; }

@@ -744,7 +744,11 @@ QZ_DEV void qzk_out_drain(const qzk_outp O, const uint8_t *slots, uint32_t slot_
 #endif
 
 #define QZK_K1_LDSW (QZK_K1_PARSEW > (sizeof(qzk_huff_lds) + 3) / 4 ? QZK_K1_PARSEW : (sizeof(qzk_huff_lds) + 3) / 4)
-QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
+/* FED: the launch may start before its input is there (avail) and may move the coded chunks to the destination itself
+ * (O.dst) - the form calls fed from host memory take; the resident form is compiled without either, so that what it
+ * never uses costs it no registers */
+template <bool FED>
+QZ_DEV void qzk_lz77_pull_body(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks,
                                                      uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tables,
                                                      uint32_t *counter, const uint32_t *cdesc, uint32_t epoch_base,
                                                      uint8_t *slots, uint32_t slot_stride, uint32_t final_chunk, uint32_t *out_len,
@@ -766,7 +770,7 @@ QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_p
         uint32_t chunk = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);
         chunk = qz_readfirstlane(chunk);
         if (chunk >= nchunks) break;
-        if (avail) {                                   /* kernel argument, wave-uniform values */
+        if (FED && avail) {                            /* kernel argument, wave-uniform values */
             const uint32_t ahead = 1u + 1024u / chunk_sz;                   /* whole chunks the ring's read-ahead may touch */
             if (!qzk_wait_input(avail, chunk + 1 + ahead < nchunks ? chunk + 1 + ahead : nchunks, chunk_sz)) break;
         }
@@ -794,7 +798,7 @@ QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_p
 #endif
             qz_lds_sync();
 #ifndef QZ_SIM
-            if (O.dst) {                            /* kernel argument */
+            if (FED && O.dst) {                     /* kernel argument */
                 const uint32_t n1 = qz_readfirstlane(__hip_atomic_load(out_len + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1;
                 __hip_atomic_store(O.pub + chunk, n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* every lane, the same word */
                 pend[pt % QZK_OUT_PEND] = chunk;
@@ -806,8 +810,15 @@ QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_p
         }
     }
 #ifndef QZ_SIM
-    if (O.dst && slots) qzk_out_drain(O, slots, slot_stride, pend, &ph, pt, nchunks, true, qz_lane());
+    if (FED && O.dst && slots) qzk_out_drain(O, slots, slot_stride, pend, &ph, pt, nchunks, true, qz_lane());
 #endif
 }
+#define QZK_PULL_PARAMS const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t nchunks, uint8_t *sym_lc, uint16_t *sym_dist, \
+    qzk_lzmeta *meta, qzk_bkt *tables, uint32_t *counter, const uint32_t *cdesc, uint32_t epoch_base, uint8_t *slots, \
+    uint32_t slot_stride, uint32_t final_chunk, uint32_t *out_len, uint32_t *crc_out, const uint32_t *avail, const qzk_outp O
+#define QZK_PULL_ARGS src, src_len, chunk_sz, nchunks, sym_lc, sym_dist, meta, tables, counter, cdesc, epoch_base, slots, slot_stride, \
+    final_chunk, out_len, crc_out, avail, O
+QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_pull_kernel(QZK_PULL_PARAMS) { qzk_lz77_pull_body<false>(QZK_PULL_ARGS); }
+QZ_KERNEL_OCC(64 * QZK_K1_WAVES, (QZK_K1_OCC * QZK_K1_WAVES + 3) / 4) qzk_lz77_pull_fed_kernel(QZK_PULL_PARAMS) { qzk_lz77_pull_body<true>(QZK_PULL_ARGS); }
 
 #endif
