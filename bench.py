@@ -15,10 +15,14 @@ to rank 0's HBM - as peer-to-peer copies into an IPC window and as an RCCL send/
 `config.one_stream` reports them.  `python bench.py --gpus N` launches its own N ranks when no launcher set WORLD_SIZE.
 
 Beside the headline the line carries (rank 0, N = 1 only, all outside the timed region):
-  config.api_*          the same work through qatzip.h itself: qzCompress / qzDecompress on qzMalloc(PINNED_MEM) buffers
+  config.api_*          the same work through qatzip.h itself: ONE qzCompress / qzDecompress call of --api-mb (2047) MiB on
+                        qzMalloc(PINNED_MEM) buffers, PCIe both ways included, and its ratio to min(link, kernel rate)
+  config.pcie_*         plain pinned hipMemcpyAsync, 1 GiB each way, on this box
+  config.concurrent_sessions   the buffer as 2 GiB calls of two sessions started together (the harness' -t)
   config.raw_sweep      BASELINE config 3: QZ_DEFLATE_RAW, hw_buff_sz 16 / 64 / 128 KB
   config.lz4            BASELINE config 4: LZ4 frames of 64 KB with XXH32
   roofline              the dominant kernel against the HBM peak (datasheet) and the copy rate measured on this box
+  roofline_decode       the two inflate kernels of a call, the same way
   cpu_baseline          the software path's port on every physical core of this host, and this host's own libz
 
 Prints ONE JSON line on rank 0.
