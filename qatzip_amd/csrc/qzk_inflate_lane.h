@@ -144,7 +144,9 @@ typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chai
 #define QZK_TOK_SEQCAP(out_cap) ((uint64_t)(out_cap) / 3 + 2)
 
 enum { QZK_LS_HDR = 0, QZK_LS_SYM, QZK_LS_RAW, QZK_LS_DONE };
+#ifndef QZK_LIT_RUN
 #define QZK_LIT_RUN 4              /* literals one trip of the serial phase A may take (six, with the staging widened to match, measured 1.5 % slower) */
+#endif
 
 /* slow half of a symbol decode: the root entry was empty (code longer than the root) */
 QZ_DEV int qzk_ldecode_long(qzk_lbits *b, int rootbits, const uint16_t *sorted, const uint16_t *count,
@@ -325,7 +327,10 @@ QZ_DEV void qzk_tok_init(qzk_tok_out *O, uint8_t *lp, qzk_seq *sq, bool count_on
 /* append k (1..QZK_LIT_RUN) literals packed in v, lowest byte first, nothing above them */
 QZ_DEV void qzk_tok_lits(qzk_tok_out *O, uint64_t v, uint32_t k)
 {
-    if (!O->count_only) { ((qz_u32u *)(O->lp + O->lw))->v = (uint32_t)v; O->lw += k; }
+    if (!O->count_only) {
+        if (QZK_LIT_RUN > 4) qzk_st64u(O->lp + O->lw, v); else ((qz_u32u *)(O->lp + O->lw))->v = (uint32_t)v;
+        O->lw += k;
+    }
     O->lrun += k;
 }
 QZ_DEV void qzk_tok_byte(qzk_tok_out *O, uint32_t byte) { qzk_tok_lits(O, byte, 1); }
