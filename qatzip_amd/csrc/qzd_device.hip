@@ -634,6 +634,12 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
      * and the parse runs beside the whole copy instead of beside all but the first batch of it. */
     const bool stream_in = h_src && fuse && !cdesc && n >= (64ull << 20) && c->h_wm && !getenv("QATZIP_AMD_HOST_BATCHED");
     if (stream_in) { BATCH = nchunks; first_env = 0; c->h_wm[0] = 0; c->h_wm[1] = 0; }
+    /* a launch that waits for its input must hear from the host on every way out of this function: whatever returns
+     * early (a HIP error between the launch and the copy) leaves the watermark at "giving up" */
+    struct FedGuard {
+        uint32_t *wm; bool armed;
+        ~FedGuard() { if (armed && wm) __atomic_store_n(&wm[0], 0xffffffffu, __ATOMIC_RELEASE); }
+    } fed_guard = { c->h_wm, stream_in };
     /* one launch for the whole call: its waves also move the stream to d_dst (qzk_outp) - no scan, no gather behind it */
     const char *oute = getenv("QATZIP_AMD_K1_OUT");
     /* (measured, profiles/r3_api_stream.txt: with the destination across PCIe the stream then travels while the parse runs,
@@ -775,6 +781,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         landed(n);
         (void)done_to;
     }
+    fed_guard.armed = false;
     return QZD_OK;
 }
 
