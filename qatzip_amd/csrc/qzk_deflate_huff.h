@@ -70,16 +70,31 @@ QZ_DEV uint32_t qzk_bitrev(uint32_t code, int len)         /* len 1..15 */
 
 QZ_DEV void qzk_pqdown(uint32_t *heap, int heap_len, int k)
 {
-    /* one LDS round trip per level: both children come in one access (j is even, the slot after the heap's end exists
-     * and is never chosen) and the smaller one is picked in registers */
+    /* one LDS round trip per TWO levels: the children of k (heap[2k], heap[2k+1]: j is even, the slot after the heap's end
+     * exists and is never chosen) and its four grandchildren (heap[4k .. 4k+3]) are asked for together, the smaller child
+     * and then the smaller of ITS children are picked in registers - the same comparisons in the same order as zlib's
+     * pqdownheap, a level at a time; only the loads are early.  (This loop is a chain of dependent LDS reads on one lane:
+     * the serial tree build was a tenth of the fused kernel's time per chunk.) */
     const uint32_t v = heap[k];
     int j = k << 1;
     while (j <= heap_len) {
         const uint32_t c0 = heap[j], c1 = heap[j + 1];
-        uint32_t c = c0;
-        if (j < heap_len && QZK_SMALLER(c1, c0)) { j++; c = c1; }
+        uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+        const bool deep = 2 * j <= heap_len;                       /* a second level exists below either child */
+        if (deep) { g0 = heap[2 * j]; g1 = heap[2 * j + 1]; g2 = heap[2 * j + 2]; g3 = heap[2 * j + 3]; }
+        uint32_t c = c0; bool right = false;
+        if (j < heap_len && QZK_SMALLER(c1, c0)) { j++; c = c1; right = true; }
         if (QZK_SMALLER(v, c)) break;
         heap[k] = c; k = j; j <<= 1;
+        if (j > heap_len) break;
+        {   /* second level, from the words already here (heap[j], heap[j + 1] with the new j; entries above heap_len are
+             * never chosen, exactly as above) */
+            const uint32_t d0 = right ? g2 : g0, d1 = right ? g3 : g1;
+            uint32_t d = d0;
+            if (j < heap_len && QZK_SMALLER(d1, d0)) { j++; d = d1; }
+            if (QZK_SMALLER(v, d)) break;
+            heap[k] = d; k = j; j <<= 1;
+        }
     }
     heap[k] = v;
 }
