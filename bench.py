@@ -357,6 +357,9 @@ def one_stream_leg(ctx, qz, pg, rank, world, d_src, shard_mb, steps):
     CPU CRC-32s and a prefix of its payload against the oracle (outside the timed loop)."""
     import zlib
     from qatzip_amd import shard
+    # the ranks of this leg share one node by contract: RCCL's bootstrap sockets may use the loopback interface (the
+    # container's hostname need not resolve); a launcher that knows better sets the variable itself
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     n = shard_mb << 20
     src = view(qz, d_src, 0, n)
     host = d_src.download(n) if n <= (1 << 30) else None
