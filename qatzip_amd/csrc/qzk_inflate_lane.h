@@ -36,9 +36,22 @@
 #ifndef QZK_LDROOT
 #define QZK_LDROOT 7
 #endif
-/* the code-length code of a dynamic block (<= 7 bits) borrows the distance root: no wider than that table is */
-#define QZK_CLROOT (QZK_LDROOT < 7 ? QZK_LDROOT : 7)
-#define QZK_LANE_ROOTSZ ((1 << QZK_LLROOT) + (1 << QZK_LDROOT))
+/* Per lane, in LDS (QZK_LANE_ROOTSZ u16 = 1.25 KiB; the LDS is what bounds the lanes a CU holds, so every byte counts):
+ *   [0, 1024)     literal/length root, 2^9 x u16: sym << 4 | code length, 0 = the code is longer than the root
+ *   [1024, 1280)  the "side" region, 256 bytes:
+ *       distance root, 2^QZK_LDROOT x u8: sym << 3 | code length (a distance symbol is < 30 and a root code <= 7 bits), then
+ *       the LONG-LITERAL POOL, QZK_LPOOL_N x u8: the literal/length symbols whose codes are longer than the root, in
+ *       canonical order (shortest codes = likeliest symbols first), as many as fit; 0xff = "not a literal below 255 -
+ *       ask the segment's sorted list in memory".  On mixed data (text next to bytes of every value) a block has ~220
+ *       such symbols carrying up to a fifth of its symbols (tools/inflate_longcodes.py), and fetching each of them
+ *       from memory stood on every lane's critical path.
+ * While a dynamic block's header is read, the side region holds the code-length code's root (2^7 x u16). */
+#define QZK_CLROOT 7
+#define QZK_SIDE_BYTES 256
+#define QZK_LPOOL_N (QZK_SIDE_BYTES - (1 << QZK_LDROOT))
+#define QZK_LANE_ROOTSZ ((1 << QZK_LLROOT) + QZK_SIDE_BYTES / 2)
+#define QZK_DROOT8(droot) ((uint8_t *)(droot))
+#define QZK_LPOOL(droot) ((uint8_t *)(droot) + (1 << QZK_LDROOT))
 
 typedef struct {
     uint16_t lsorted[288], dsorted[32];
@@ -48,8 +61,10 @@ typedef struct {
 } qzk_inf_tab;
 
 /* serial (per-lane) canonical table build; returns 0 ok, 1 incomplete, -1 over-subscribed */
+/* FMT8: the root is the distance root (u8 entries, sym << 3 | len); pool: where the long literal/length symbols go */
+template <bool FMT8 = false>
 QZ_DEV int qzk_lane_build(const uint8_t *lens, int n, uint16_t *root, int rootbits, uint16_t *sorted,
-                          uint16_t *count, uint16_t *first, uint16_t *index, int *maxlen_out)
+                          uint16_t *count, uint16_t *first, uint16_t *index, int *maxlen_out, uint8_t *pool = 0)
 {
     for (int l = 0; l < 16; l++) count[l] = 0;
     for (int i = 0; i < n; i++) count[lens[i]]++;
@@ -63,7 +78,10 @@ QZ_DEV int qzk_lane_build(const uint8_t *lens, int n, uint16_t *root, int rootbi
         first[l] = (uint16_t)code; index[l] = (uint16_t)off;
         code = (code + c) << 1; off += c;
     }
-    for (int i = 0; i < (1 << rootbits); i += 2) *(uint32_t *)(root + i) = 0;
+    if (FMT8) { for (int i = 0; i < (1 << rootbits); i += 4) *(uint32_t *)((uint8_t *)root + i) = 0; }
+    else for (int i = 0; i < (1 << rootbits); i += 2) *(uint32_t *)(root + i) = 0;
+    if (pool) for (int i = 0; i < QZK_LPOOL_N; i += 4) *(uint32_t *)(pool + i) = 0xffffffffu;
+    const uint32_t long_base = rootbits < 15 ? index[rootbits + 1] : off;    /* symbols with root codes come first in the sorted list */
     uint16_t next[16];
     for (int l = 1; l <= 15; l++) next[l] = 0;
     for (int i = 0; i < n; i++) {
@@ -73,7 +91,11 @@ QZ_DEV int qzk_lane_build(const uint8_t *lens, int n, uint16_t *root, int rootbi
         sorted[index[l] + rank] = (uint16_t)i;
         if (l <= rootbits) {
             const uint32_t r = qzk_rev(first[l] + rank, l);
-            for (uint32_t f = r; f < (1u << rootbits); f += 1u << l) root[f] = (uint16_t)((i << 4) | l);
+            if (FMT8) { for (uint32_t f = r; f < (1u << rootbits); f += 1u << l) ((uint8_t *)root)[f] = (uint8_t)((i << 3) | l); }
+            else for (uint32_t f = r; f < (1u << rootbits); f += 1u << l) root[f] = (uint16_t)((i << 4) | l);
+        } else if (pool) {
+            const uint32_t pr = index[l] + rank - long_base;
+            if (pr < (uint32_t)QZK_LPOOL_N && i < 255) pool[pr] = (uint8_t)i;
         }
     }
     *maxlen_out = maxlen;
@@ -216,6 +238,7 @@ QZ_DEV void qzk_longtab_load(uint32_t *LR, uint32_t *DR, const qzk_inf_tab *T, i
 typedef struct {
     qzk_lbits b;
     uint32_t op, nblocks, last, clen, rpos, out_cap;
+    uint32_t lbase;                     /* literal/length symbols with root codes = where the long ones begin in the sorted list */
     int lmax, dmax, status, state;
     bool through;
 } qzk_lane_st;
@@ -253,9 +276,10 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
     if (type == 3) return;
     if (type == 1) {
         for (int i = 0; i < 288; i++) T->lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-        qzk_lane_build(T->lens, 288, lroot, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &S->lmax);
+        qzk_lane_build(T->lens, 288, lroot, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &S->lmax, QZK_LPOOL(droot));
         for (int i = 0; i < 30; i++) T->lens[i] = 5;
-        qzk_lane_build(T->lens, 30, droot, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &S->dmax);
+        qzk_lane_build<true>(T->lens, 30, droot, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &S->dmax);
+        S->lbase = T->lindex[QZK_LLROOT + 1];
         S->state = QZK_LS_SYM;
         return;
     }
@@ -294,10 +318,12 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
         prev = val; i += rep;
     }
     if (L[256] == 0) return;
-    int r = qzk_lane_build(L, (int)nlen, lroot, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &S->lmax);
+    /* (the code-length code's root stood in the side region: both builds below clear their part of it) */
+    int r = qzk_lane_build(L, (int)nlen, lroot, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &S->lmax, QZK_LPOOL(droot));
     if (r < 0 || (r > 0 && S->lmax != 1)) return;
-    r = qzk_lane_build(L + nlen, (int)ndist, droot, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &S->dmax);
+    r = qzk_lane_build<true>(L + nlen, (int)ndist, droot, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &S->dmax);
     if (r < 0 || (r > 0 && S->dmax > 1)) return;
+    S->lbase = T->lindex[QZK_LLROOT + 1];
     S->state = QZK_LS_SYM;
 }
 
@@ -311,6 +337,9 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
  * because their refill was a load on demand that queued behind every store; with the refill a trip ahead the staging only
  * cost instructions: profiles/r3_inflate_direct_stores.txt.) */
 #define QZK_TOK_ROUND 8
+#ifndef QZK_TOK_TRIPS
+#define QZK_TOK_TRIPS 256           /* trips of the hot loop before the wave looks at its parked lanes again */
+#endif
 typedef struct {
     uint8_t *lp; qzk_seq *sq;
     uint32_t lrun, nseq;                /* literals since the last sequence, sequences so far */
@@ -383,9 +412,9 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
         int err = sym >= 29 ? QZK_INF_EDATA : (int)xb > b->bc ? QZK_INF_EIN : 0;
         len += QZK_GETBITS(b, xb); QZK_DROP(b, xb);
         if (MIDREFILL) qzk_lrefill(b);
-        const uint32_t de = droot[(uint32_t)b->bb & ((1u << QZK_LDROOT) - 1)];
+        const uint32_t de = QZK_DROOT8(droot)[(uint32_t)b->bb & ((1u << QZK_LDROOT) - 1)];
         int ds;
-        if (de != 0 && (int)(de & 15) <= b->bc) { QZK_DROP(b, de & 15); ds = (int)(de >> 4); }
+        if (de != 0 && (int)(de & 7) <= b->bc) { QZK_DROP(b, de & 7); ds = (int)(de >> 3); }
         else if (de) ds = -1;
         else if (DR) ds = qzk_ldecode_long_reg_t<QZK_LDROOT, MIDREFILL>(b, DR, T->dsorted, S->dmax);
         else ds = qzk_ldecode_long(b, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, S->dmax);
@@ -418,6 +447,140 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
     if (lk) { qzk_tok_lits(O, lv, lk); S->op += lk; }
 }
 
+
+/* ------------------------------------------------------------------ the serial phase A's trip (round 4)
+ * A lane's segment is ONE dependent chain - bits -> root lookup -> code length -> shift -> next lookup - and the phase
+ * ends when the longest chain does, so a trip is written for that chain and nothing else:
+ *   - the trip's stores are UNCONDITIONAL and come last: one literal store (however many literals, zero included: the
+ *     bytes above them are overwritten by the next trip) and one sequence store (a trip without a sequence writes the
+ *     slot the next sequence will overwrite).  A constant number of memory operations behind the next trip's input load
+ *     lets the compiler wait for that load alone (s_waitcnt vmcnt(2)); with stores under branches it had to wait for
+ *     vmcnt(0), i.e. for this trip's stores to reach the L2, at the top of every trip;
+ *   - codes longer than the root are settled without memory where it matters: the six intervals of the lengths 10..15
+ *     in registers give the length and the canonical index, and a long LITERAL is one more LDS read (the pool); the
+ *     distance code's long half is registers only (intervals + the <= 30 symbols packed five bits each);
+ *   - selects instead of branches on the common path; what is rare (a long code, the end of a block, an error) sits in
+ *     blocks the wave skips when no lane needs them.
+ * Same tokens as qzk_lane_symbol<false, true> (the careful reader and the speculative decoders keep using that one). */
+#ifdef QZ_SIM
+#define QZK_PIN(x) ((void)0)
+#else
+#define QZK_PIN(x) asm volatile("" : "+v"(x))       /* the value is needed HERE: a pending load is waited for at this point */
+#endif
+typedef struct { uint64_t w0, w1, w2; } qzk_dsyms;       /* <= 30 distance symbols in canonical order, five bits each, twelve per word
+                                                           * (named words, not an array: the compiler turns a select over an array
+                                                           * into an indexed load from scratch) */
+QZ_DEV uint64_t qzk_dsyms_word(const uint16_t *dsorted, uint32_t n, uint32_t k)
+{
+    uint64_t word = 0;
+    for (uint32_t j = 0; j < 12; j++) { const uint32_t i = 12u * k + j; if (i < n) word |= (uint64_t)((uint32_t)dsorted[i] & 31u) << (5 * j); }
+    return word;
+}
+QZ_DEV void qzk_dsyms_load(qzk_dsyms *DS, const uint16_t *dsorted, const uint16_t *dcount)
+{
+    uint32_t n = 0;
+    for (int l = 1; l <= 15; l++) n += dcount[l];
+    if (n > 30) n = 30;
+    DS->w0 = qzk_dsyms_word(dsorted, n, 0); DS->w1 = qzk_dsyms_word(dsorted, n, 1); DS->w2 = qzk_dsyms_word(dsorted, n, 2);
+}
+
+/* the long half of a code: (length, canonical index) from the register intervals; length 0 = no such code */
+template <int ROOT>
+QZ_DEV void qzk_long_interval(uint64_t bb, const uint32_t *LR, uint32_t *sel_l, uint32_t *sel_i)
+{
+    constexpr int N = 15 - ROOT;
+    const uint32_t V = qzk_rev((uint32_t)bb & 0x7fffu, 15);
+    uint32_t sl = 0, si = 0;
+#pragma unroll
+    for (int k = N - 1; k >= 0; k--) {                          /* longest first: the shortest hit is kept */
+        const int l = ROOT + 1 + k;
+        const uint32_t first = LR[k] & 0x7fffu, limit = LR[k] >> 15, c = V >> (15 - l);
+        const uint32_t d = (LR[N + (k >> 1)] >> (16 * (k & 1))) & 0xffffu;
+        const bool hit = c >= first && c < limit;
+        sl = hit ? (uint32_t)l : sl; si = hit ? ((c + d) & 0xffffu) : si;
+    }
+    *sel_l = sl; *sel_i = si;
+}
+
+template <int NX>      /* NX: literals a trip may take behind its first symbol */
+QZ_DEV void qzk_lane_trip(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, const uint16_t *lroot, const uint16_t *droot,
+                          uint64_t hist, const uint32_t *LR, const uint32_t *DR, const qzk_dsyms *DS)
+{
+    uint64_t bb = S->b.bb; int bc = S->b.bc;                    /* >= 56 valid bits: a whole symbol with everything it drags along */
+    const uint8_t *const d8 = QZK_DROOT8(droot), *const pool = QZK_LPOOL(droot);
+    const uint32_t e = lroot[(uint32_t)bb & ((1u << QZK_LLROOT) - 1)];
+    uint32_t l = e & 15; int sym = (int)(e >> 4);
+    if (e == 0) {                                               /* longer than the root */
+        uint32_t sl, si;
+        qzk_long_interval<QZK_LLROOT>(bb, LR, &sl, &si);
+        const uint32_t pr = si - S->lbase;
+        const uint32_t pv = pool[pr < (uint32_t)QZK_LPOOL_N ? pr : 0u];
+        sym = -1; l = sl;
+        if (sl != 0) {
+            if (pr < (uint32_t)QZK_LPOOL_N && pv != 0xffu) sym = (int)pv;
+            else { sym = T->lsorted[si]; QZK_PIN(sym); }       /* a long length code, END_BLOCK, a literal the pool has no room for;
+                                                                 * pinned: the wait for this load belongs in here, not where the paths meet */
+        }
+    }
+    bb >>= l; bc -= (int)l;
+    uint32_t room = S->out_cap - S->op;                         /* bytes the segment may still produce */
+    uint32_t lv = 0, lk = 0;                                    /* the trip's literals (packed, lowest first), their number */
+    uint64_t lv_hi = 0;
+    uint64_t rec = 0; uint32_t nrec = 0;                        /* the trip's sequence, if it has one */
+    bool run = false;
+    const bool is_lit = (uint32_t)sym < 256u;
+    if (is_lit && room != 0) { lv = (uint32_t)sym; lk = 1; run = true; }
+    if (sym > 256) {
+        const int ls = sym - 257;
+        uint32_t xb = (ls < 8 || ls >= 28) ? 0u : (uint32_t)(ls - 4) >> 2;
+        uint32_t len = ls < 8 ? 3u + (uint32_t)ls : ls >= 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3)) << xb);
+        len += (uint32_t)bb & ((1u << xb) - 1); bb >>= xb; bc -= (int)xb;
+        const uint32_t de = d8[(uint32_t)bb & ((1u << QZK_LDROOT) - 1)];
+        uint32_t dl = de & 7; int ds = (int)(de >> 3);
+        if (de == 0) {
+            uint32_t sl, si;
+            qzk_long_interval<QZK_LDROOT>(bb, DR, &sl, &si);
+            const uint32_t w = (si * 43u) >> 9, sh = 5u * (si - 12u * w);
+            const uint64_t word = w == 0 ? DS->w0 : w == 1 ? DS->w1 : DS->w2;
+            ds = sl != 0 && si < 30 ? (int)((uint32_t)(word >> sh) & 31u) : -1; dl = sl;
+        }
+        bb >>= dl; bc -= (int)dl;
+        const bool dbad = ds < 0 || ds >= 30;
+        if (dbad) ds = 0;
+        xb = ds < 4 ? 0u : (uint32_t)(ds - 2) >> 1;
+        uint32_t dist = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1)) << xb);
+        dist += (uint32_t)bb & ((1u << xb) - 1); bb >>= xb; bc -= (int)xb;
+        const int err = ls >= 29 || dbad ? QZK_INF_EDATA : (uint64_t)dist > hist + S->op ? QZK_INF_EHIST : len > room ? QZK_INF_EOUT : 0;
+        if (err) { S->status = err; S->state = QZK_LS_DONE; }
+        else {
+            rec = (uint64_t)O->lrun | (uint64_t)len << 32 | (uint64_t)(dist - 1) << 48; nrec = 1;
+            S->op += len; room -= len; run = true;
+        }
+    } else if (!(is_lit && room != 0)) {                        /* the end of the block, or of the decode */
+        if (sym == 256) { if (S->last) { S->status = QZK_INF_FINAL; S->state = QZK_LS_DONE; } else S->state = QZK_LS_HDR; }
+        else { S->status = sym < 0 ? QZK_INF_EDATA : QZK_INF_EOUT; S->state = QZK_LS_DONE; }
+    }
+    /* literals come in runs, and a match is usually followed by some: up to NX more while their codes sit in the root
+     * table, the bits the trip started with last and the segment has room */
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+        const uint32_t e2 = lroot[(uint32_t)bb & ((1u << QZK_LLROOT) - 1)];
+        const uint32_t l2 = e2 & 15;
+        run = run && (e2 - 1u) < 4095u && (int)l2 <= bc && lk < room;
+        const uint32_t take = run ? l2 : 0u;
+        bb >>= take; bc -= (int)take;
+        if (NX > 3) { if (lk < 4) lv |= run ? (e2 >> 4) << (8 * lk) : 0u; else lv_hi |= run ? (uint64_t)(e2 >> 4) << (8 * lk) : 0ull; }
+        else lv |= run ? (e2 >> 4) << (8 * lk) : 0u;
+        lk += run ? 1u : 0u;
+    }
+    /* the trip's two stores, always both */
+    ((uint64_t *)O->sq)[O->nseq] = rec;
+    O->nseq += nrec; O->lrun = nrec ? 0u : O->lrun;
+    if (NX > 3) qzk_st64u(O->lp + O->lw, (uint64_t)lv | lv_hi); else ((qz_u32u *)(O->lp + O->lw))->v = lv;
+    O->lw += lk; O->lrun += lk; S->op += lk;
+    S->b.bb = bb; S->b.bc = bc;
+}
+
 /* LPW = segments (active lanes) per single-wave workgroup: LPW * 1.25 KiB of LDS (16 -> eight workgroups per CU) */
 /* OCC = waves per SIMD the register budget is cut for (LPW 16: the LDS admits 8 waves per CU = 2 per SIMD; LPW 8: 16 = 4) */
 template <int LPW, int OCC = 2>
@@ -434,7 +597,7 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
     qzk_lane_st S;
     S.b.p = comp + sg.in_off; S.b.end = sg.in_len; qzk_lseek(&S.b, 0);
     S.op = 0; S.nblocks = 0; S.last = 0; S.clen = 0; S.rpos = 0; S.out_cap = sg.out_cap;
-    S.lmax = 0; S.dmax = 0; S.status = QZK_INF_EDATA; S.state = QZK_LS_HDR;
+    S.lmax = 0; S.dmax = 0; S.lbase = 0; S.status = QZK_INF_EDATA; S.state = QZK_LS_HDR;
     S.through = sg.flags & QZK_INF_THROUGH_FLUSH;
     qzk_tok_out O;
     {
@@ -450,28 +613,31 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
     uint32_t LR[QZK_LR_WORDS], DR[QZK_DR_WORDS];    /* the long literal/length and distance codes of the current block (registers) */
     for (int i = 0; i < QZK_LR_WORDS; i++) LR[i] = 0;
     for (int i = 0; i < QZK_DR_WORDS; i++) DR[i] = 0;
+    qzk_dsyms DS; DS.w0 = DS.w1 = DS.w2 = 0;        /* the distance symbols of the current block */
 
     while (S.state != QZK_LS_DONE) {
         qzk_lbits *b = &S.b;
-        if (S.state == QZK_LS_SYM && b->pos + 16 <= b->end) {
+        if (S.state == QZK_LS_SYM && b->pos + 16 <= b->end && !O.count_only) {
             /* ---- the hot loop.  Branch-free refill: the 8 bytes at the read position are always already in flight
              * (pw), each trip ORs them in above the valid bits, steps over the bytes that fitted and issues the load
              * for the next trip, whose latency the symbol decode then covers; >= 56 valid bits per trip is a whole
-             * symbol (15 + 5 + 15 + 13).  Rounds of QZK_TOK_ROUND trips (the inner loop's bound, kept from the staging days); bounded so
-             * that lanes parked in a cold state get their turn. ---- */
+             * symbol (15 + 5 + 15 + 13).  Bounded (QZK_TOK_TRIPS trips) so that lanes parked in a cold state - the next
+             * block's header - get their turn. ---- */
             b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;     /* hand whole bytes back */
             uint64_t pw = qzk_ld64u(b->p + b->pos);
-            for (int round = 0; round < 32 && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; round++) {
-                for (int trip = 0; trip < QZK_TOK_ROUND && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
-                    b->bb |= pw << b->bc;
-                    b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
-                    pw = qzk_ld64u(b->p + b->pos);
-                    qzk_lane_symbol<false, true>(&S, &O, T, lroot, droot, S.through ? sg.out_off : 0, LR, DR);
+            /* every trip ends with its two stores behind the load for the next one, so the top of the loop waits for all
+             * but the two newest memory operations - provided the way INTO the loop looks the same: two stores to the slots
+             * the first trip overwrites anyway */
+            ((uint64_t *)O.sq)[O.nseq] = 0; ((qz_u32u *)(O.lp + O.lw))->v = 0;
+            const uint64_t hist = S.through ? sg.out_off : 0;
+            for (int trip = 0; trip < QZK_TOK_TRIPS && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
+                b->bb |= pw << b->bc;
+                b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
+                pw = qzk_ld64u(b->p + b->pos);
+                qzk_lane_trip<QZK_LIT_RUN - 1>(&S, &O, T, lroot, droot, hist, LR, DR, &DS);
 #ifdef QZK_INF_PROF
-                    prof_trips++;
+                prof_trips++;
 #endif
-                }
-                qzk_tok_round_flush(&O);
             }
             b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;
             const uint32_t keep = (uint32_t)b->bc; const uint64_t low = b->bb;
@@ -488,7 +654,7 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
             }
         } else if (S.state == QZK_LS_HDR) {
             qzk_lane_header(&S, T, lroot, droot);
-            if (S.state == QZK_LS_SYM) qzk_longtab_load(LR, DR, T, S.lmax, S.dmax);
+            if (S.state == QZK_LS_SYM) { qzk_longtab_load(LR, DR, T, S.lmax, S.dmax); qzk_dsyms_load(&DS, T->dsorted, T->dcount); }
         }
         else if (S.state == QZK_LS_RAW) {
             if (O.count_only) { S.op += S.clen; S.rpos += S.clen; S.clen = 0; }         /* nothing to move */

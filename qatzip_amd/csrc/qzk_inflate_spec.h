@@ -71,7 +71,7 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
     S.b.p = comp + sg.in_off; S.b.end = sg.in_len; qzk_lseek(&S.b, 0);
     S.op = 0; S.nblocks = 0; S.last = 0; S.clen = 0; S.rpos = 0;
     S.out_cap = j == 0 ? sg.out_cap : 0xffffffffu;                 /* lane 0 knows the output offset, phase B checks the rest */
-    S.lmax = 0; S.dmax = 0; S.status = QZK_INF_EDATA; S.state = QZK_LS_HDR;
+    S.lmax = 0; S.dmax = 0; S.lbase = 0; S.status = QZK_INF_EDATA; S.state = QZK_LS_HDR;
     S.through = sg.flags & QZK_INF_THROUGH_FLUSH;
     qzk_tok_out O;
     qzk_tok_init(&O, lits + ts[slot].lit_off, seqs + ts[slot].seq_off, false);

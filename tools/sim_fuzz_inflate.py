@@ -17,10 +17,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import datagen  # noqa: E402
 
 SIMDIR = os.path.join(ROOT, "tests", "sim")
-so = os.path.join(SIMDIR, "libqzsim.so")
+so = os.environ.get("QZSIM_SO") or os.path.join(SIMDIR, "libqzsim.so")       # QZSIM_SO: an emulator build with other -D flags
 if not os.path.exists(so):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-I", SIMDIR, "-Wno-unused-function", "-o", so,
-                           os.path.join(SIMDIR, "sim_driver.cpp")])
+                           os.path.join(SIMDIR, "sim_driver.cpp")] + os.environ.get("QZSIM_FLAGS", "").split())
 S = C.CDLL(so)
 for f in (S.sim_inflate, S.sim_inflate_lane):
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
