@@ -41,11 +41,20 @@
 #define QZD_LANE_MIN_SEGS_BIG 10500u
 #define QZD_LANE_MIN(seg_bytes) ((seg_bytes) <= 65536u + 64u ? QZD_LANE_MIN_SEGS : QZD_LANE_MIN_SEGS_BIG)
 #define QZD_LANE_SEGS_PER_WAVE 16u
-/* sub-decoders per segment of phase A.  1 = the serial phase A.  The speculative one (2, 4, 8; QATZIP_AMD_INFLATE_K)
- * decodes compressible segments K times faster, but blocks of near-equal code lengths (incompressible data that still
- * got Huffman-coded) never let a misaligned decoder fall into step, so those segments come back to the serial kernel
- * and set the pace: on the bench data 13 % of the segments do, and the serial phase A alone is faster */
-#define QZD_SPEC_LANES 1u
+/* lanes per segment of phase A (QATZIP_AMD_INFLATE_K = 1, 2, 4, 8 overrides; 1 = the serial phase A).  The LDS seats
+ * sixteen segments' tables per wave, so four lanes per segment fill the wave: the lanes share the tables, start at evenly
+ * spaced bits and fall into step with each other (qzk_inflate_spec.h) */
+#define QZD_SPEC_LANES 4u
+static uint32_t spec_lanes(const qzk_infseg *hs, uint32_t nsegs)
+{
+    uint32_t K = QZD_SPEC_LANES;
+    const char *ke = getenv("QATZIP_AMD_INFLATE_K");
+    if (ke) { int v = atoi(ke); if (v == 1 || v == 2 || v == 4 || v == 8) K = (uint32_t)v; }
+    /* it needs a compressed-length hint (qzk_infseg.pad) and segments that write output and begin with no history */
+    for (uint32_t i = 0; i < nsegs && K > 1; i++)
+        if ((hs[i].flags & (QZK_INF_COUNT_ONLY | QZK_INF_THROUGH_FLUSH)) || hs[i].pad == 0) K = 1;
+    return K;
+}
 #define QZD_SO_PARTS 8u             /* output ranges a streamed decode is resolved and sent in */
 
 /* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF.  A thread takes sixteen byte positions a trip:
@@ -98,9 +107,9 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     uint64_t lit_total = 0, seq_total = 0;
     for (uint32_t i = 0; i < nsegs; i++) {
         const bool writes = !(hs[i].flags & QZK_INF_COUNT_ONLY);
-        const uint64_t lc = !writes ? 0 : K == 1 ? QZK_TOK_LITCAP(hs[i].out_cap) : QZK_SPEC_LITCAP(hs[i].out_cap, K);
-        const uint64_t sc = !writes ? 0 : K == 1 ? QZK_TOK_SEQCAP(hs[i].out_cap) : QZK_SPEC_SEQCAP(hs[i].out_cap, K);
         for (uint32_t j = 0; j < K; j++) {
+            const uint64_t lc = !writes ? 0 : K == 1 ? QZK_TOK_LITCAP(hs[i].out_cap) : QZK_SPEC_LITCAP(hs[i].out_cap, K, j);
+            const uint64_t sc = !writes ? 0 : K == 1 ? QZK_TOK_SEQCAP(hs[i].out_cap) : QZK_SPEC_SEQCAP(hs[i].out_cap, K, j);
             tsv[(size_t)i * K + j].lit_off = lit_total; tsv[(size_t)i * K + j].seq_off = seq_total;
             lit_total += lc; seq_total += sc;
         }
@@ -111,7 +120,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     const size_t rcb = K == 1 ? 0 : (((size_t)nsegs * K * QZK_SPEC_NREC * sizeof(qzk_rec) + 255) & ~(size_t)255);
     const size_t litb = (lit_total + 511) & ~(uint64_t)255, seqb = seq_total * sizeof(qzk_seq);
     /* output streaming: only the plain decode of a whole member (every segment writes, known output offsets) */
-    const bool stream_out = run_b && c->so_host && c->so_nat && K == 1 && nsegs >= QZD_LANE_MIN_SEGS;
+    const bool stream_out = run_b && c->so_host && c->so_nat && nsegs >= QZD_LANE_MIN_SEGS;
     const size_t ordb = ((size_t)nsegs * 4 + 255) & ~(size_t)255;
     const size_t need = tabb + tsb + chb + rcb + litb + seqb + ordb + 256;
     if (need > c->big_cap) {
@@ -129,41 +138,62 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     uint8_t *lit_d = pb; pb += litb;
     qzk_seq *seq_d = (qzk_seq *)pb; pb += (seqb + 255) & ~(size_t)255;
     uint32_t *ord_d = (uint32_t *)pb;
-    if (stream_out) { memcpy(st_ord, c->so_nat, (size_t)nsegs * 4); HIPCHK(c, hipMemcpyAsync(ord_d, st_ord, (size_t)nsegs * 4, hipMemcpyHostToDevice, st)); }
     HIPCHK(c, hipMemcpyAsync(d_segs, st_segs, sb, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(ts_d, tsv, (size_t)nsegs * K * sizeof(qzk_tokseg), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[1][1], st));
-    if (K == 1) {
-        /* segments per single-wave workgroup: each lane keeps 1.25 KiB of root tables in LDS, and partly filled waves
-         * give the serial decode loops more waves to hide behind (measured in DESIGN.md K3b) */
-        uint32_t lpw = QZD_LANE_SEGS_PER_WAVE;
-        const char *le = getenv("QATZIP_AMD_INFLATE_LPW");
-        if (le) { int v = atoi(le); if (v == 8 || v == 16 || v == 32 || v == 64) lpw = (uint32_t)v; }
-        const dim3 grid((nsegs + lpw - 1) / lpw), blk(lpw);
+    /* segments per single-wave workgroup of the serial phase A: each lane keeps 1.25 KiB of root tables in LDS, and partly
+     * filled waves give the serial decode loops more waves to hide behind (measured in DESIGN.md K3b) */
+    uint32_t lpw = QZD_LANE_SEGS_PER_WAVE;
+    const char *le = getenv("QATZIP_AMD_INFLATE_LPW");
+    if (le) { int v = atoi(le); if (v == 8 || v == 16 || v == 32 || v == 64) lpw = (uint32_t)v; }
+    const char *oe = getenv("QATZIP_AMD_INFLATE_OCC");
+    const int occ = oe ? atoi(oe) : 0;
 #ifndef QZD_TOK_OCC
 #define QZD_TOK_OCC 2           /* waves per SIMD of phase A's sixteen-lane workgroups: what their root tables leave room for in LDS */
 #endif
+    /* the serial phase A over all segments (order NULL) or over `count` of them picked by index; it fills sub-stream 0 */
+    auto tok_launch = [&](const uint32_t *order, uint32_t count) {
+        const dim3 grid(((order ? count : nsegs) + lpw - 1) / lpw), blk(lpw);
 #define QZD_TOK_LAUNCH(N, W) hipLaunchKernelGGL((qzk_inflate_tok_kernel<N, W>), grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
-                                               ts_d, lit_d, seq_d, ch_d)
-        const char *oe = getenv("QATZIP_AMD_INFLATE_OCC");
-        const int occ = oe ? atoi(oe) : 0;
+                                               ts_d, lit_d, seq_d, ch_d, order, count, K)
         if (lpw == 8) { if (occ == 2) QZD_TOK_LAUNCH(8, 2); else QZD_TOK_LAUNCH(8, 4); }
         else if (lpw == 32) QZD_TOK_LAUNCH(32, 1); else if (lpw == 64) QZD_TOK_LAUNCH(64, 1);
         else QZD_TOK_LAUNCH(16, QZD_TOK_OCC);
 #undef QZD_TOK_LAUNCH
-    } else {
+    };
+    if (K == 1) tok_launch(NULL, 0);
+    else {
         const uint32_t spw = 64 / K;
         const dim3 grid((nsegs + spw - 1) / spw), blk(64);
+        static uint32_t spec_epoch = 0;                             /* tags the marks of a launch: scratch left by an earlier one is not mistaken for them */
+        const uint32_t epoch = ++spec_epoch;
 #define QZD_SPEC_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_spec_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
-                                             ts_d, lit_d, seq_d, ch_d, rec_d)
+                                             ts_d, lit_d, seq_d, ch_d, rec_d, epoch)
         if (K == 2) QZD_SPEC_LAUNCH(2); else if (K == 4) QZD_SPEC_LAUNCH(4); else QZD_SPEC_LAUNCH(8);
 #undef QZD_SPEC_LAUNCH
+        /* what that kernel hands back (QZK_INF_ESPEC: a sub-stream outgrew its scratch, too many pieces) goes through the
+         * serial phase A, into the segment's first sub-stream - which is sized for a whole segment */
+        HIPCHK(c, hipMemcpyAsync(st_res, d_res, rb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        uint32_t nredo = 0;
+        for (uint32_t i = 0; i < nsegs; i++) if (st_res[i].status == QZK_INF_ESPEC) st_ord[nredo++] = i;
+        if (getenv("QATZIP_AMD_TRACE")) {
+            uint32_t hist[64] = {0};
+            for (uint32_t i = 0; i < nredo; i++) { const uint32_t w = st_res[st_ord[i]].nblocks; hist[w < 64 ? w : 63]++; }
+            fprintf(stderr, "[two_phase] K=%u: %u of %u segments handed back to the serial kernel; reasons:", K, nredo, nsegs);
+            for (int k = 0; k < 64; k++) if (hist[k]) fprintf(stderr, " %d:%u", k, hist[k]);
+            fprintf(stderr, "\n");
+        }
+        if (nredo) {
+            HIPCHK(c, hipMemcpyAsync(ord_d, st_ord, (size_t)nredo * 4, hipMemcpyHostToDevice, st));
+            tok_launch(ord_d, nredo);
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev[1][0], st));
     c->tp.segs = d_segs; c->tp.res = d_res; c->tp.ts = ts_d; c->tp.lits = lit_d; c->tp.seqs = seq_d; c->tp.chains = ch_d;
     c->tp.ord = ord_d; c->tp.nsegs = nsegs; c->tp.K = K;
     if (!run_b) {
-        /* phase A only (K == 1): its results say which candidates are real segments and where their output belongs;
+        /* phase A only: its results say which candidates are real segments and where their output belongs;
          * two_phase_resolve() runs phase B once the host has decided */
         HIPCHK(c, hipMemcpyAsync(st_res, d_res, rb, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -171,6 +201,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         memcpy(h_res, st_res, rb);
         return QZD_OK;
     }
+    if (stream_out) { memcpy(st_ord, c->so_nat, (size_t)nsegs * 4); HIPCHK(c, hipMemcpyAsync(ord_d, st_ord, (size_t)nsegs * 4, hipMemcpyHostToDevice, st)); }
     if (!stream_out) {
         hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
                            d_comp, d_out, d_segs, d_res, nsegs, ts_d, K, lit_d, seq_d, ch_d, (const uint32_t *)NULL, 0u);
@@ -204,24 +235,6 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     memcpy(h_res, st_res, rb);
     float t = 0;
     if (hipEventElapsedTime(&t, c->ev[1][0], c->ev[1][2]) == hipSuccess) c->inf_ms[2] += t;     /* phase B share */
-    if (K == 1) return QZD_OK;
-    /* the segments the speculative kernel handed back */
-    std::vector<uint32_t> redo;
-    for (uint32_t i = 0; i < nsegs; i++) if (h_res[i].status == QZK_INF_ESPEC) redo.push_back(i);
-    if (getenv("QATZIP_AMD_TRACE")) {
-        uint32_t hist[64] = {0};
-        for (uint32_t i : redo) hist[h_res[i].nblocks < 64 ? h_res[i].nblocks : 63]++;
-        fprintf(stderr, "[two_phase] K=%u: %zu of %u segments handed back to the serial kernel; reasons:", K, redo.size(), nsegs);
-        for (int k = 0; k < 64; k++) if (hist[k]) fprintf(stderr, " %d:%u", k, hist[k]);
-        fprintf(stderr, "\n");
-    }
-    if (redo.empty()) return QZD_OK;
-    std::vector<qzk_infseg> rs(redo.size());
-    std::vector<qzk_infres> rr(redo.size());
-    for (size_t i = 0; i < redo.size(); i++) rs[i] = hs[redo[i]];
-    rc = two_phase(c, d_comp, d_out, rs.data(), (uint32_t)redo.size(), rr.data(), 1, st);
-    if (rc) return rc;
-    for (size_t i = 0; i < redo.size(); i++) h_res[redo[i]] = rr[i];
     return QZD_OK;
 }
 
@@ -232,12 +245,13 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
 static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qzk_infseg *hs, uint32_t nsegs,
                              const uint32_t *h_order, uint32_t count, qzk_infres *h_res, uint8_t *h_dst, hipStream_t st)
 {
-    if (nsegs != c->tp.nsegs || c->tp.K != 1 || count == 0) return QZD_ERR_PARAM;
+    if (nsegs != c->tp.nsegs || count == 0) return QZD_ERR_PARAM;
+    const uint32_t K = c->tp.K;                                      /* sub-streams per segment of the phase A that ran */
     qzk_infseg *d_segs = (qzk_infseg *)c->tp.segs; qzk_infres *d_res = (qzk_infres *)c->tp.res;
     /* the pinned mirror, laid out as two_phase() left it (same nsegs, K == 1) */
     const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
     const size_t o_res = (sb + 15) & ~(size_t)15, o_ts = o_res + ((rb + 15) & ~(size_t)15);
-    const size_t o_ord = o_ts + (((size_t)nsegs * sizeof(qzk_tokseg) + 15) & ~(size_t)15);
+    const size_t o_ord = o_ts + (((size_t)nsegs * K * sizeof(qzk_tokseg) + 15) & ~(size_t)15);
     if (o_ord + (size_t)nsegs * 4 > c->aux_cap) return QZD_ERR_PARAM;
     qzk_infres *st_res = (qzk_infres *)(c->h_aux + o_res);
     memcpy(c->h_aux, hs, sb);
@@ -252,7 +266,7 @@ static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, 
         off[p] = hs[h_order[first]].out_off;
         off[p + 1] = hs[h_order[end - 1]].out_off + hs[h_order[end - 1]].out_cap;
         hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((end - first + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
-                           d_comp, d_out, d_segs, d_res, nsegs, (const qzk_tokseg *)c->tp.ts, 1u, (const uint8_t *)c->tp.lits,
+                           d_comp, d_out, d_segs, d_res, nsegs, (const qzk_tokseg *)c->tp.ts, K, (const uint8_t *)c->tp.lits,
                            (const qzk_seq *)c->tp.seqs, (const qzk_chain *)c->tp.chains, (const uint32_t *)(c->tp.ord + first), end - first);
         if (h_dst) HIPCHK(c, hipEventRecord(c->so_ev[p], st));
     }
@@ -288,13 +302,7 @@ extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *
     const bool lanes = force ? force[0] == 'l' : nsegs >= QZD_LANE_MIN(hs[0].out_cap);
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
     if (lanes) {
-        /* speculative sub-segment decoding needs a length hint (qzd_infseg.pad) and segments that write output */
-        uint32_t K = QZD_SPEC_LANES;
-        const char *ke = getenv("QATZIP_AMD_INFLATE_K");
-        if (ke) { int v = atoi(ke); if (v == 1 || v == 2 || v == 4 || v == 8) K = (uint32_t)v; }
-        for (uint32_t i = 0; i < nsegs && K > 1; i++)
-            if ((hs[i].flags & (QZK_INF_COUNT_ONLY | QZK_INF_THROUGH_FLUSH)) || hs[i].pad == 0) K = 1;
-        int rc = two_phase(c, d_comp, d_out, hs, nsegs, (qzk_infres *)h_res, K, st);
+        int rc = two_phase(c, d_comp, d_out, hs, nsegs, (qzk_infres *)h_res, spec_lanes(hs, nsegs), st);
         if (rc) return rc;
     } else {
         const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
@@ -542,7 +550,7 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
             }
             lap("segment records");
             HIPCHK(c, hipEventRecord(c->ev[0][0], c->st[0]));
-            rc = two_phase(c, d_src, d_dst, ps.data(), ns, pr.data(), 1, c->st[0], false);
+            rc = two_phase(c, d_src, d_dst, ps.data(), ns, pr.data(), spec_lanes(ps.data(), ns), c->st[0], false);
             if (rc) return rc;
             lap("phase A");
             std::vector<uint32_t> chain;                        /* launch indices of the real segments, in output order */

@@ -502,9 +502,9 @@ QZ_DEV void qzk_long_interval(uint64_t bb, const uint32_t *LR, uint32_t *sel_l, 
     *sel_l = sl; *sel_i = si;
 }
 
-template <int NX>      /* NX: literals a trip may take behind its first symbol */
+template <int NX>      /* NX: literals a trip may take behind its first symbol (none when !allow: the speculative decoders near a mark) */
 QZ_DEV void qzk_lane_trip(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, const uint16_t *lroot, const uint16_t *droot,
-                          uint64_t hist, const uint32_t *LR, const uint32_t *DR, const qzk_dsyms *DS)
+                          uint64_t hist, const uint32_t *LR, const uint32_t *DR, const qzk_dsyms *DS, bool allow = true)
 {
     uint64_t bb = S->b.bb; int bc = S->b.bc;                    /* >= 56 valid bits: a whole symbol with everything it drags along */
     const uint8_t *const d8 = QZK_DROOT8(droot), *const pool = QZK_LPOOL(droot);
@@ -529,7 +529,7 @@ QZ_DEV void qzk_lane_trip(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, 
     uint64_t rec = 0; uint32_t nrec = 0;                        /* the trip's sequence, if it has one */
     bool run = false;
     const bool is_lit = (uint32_t)sym < 256u;
-    if (is_lit && room != 0) { lv = (uint32_t)sym; lk = 1; run = true; }
+    if (is_lit && room != 0) { lv = (uint32_t)sym; lk = 1; run = allow; }
     if (sym > 256) {
         const int ls = sym - 257;
         uint32_t xb = (ls < 8 || ls >= 28) ? 0u : (uint32_t)(ls - 4) >> 2;
@@ -554,7 +554,7 @@ QZ_DEV void qzk_lane_trip(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, 
         if (err) { S->status = err; S->state = QZK_LS_DONE; }
         else {
             rec = (uint64_t)O->lrun | (uint64_t)len << 32 | (uint64_t)(dist - 1) << 48; nrec = 1;
-            S->op += len; room -= len; run = true;
+            S->op += len; room -= len; run = allow;
         }
     } else if (!(is_lit && room != 0)) {                        /* the end of the block, or of the decode */
         if (sym == 256) { if (S->last) { S->status = QZK_INF_FINAL; S->state = QZK_LS_DONE; } else S->state = QZK_LS_HDR; }
@@ -574,9 +574,13 @@ QZ_DEV void qzk_lane_trip(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, 
         lk += run ? 1u : 0u;
     }
     /* the trip's two stores, always both */
+#ifndef QZK_X_NOSEQ
     ((uint64_t *)O->sq)[O->nseq] = rec;
+#endif
     O->nseq += nrec; O->lrun = nrec ? 0u : O->lrun;
+#ifndef QZK_X_NOLIT
     if (NX > 3) qzk_st64u(O->lp + O->lw, (uint64_t)lv | lv_hi); else ((qz_u32u *)(O->lp + O->lw))->v = lv;
+#endif
     O->lw += lk; O->lrun += lk; S->op += lk;
     S->b.bb = bb; S->b.bc = bc;
 }
@@ -586,10 +590,13 @@ QZ_DEV void qzk_lane_trip(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, 
 template <int LPW, int OCC = 2>
 QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                  qzk_inf_tab *tabs, const qzk_tokseg *ts, uint8_t *lits, qzk_seq *seqs,
-                                 qzk_chain *chains)
+                                 qzk_chain *chains, const uint32_t *order = 0 /* or: the launch covers `count` segments picked by index */,
+                                 uint32_t count = 0, uint32_t ts_stride = 1 /* sub-streams per segment in ts: this kernel fills the first */)
 {
     QZ_LDS uint16_t roots[LPW][QZK_LANE_ROOTSZ];
-    const uint32_t sidx = blockIdx.x * LPW + threadIdx.x;
+    const uint32_t widx = blockIdx.x * LPW + threadIdx.x;
+    if (widx >= (order ? count : nsegs)) return;
+    const uint32_t sidx = order ? order[widx] : widx;
     if (sidx >= nsegs) return;
     const qzk_infseg sg = segs[sidx];
     qzk_inf_tab *T = tabs + sidx;
@@ -602,7 +609,7 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
     qzk_tok_out O;
     {
         const bool co = sg.flags & QZK_INF_COUNT_ONLY;
-        qzk_tok_init(&O, co ? lits : lits + ts[sidx].lit_off, co ? seqs : seqs + ts[sidx].seq_off, co);
+        qzk_tok_init(&O, co ? lits : lits + ts[(uint64_t)sidx * ts_stride].lit_off, co ? seqs : seqs + ts[(uint64_t)sidx * ts_stride].seq_off, co);
     }
     /* the pieces phase B puts the segment together from: runs of sequences, and stored blocks as they lie in the input */
     qzk_chain *const C = chains + sidx;

@@ -1,70 +1,90 @@
 /*
- * qzk_inflate_spec.h — K3b phase A with SUB-SEGMENT SPECULATION: K lanes per segment, gfx950.
+ * qzk_inflate_spec.h — K3b phase A with K LANES PER SEGMENT, gfx950.
  *
- * Phase A of the two-phase inflate (qzk_inflate_lane.h) is bound by a lone lane's serial
- * walk over its segment: 1.4 us per symbol whatever the segment count.  Huffman streams
- * resynchronise on their own: a decoder started at an arbitrary bit falls into step with
- * the true symbol boundaries after a few symbols.  So a segment is decoded by a GROUP of K
- * lanes, block by block ("rounds"):
- *   1. lane 0 of the group parses the block header where the previous round ended (stored
- *      blocks it copies itself, they are a memcpy) and builds the Huffman tables, which
- *      the group shares in LDS;
- *   2. the K lanes start at K evenly spaced bit offsets of what is left of the segment and
- *      decode into their own literal / sequence sub-streams.  A lane that reaches its
- *      neighbour's start keeps going until its own symbol boundary coincides with one the
- *      neighbour published (every 8th of the neighbour's first 128 symbol starts, in LDS):
- *      from there on the two decode identically, so the lane stops and the neighbour's
- *      tokens take over from that record.  Lane 0 is right by construction, hence by
- *      induction every lane on the chain is.  A neighbour that never falls into step (or
- *      ran into garbage) is skipped: the lane carries on to the next one;
- *   3. lane 0 walks the chain, appends the pieces to the segment's piece list (what phase B,
- *      qzk_lz_resolve_kernel, stitches together) and takes over the bit position behind the
- *      block's END_BLOCK for the next round.
- * Whatever does not fit (bad data, a sub-stream outgrowing its scratch, too many pieces) is
- * answered with QZK_INF_ESPEC and the host decodes that segment with the serial kernel:
- * this kernel either delivers a fully validated segment or nothing.
+ * Phase A of the two-phase inflate (qzk_inflate_lane.h) is bound twice over: the LDS holds the root tables of 128
+ * segments per CU, so a wave carries sixteen decoding lanes out of sixty-four - and every wave instruction costs the
+ * same four cycles whether sixteen lanes follow it or all of them; and a lane walks its segment alone, so the phase
+ * cannot end before the longest segment's chain does (a 1 GiB call of 64 KB segments takes as long as a 2 GiB one).
+ * Huffman streams resynchronise on their own: a decoder started at an arbitrary bit falls into step with the true
+ * symbol boundaries after a few symbols (codes of very even lengths take hundreds; only a perfectly flat code never
+ * does).  So a segment is decoded by a GROUP of K lanes that share its tables - the wave's other lanes, which the LDS
+ * left idle - block by block ("rounds"):
+ *   1. lane 0 of the group parses the block header where the previous round ended (stored blocks become raw pieces:
+ *      they are a memcpy for phase B) and builds the Huffman tables in the group's LDS;
+ *   2. the K lanes start at K evenly spaced bit offsets of what is left of the segment and decode with the serial
+ *      kernel's own trip (qzk_lane_trip) into sub-streams of their own.  Every lane leaves a trail: the bit position
+ *      and token counters of its trip starts - the first QZK_SPEC_DENSE one by one, then every QZK_SPEC_EVERY-th, as
+ *      long as it runs.  A lane that has reached a neighbour's share looks at that trail: when the next mark is within
+ *      reach of a trip it takes one symbol a trip (every symbol boundary is then a trip start), and the moment its own
+ *      trip start IS a mark the two are in step for good - same tables, same bits - so the lane stops and the
+ *      neighbour's tokens take over from that mark.  Lane 0 is right by construction, hence by induction every lane on
+ *      the chain is.  A lane that is not in step by the end of a neighbour's share simply carries on into the next
+ *      one's (round 3's version gave up there and handed the segment back: the segments that never fell into step
+ *      were decoded twice, and set the pace); a lane that decodes garbage stops at the end of the segment's input;
+ *   3. lane 0 walks the chain (the stops travel through cross-lane reads, not memory), appends the pieces to the
+ *      segment's piece list (what phase B, qzk_lz_resolve_kernel, stitches together) and takes over the bit position
+ *      behind the block's END_BLOCK for the next round.
+ * What does not fit (bad data, a sub-stream outgrowing its scratch, too many pieces) is answered with QZK_INF_ESPEC
+ * and the host decodes that segment with the serial kernel: this kernel delivers a validated segment or nothing.
  * Same place in the reference as the rest of K3: zlib inflate(), src/qatzip_sw.c:339.
  */
 #ifndef QZK_INFLATE_SPEC_H
 #define QZK_INFLATE_SPEC_H
 #include "qzk_inflate_lane.h"
 
-#define QZK_SPEC_NREC 16           /* symbol starts a lane publishes per round ... */
-#define QZK_SPEC_EVERY 8           /* ... one every so many symbols (covers the first 128) */
-#define QZK_SPEC_REACH 8u          /* a lane gives up 1/REACH of a share beyond its own share (it should have fallen into step) */
+#ifndef QZK_SPEC_NREC
+#define QZK_SPEC_NREC 64           /* marks a lane may leave per round ... */
+#endif
+#ifndef QZK_SPEC_DENSE
+#define QZK_SPEC_DENSE 24          /* ... its first trips one by one ... */
+#endif
+#ifndef QZK_SPEC_EVERY
+#define QZK_SPEC_EVERY 32          /* ... then one trip in so many (a power of two) */
+#endif
 #define QZK_SPEC_MINBITS 512u      /* a block is split only when every lane gets at least this much of it */
-/* scratch of one sub-stream: QZK_SPEC_SLACK times its fair share of the segment's worst case */
-#define QZK_SPEC_SLACK 4ull
-#define QZK_SPEC_LITCAP(out_cap, K) (((QZK_SPEC_SLACK * (uint64_t)(out_cap) / (K) + 255) & ~(uint64_t)63) + 64)
-#define QZK_SPEC_SEQCAP(out_cap, K) ((QZK_SPEC_SLACK * ((uint64_t)(out_cap) / 3) / (K) + 24) & ~(uint64_t)1)
+/* scratch of the sub-streams: lane 0 may have to decode the whole segment alone (nobody falls into step with a flat
+ * code); the last lane decodes to the end of the block however much longer than guessed that is (a share and all that
+ * follows it: K - 1 shares cover it whenever the block is not longer than the segment's input); the lanes between stop at
+ * twice a fair share - past that the segment goes back to the serial kernel */
+#ifdef QZK_SPEC_TINY        /* emulator stress builds: sub-streams that overflow at once, so that the continuation rounds are exercised */
+#define QZK_SPEC_SLACK(K, j) 1ull / 3
+#else
+#define QZK_SPEC_SLACK(K, j) ((j) == (K) - 1 ? (uint64_t)((K) > 2 ? (K) - 1 : 2) : 2ull)
+#endif
+#define QZK_SPEC_LITCAP(out_cap, K, j) ((j) == 0 ? QZK_TOK_LITCAP(out_cap) + 64 + 512 : (((uint64_t)(out_cap) * QZK_SPEC_SLACK(K, j) / (K) + 255) & ~(uint64_t)63) + 64 + 512)
+#define QZK_SPEC_SEQCAP(out_cap, K, j) ((j) == 0 ? (QZK_TOK_SEQCAP(out_cap) + 13 + 64) & ~(uint64_t)1 : (((uint64_t)(out_cap) / 3) * QZK_SPEC_SLACK(K, j) / (K) + 24 + 64) & ~(uint64_t)1)
 
-typedef struct { uint32_t nlit, nseq, lrun, olen; } qzk_rec;      /* token-stream counters at a published symbol start */
-/* what lane 0 tells its group before a round: mode 0 = segment finished, 1 = decode this block */
-typedef struct { uint32_t mode, hdr_end, span, last; int lmax, dmax; } qzk_spec_hdr;
+typedef struct __attribute__((aligned(32))) { uint32_t pos, nlit, nseq, lrun, olen, tag, pad0, pad1; } qzk_rec;     /* a mark: trip start (bit offset) and the token counters there */
 enum { QZK_ST_RUN = 0, QZK_ST_SYNC, QZK_ST_EOB, QZK_ST_REDO };
-/* how a lane's round ended: SYNC with (target, cidx), or EOB (its block ended at bit `at`), or REDO */
-typedef struct { int kind; uint32_t target, cidx, at, nlit0, nseq0, lrun0, olen0, nlit, nseq, olen; } qzk_spec_stop;
+/* how a lane's round ended: SYNC with mark cidx of lane `target`, or EOB (its block ended at bit `at`), or REDO (why) */
+typedef struct { uint32_t kind, target, cidx, at, nlit0, nseq0, olen0, nlit, nseq, olen; } qzk_spec_stop;
 
+#ifdef QZ_SIM
+QZ_DEV uint32_t qzk_ld32_l2(const uint32_t *p) { return *p; }
+#else
+/* served by the L2: marks are written by another lane of the wave, possibly a moment ago */
+QZ_DEV uint32_t qzk_ld32_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
+#ifdef QZK_SPEC_STATS
+static uint32_t qzk_spec_stats[1 << 20];
+#endif
 template <int K>
-QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
+QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                   qzk_inf_tab *tabs, const qzk_tokseg *ts /* [nsegs * K] */, uint8_t *lits, qzk_seq *seqs,
-                                  qzk_chain *chains, qzk_rec *recs /* [nsegs * K * QZK_SPEC_NREC] */)
+                                  qzk_chain *chains, qzk_rec *recs /* [nsegs * K * QZK_SPEC_NREC] */, uint32_t epoch)
 {
     constexpr int SPW = 64 / K;                                     /* segments per wave */
     QZ_LDS uint16_t roots[SPW][QZK_LANE_ROOTSZ];
-    QZ_LDS qzk_spec_hdr ghdr[SPW];
-    QZ_LDS qzk_spec_stop gstop[64];
-    QZ_LDS uint32_t gpos[64][QZK_SPEC_NREC];                        /* published symbol starts (bit offsets) */
-    QZ_LDS uint32_t gnrec[64];
 
-    const int lane = (int)threadIdx.x, g = lane / K, j = lane % K;
+    const int lane = (int)threadIdx.x, g = lane / K, j = lane % K, gbase = lane - j;
     const uint32_t sidx = blockIdx.x * SPW + (uint32_t)g;
     const bool live = sidx < nsegs;
     const qzk_infseg sg = segs[live ? sidx : 0];
     qzk_inf_tab *T = tabs + (live ? sidx : 0);
     uint16_t *const lroot = roots[g], *const droot = lroot + (1 << QZK_LLROOT);
     const uint32_t slot = (live ? sidx : 0) * K + (uint32_t)j;     /* my sub-stream */
-    qzk_rec *myrec = recs + (uint64_t)slot * QZK_SPEC_NREC;
+    qzk_rec *const myrec = recs + (uint64_t)slot * QZK_SPEC_NREC;
     qzk_chain *C = chains + (live ? sidx : 0);
 
     qzk_lane_st S;
@@ -72,28 +92,42 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
     S.op = 0; S.nblocks = 0; S.last = 0; S.clen = 0; S.rpos = 0;
     S.out_cap = j == 0 ? sg.out_cap : 0xffffffffu;                 /* lane 0 knows the output offset, phase B checks the rest */
     S.lmax = 0; S.dmax = 0; S.lbase = 0; S.status = QZK_INF_EDATA; S.state = QZK_LS_HDR;
-    S.through = sg.flags & QZK_INF_THROUGH_FLUSH;
+    S.through = false;
     qzk_tok_out O;
     qzk_tok_init(&O, lits + ts[slot].lit_off, seqs + ts[slot].seq_off, false);
-    const uint32_t lit_cap = (uint32_t)QZK_SPEC_LITCAP(sg.out_cap, K) - 64, seq_cap = (uint32_t)QZK_SPEC_SEQCAP(sg.out_cap, K) - 10;
+    /* checked on the trips that leave a mark: the margin is what QZK_SPEC_EVERY trips can add */
+    const uint32_t lit_cap = (uint32_t)QZK_SPEC_LITCAP(sg.out_cap, K, j) - 96 - QZK_SPEC_EVERY * 8, seq_cap = (uint32_t)QZK_SPEC_SEQCAP(sg.out_cap, K, j) - 10 - QZK_SPEC_EVERY;
     const uint32_t limit_bits = 8u * (sg.pad != 0 && sg.pad < sg.in_len ? sg.pad : sg.in_len);
+    uint32_t LR[QZK_LR_WORDS], DR[QZK_DR_WORDS];
+    for (int i = 0; i < QZK_LR_WORDS; i++) LR[i] = 0;
+    for (int i = 0; i < QZK_DR_WORDS; i++) DR[i] = 0;
+    qzk_dsyms DS; DS.w0 = DS.w1 = DS.w2 = 0;
 
     /* lane 0 only: the segment's result so far */
     uint32_t nel = 0, total_out = 0, blk_bits = 0;                  /* pieces, output bytes, length of the previous Huffman block */
     int seg_status = QZK_INF_ESPEC;                                 /* set to FINAL / FLUSH when the segment ends well */
     uint32_t why = 0;                                               /* developer aid: why the segment was handed back */
     bool seg_done = !live;                                          /* lane 0: nothing more to do for this segment */
+    uint32_t cont_at = 0; bool cont = false;                        /* lane 0: the block goes on at this bit (a lane on the chain ran out of scratch) */
+    uint32_t c_last = 0, c_lmax = 0, c_dmax = 0, c_lbase = 0;       /* ... with the tables it has */
 
-    for (;;) {
+    for (uint32_t round = 0;; round++) {
         /* ---- 1. lane 0: block headers and stored blocks up to the next Huffman block ---- */
-        if (j == 0) {
-            qzk_spec_hdr H; H.mode = 0; H.hdr_end = 0; H.span = 0; H.last = 0; H.lmax = 0; H.dmax = 0;
-            while (!seg_done && H.mode == 0) {
+        uint32_t h_mode = 0, h_end = 0, h_span = 0, h_last = 0, h_lmax = 0, h_dmax = 0, h_lbase = 0;
+        if (j == 0 && cont) {
+            /* the same block, from where the chain broke: no header, the tables stand; what is left is shared out again
+             * (the lane whose scratch is full stops at its first trip and is on nobody's chain) */
+            cont = false;
+            h_mode = 2; h_end = cont_at; h_last = c_last; h_lmax = c_lmax; h_dmax = c_dmax; h_lbase = c_lbase;
+            uint32_t share = limit_bits > cont_at ? limit_bits - cont_at : 0;
+            h_span = share > QZK_SPEC_MINBITS * K ? share / K : 0;
+        } else if (j == 0) {
+            while (!seg_done && h_mode == 0) {
                 S.op = total_out;
                 qzk_lane_header(&S, T, lroot, droot);
                 if (S.state == QZK_LS_RAW) {
                     /* stored block: nothing to decode - phase B copies it straight from the input */
-                    if (nel >= QZK_CHAIN_MAXEL) { seg_done = true; break; }
+                    if (nel >= QZK_CHAIN_MAXEL) { why = 20; seg_done = true; break; }
                     qzk_chain_el e; e.sub = QZK_PIECE_RAW; e.seq_first = S.rpos; e.seq_count = S.clen; e.lit_first = 0; e.lrun_skip = 0;
                     C->el[nel++] = e;
                     total_out += S.clen; S.clen = 0;
@@ -101,68 +135,103 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
                     else S.state = QZK_LS_HDR;
                 } else if (S.state == QZK_LS_SYM) {
                     const uint32_t at = 8u * S.b.pos - (uint32_t)S.b.bc;
-                    H.mode = 1; H.hdr_end = at; H.last = S.last; H.lmax = S.lmax; H.dmax = S.dmax;
+                    h_mode = 1; h_end = at; h_last = S.last; h_lmax = (uint32_t)S.lmax; h_dmax = (uint32_t)S.dmax; h_lbase = S.lbase;
                     /* what the group shares: the rest of the segment, or - from the second block on - a block as long as
                      * the previous one (zlib closes a block every 32767 symbols, so blocks of a segment are alike).
                      * Too little to share: span 0 parks the other lanes, lane 0 decodes alone */
                     uint32_t share = limit_bits > at ? limit_bits - at : 0;
                     /* more than 5 bits per output byte: mostly literals, the segment will take several 32767-symbol
                      * blocks - guess half of it for the first one */
+#ifndef QZK_SPEC_WHOLE
                     if (!blk_bits && (uint64_t)limit_bits > 5ull * sg.out_cap) blk_bits = share / 2;
+#endif
                     if (blk_bits && blk_bits + blk_bits / 8 < share) share = blk_bits + blk_bits / 8;
-                    H.span = share > QZK_SPEC_MINBITS * K ? share / K : 0;
+                    h_span = share > QZK_SPEC_MINBITS * K ? share / K : 0;
+#ifdef QZK_X_ALONE
+                    h_span = 0;
+#endif
                 } else if (S.state == QZK_LS_HDR) {
-                    /* an empty stored block in through-mode: next header */
-                } else {                                            /* DONE: FINAL / FLUSH, or an error for the serial kernel to name */
-                    if (S.status == QZK_INF_FINAL || S.status == QZK_INF_FLUSH) seg_status = S.status;
+                    /* an empty stored block that is not the flush marker: next header */
+                } else {                                            /* DONE: FINAL / FLUSH, or an error - lane 0 reads the true stream, so it is the segment's */
+                    seg_status = S.status;
                     seg_done = true;
                 }
             }
-            ghdr[g] = H;
         }
-        gnrec[lane] = 0;
-        qz_lds_sync();
-        const qzk_spec_hdr H = ghdr[g];
-        if (qz_ballot(H.mode != 0) == 0) break;                     /* every group of the wave has finished */
+        qz_wave_sync();                                             /* the tables (LDS) and their ranges (the segment's record) are the group's now */
+        h_mode = qz_shfl(h_mode, gbase); h_end = qz_shfl(h_end, gbase); h_span = qz_shfl(h_span, gbase); h_last = qz_shfl(h_last, gbase);
+        h_lmax = qz_shfl(h_lmax, gbase); h_dmax = qz_shfl(h_dmax, gbase); h_lbase = qz_shfl(h_lbase, gbase);
+        if (qz_ballot(h_mode != 0) == 0) break;                     /* every group of the wave has finished */
 
         /* ---- 2. the group decodes the block ---- */
-        bool active = H.mode != 0 && (j == 0 || H.span != 0);
-        if (active && j > 0) {                                      /* my guessed start */
-            const uint32_t at = H.hdr_end + (uint32_t)j * H.span;
-            qzk_lseek(&S.b, at >> 3);
-            qzk_lrefill(&S.b);
-            QZK_DROP(&S.b, at & 7);
-            S.last = H.last; S.lmax = H.lmax; S.dmax = H.dmax; S.op = 0;
+        bool active = h_mode != 0 && (j == 0 || h_span != 0);
+        if (active && (j > 0 || h_mode == 2)) {                     /* my guessed start (lane 0 stands behind the header, or goes to where the chain broke) */
+            const uint32_t at = h_end + (uint32_t)j * h_span;
+            if (j > 0 && (at + 64 >= limit_bits || (at >> 3) + 16 > S.b.end || QZK_NLIT(O) > lit_cap || O.nseq > seq_cap)) active = false;
+            else {
+                qzk_lseek(&S.b, at >> 3);
+                qzk_lrefill(&S.b);
+                QZK_DROP(&S.b, at & 7);
+                S.last = h_last; S.op = j == 0 ? total_out : 0;
+            }
         }
+        S.lmax = (int)h_lmax; S.dmax = (int)h_dmax; S.lbase = h_lbase;
+        if (h_mode != 0) { qzk_longtab_load(LR, DR, T, S.lmax, S.dmax); qzk_dsyms_load(&DS, T->dsorted, T->dcount); }
         S.state = QZK_LS_SYM;
-        /* a lane that started beyond the end of the block (the block was shorter than guessed) decodes garbage and never
-         * falls into step: it gives up shortly after its own share, lane 0 (always right) never does */
-        const uint32_t give_up = j == 0 || H.span == 0 ? 0xffffffffu
-                               : j == K - 1 ? H.hdr_end + ((uint32_t)K + 2) * H.span          /* the block may be longer than guessed */
-                               : H.hdr_end + ((uint32_t)j + 1) * H.span + H.span / QZK_SPEC_REACH;
-        uint32_t nsym = 0, target = H.span ? (uint32_t)j + 1 : (uint32_t)K, cursor = 0;
+        const uint32_t tag = (epoch << 6) | (round & 63u);
+        /* a lane that started beyond the end of the block (the block was shorter than guessed) or that never falls into
+         * step decodes garbage: the end of the segment's input stops it; lane 0 is always right */
+        const uint32_t give_up = j == 0 ? 0xffffffffu : limit_bits + 64;
+        /* whose trail I am looking at: `target` (none before my own share ends), its mark `cursor`, that mark's position
+         * `rp` (0xffffffff: none within sight) */
+        uint32_t target = (uint32_t)j, cursor = 0, rp = 0xffffffffu;
+        uint32_t wake = h_span != 0 && j + 1 < K ? h_end + ((uint32_t)j + 1) * h_span : 0xffffffffu;    /* the position at which I look at a trail next */
+        uint32_t ntrip = 0, ridx = 0;
         qzk_spec_stop st; st.kind = QZK_ST_RUN; st.target = 0; st.cidx = 0; st.at = 0;
-        st.nlit0 = QZK_NLIT(O) - O.lrun; st.nseq0 = O.nseq; st.lrun0 = 0; st.olen0 = S.op;   /* where my piece of this round starts */
+        st.nlit0 = QZK_NLIT(O) - O.lrun; st.nseq0 = O.nseq; st.olen0 = S.op;   /* where my piece of this round starts */
+        st.nlit = st.nseq = st.olen = 0;
 
-        /* what every symbol start does before the symbol: publish / look for the neighbour's footprint / watch the scratch */
-#define QZK_SPEC_PRE() do { \
+        /* What every trip start does before the trip.  Every trip: am I on the neighbour's mark (in step: stop), has a mark or
+         * the next lane's share come up (look at the trail), may the trip take literals behind its first symbol (`allow`: not
+         * within reach of a mark, where every symbol boundary must be a trip start).  On the trips that leave a mark - the
+         * lanes of a wave count their trips together, so this is a branch the wave takes as one - the mark is stored, the
+         * scratch and the end of the input are checked (with the margin of the trips in between) and a trail that was not
+         * written yet is looked at again.  The mark goes out BEFORE the trip's own two unconditional stores: the wait at the
+         * top of the loop counts those two, and a third store in front of them only makes it wait for an older one. */
+#define QZK_SPEC_PRE() \
         const uint32_t at_ = 8u * S.b.pos - (uint32_t)S.b.bc; \
-        if ((nsym % QZK_SPEC_EVERY) == 0 && nsym < QZK_SPEC_EVERY * QZK_SPEC_NREC) { \
-            const uint32_t k_ = nsym / QZK_SPEC_EVERY; \
-            qzk_rec r_; r_.nlit = QZK_NLIT(O); r_.nseq = O.nseq; r_.lrun = O.lrun; r_.olen = S.op; \
-            myrec[k_] = r_; gpos[lane][k_] = at_; gnrec[lane] = k_ + 1; \
+        const bool due_ = ntrip < QZK_SPEC_DENSE || (ntrip & (QZK_SPEC_EVERY - 1)) == 0; \
+        ntrip++; \
+        if (due_) { \
+            if (ridx + 1 < QZK_SPEC_NREC) { \
+                qzk_rec r_; r_.pos = at_; r_.nlit = QZK_NLIT(O); r_.nseq = O.nseq; r_.lrun = O.lrun; r_.olen = S.op; r_.tag = tag; r_.pad0 = r_.pad1 = 0; \
+                myrec[ridx++] = r_; \
+            } \
+            if (st.kind == QZK_ST_RUN && (QZK_NLIT(O) > lit_cap || O.nseq > seq_cap || at_ >= give_up)) { \
+                st.kind = QZK_ST_REDO; st.cidx = at_ >= give_up ? 1u : 2u; st.at = at_; } \
+            if (rp == 0xffffffffu && target != (uint32_t)j) wake = 0;           /* the neighbour may have written since */ \
         } \
-        nsym++; \
-        while (st.kind == QZK_ST_RUN && target < (uint32_t)K && at_ >= H.hdr_end + target * H.span) { \
-            const int tl_ = lane - j + (int)target; const uint32_t tn_ = gnrec[tl_]; \
-            while (cursor < tn_ && gpos[tl_][cursor] < at_) cursor++; \
-            if (cursor < tn_ && gpos[tl_][cursor] == at_) { st.kind = QZK_ST_SYNC; st.target = target; st.cidx = cursor; } \
-            else if (cursor >= tn_) { target++; cursor = 0; }       /* never fell into step: carry on to the next one */ \
-            else break; \
+        if (at_ >= wake) { \
+            while (h_span != 0 && target + 1 < (uint32_t)K && at_ >= h_end + (target + 1) * h_span) { target++; cursor = 0; } \
+            const uint32_t next_terr_ = h_span != 0 && target + 1 < (uint32_t)K ? h_end + (target + 1) * h_span : 0xffffffffu; \
+            rp = 0xffffffffu; \
+            bool again_ = false;                                    /* more marks to step over than one look takes: look again at the next trip */ \
+            if (target != (uint32_t)j) { \
+                again_ = true; \
+                for (int tries_ = 0; tries_ < 4; tries_++) { \
+                    const qzk_rec *q_ = recs + ((uint64_t)(sidx * K + target) * QZK_SPEC_NREC + cursor); \
+                    const uint32_t qp_ = qzk_ld32_l2(&q_->pos), qt_ = qzk_ld32_l2(&q_->tag); \
+                    if (qt_ != tag) { again_ = false; break; }     /* not written (yet): the neighbour has not got there, or has stopped */ \
+                    if (qp_ >= at_) { rp = qp_; again_ = false; break; } \
+                    if (cursor + 2 >= QZK_SPEC_NREC) { again_ = false; break; }    /* the trail ends here */ \
+                    cursor++; \
+                } \
+            } \
+            wake = again_ ? 0u : rp != 0xffffffffu && rp + 1 < next_terr_ ? rp + 1 : next_terr_; \
+            QZK_PIN(rp); QZK_PIN(wake); QZK_PIN(cursor);            /* the waits for the marks just read belong in here */ \
         } \
-        if (st.kind == QZK_ST_RUN && (QZK_NLIT(O) > lit_cap || O.nseq > seq_cap || at_ >= give_up)) { \
-            st.kind = QZK_ST_REDO; st.cidx = at_ >= give_up ? 1u : 2u; } \
-    } while (0)
+        if (st.kind == QZK_ST_RUN && at_ == rp) { st.kind = QZK_ST_SYNC; st.target = target; st.cidx = cursor; } \
+        const bool allow = rp - at_ > 56u;                          /* a mark within reach: one symbol a trip, so that no boundary is stepped over */
 
         while (qz_ballot(active) != 0) {
             if (active) {
@@ -170,14 +239,15 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
                 if (b->pos + 16 <= b->end) {
                     b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;
                     uint64_t pw = qzk_ld64u(b->p + b->pos);
-                    for (int trip = 0; trip < 256 && st.kind == QZK_ST_RUN && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
+                    /* the way into the loop carries the loop's own two stores (the wait at its top counts them) */
+                    ((uint64_t *)O.sq)[O.nseq] = 0; ((qz_u32u *)(O.lp + O.lw))->v = 0;
+                    for (int trip = 0; trip < QZK_TOK_TRIPS && st.kind == QZK_ST_RUN && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
                         QZK_SPEC_PRE();
                         if (st.kind == QZK_ST_RUN) {
                             b->bb |= pw << b->bc;
                             b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
                             pw = qzk_ld64u(b->p + b->pos);
-                            qzk_lane_symbol<false, false>(&S, &O, T, lroot, droot, (uint64_t)1 << 40);
-                            qzk_tok_round_flush(&O);        /* one symbol a trip here: whole words leave as they fill */
+                            qzk_lane_trip<QZK_LIT_RUN - 1>(&S, &O, T, lroot, droot, (uint64_t)1 << 40, LR, DR, &DS, allow);
                         }
                     }
                     b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;
@@ -187,10 +257,10 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
                 } else {
                     for (int trip = 0; trip < 64 && st.kind == QZK_ST_RUN && S.state == QZK_LS_SYM; trip++) {
                         QZK_SPEC_PRE();
+                        (void)allow;
                         if (st.kind == QZK_ST_RUN) {
                             qzk_lrefill(b);
                             qzk_lane_symbol<true, false>(&S, &O, T, lroot, droot, (uint64_t)1 << 40);
-                            qzk_tok_round_flush(&O);
                         }
                     }
                 }
@@ -198,58 +268,77 @@ QZ_KERNEL_MAX(64) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg 
                     /* END_BLOCK leaves HDR (or DONE with FINAL when the block was the last one); anything else is an error */
                     if (S.state == QZK_LS_HDR || (S.state == QZK_LS_DONE && S.status == QZK_INF_FINAL)) {
                         st.kind = QZK_ST_EOB; st.at = 8u * b->pos - (uint32_t)b->bc;
-                    } else { st.kind = QZK_ST_REDO; st.cidx = 3u; }
+                    } else { st.kind = QZK_ST_REDO; st.cidx = 3u; st.at = (uint32_t)S.status; }
                 }
                 if (st.kind != QZK_ST_RUN) {
                     if (O.lrun) qzk_tok_seq(&O, 0u, 0u);            /* my piece ends with its pending literals */
-                    qzk_tok_flush(&O);
                     st.nlit = QZK_NLIT(O); st.nseq = O.nseq; st.olen = S.op;
-                    gstop[lane] = st;
                     active = false;
                 }
             }
         }
 #undef QZK_SPEC_PRE
+#ifdef QZK_SPEC_STATS          /* emulator builds only (tools/spec_stats.py): trips of every lane and round */
+        if (live && round < 8) qzk_spec_stats[(sidx * K + (uint32_t)j) * 8 + round] = ntrip | st.kind << 28;
+#endif
         qz_wave_sync();
-        /* ---- 3. lane 0 walks the chain of this round ---- */
-        if (j == 0 && H.mode != 0) {
+        /* ---- 3. lane 0 walks the chain of this round; the stops of the lanes it visits come through cross-lane reads ---- */
+        {
             uint32_t cur = 0, c_nlit = 0, c_nseq = 0, c_lrun = 0, c_olen = 0;
-            bool from_rec = false, ok = false;
+            bool from_rec = false, ok = false, walking = j == 0 && h_mode != 0;
+            int bad_status = 0;
             for (int hop = 0; hop < K; hop++) {
-                const qzk_spec_stop s = gstop[lane + (int)cur];
-                if (s.kind != QZK_ST_SYNC && s.kind != QZK_ST_EOB) { why = 10 + s.cidx; break; }
-                if (nel >= QZK_CHAIN_MAXEL) { why = 20; break; }
+                const int src = gbase + (int)(cur < (uint32_t)K ? cur : 0u);
+                qzk_spec_stop s;
+                s.kind = qz_shfl(st.kind, src); s.target = qz_shfl(st.target, src); s.cidx = qz_shfl(st.cidx, src); s.at = qz_shfl(st.at, src);
+                s.nlit0 = qz_shfl(st.nlit0, src); s.nseq0 = qz_shfl(st.nseq0, src); s.olen0 = qz_shfl(st.olen0, src);
+                s.nlit = qz_shfl(st.nlit, src); s.nseq = qz_shfl(st.nseq, src); s.olen = qz_shfl(st.olen, src);
+                if (!walking) continue;
+                const bool broke = s.kind == QZK_ST_REDO && (s.cidx == 1u || s.cidx == 2u) && cur != 0;
+                if (s.kind != QZK_ST_SYNC && s.kind != QZK_ST_EOB && !broke) {
+                    /* a lane on the chain decodes the true stream: what stopped it (cidx 3: bad data, the end of the input, the
+                     * capacity) is the segment's own error; lane 0 out of scratch (its sub-stream holds a whole segment) or
+                     * anything else is this kernel's */
+                    why = 10 + s.cidx; walking = false;
+                    if (s.kind == QZK_ST_REDO && s.cidx == 3u) bad_status = (int)s.at;
+                    continue;
+                }
+                if (nel >= QZK_CHAIN_MAXEL) { why = 20; walking = false; continue; }
                 qzk_chain_el e; e.sub = cur;
                 if (from_rec) { e.seq_first = c_nseq; e.lit_first = c_nlit; e.lrun_skip = c_lrun; total_out += s.olen - c_olen; }
                 else { e.seq_first = s.nseq0; e.lit_first = s.nlit0; e.lrun_skip = 0; total_out += s.olen - s.olen0; }
                 e.seq_count = s.nseq - e.seq_first;
                 C->el[nel++] = e;
-                if (s.kind == QZK_ST_EOB) {
-                    ok = true; blk_bits = s.at - H.hdr_end;
-                    qzk_lseek(&S.b, s.at >> 3); qzk_lrefill(&S.b); QZK_DROP(&S.b, s.at & 7);   /* I carry on behind the block */
-                    if (H.last) { seg_status = QZK_INF_FINAL; seg_done = true; } else S.state = QZK_LS_HDR;
-                    break;
+                if (broke) {
+                    /* the lane's sub-stream is full (or it ran past the input it was told of): its piece stands, and the block
+                     * goes on from where it stopped in a round of its own - lane 0's sub-stream has room for all of it */
+                    ok = true; cont = true; cont_at = s.at;
+                    c_last = h_last; c_lmax = h_lmax; c_dmax = h_dmax; c_lbase = h_lbase;
+                    walking = false;
+                    continue;
                 }
-                const qzk_rec q = recs[((uint64_t)sidx * K + s.target) * QZK_SPEC_NREC + s.cidx];
-                cur = s.target; from_rec = true; c_nlit = q.nlit; c_nseq = q.nseq; c_lrun = q.lrun; c_olen = q.olen;
+                if (s.kind == QZK_ST_EOB) {
+                    ok = true; blk_bits = s.at - h_end;
+                    qzk_lseek(&S.b, s.at >> 3); qzk_lrefill(&S.b); QZK_DROP(&S.b, s.at & 7);   /* I carry on behind the block */
+                    if (h_last) { seg_status = QZK_INF_FINAL; seg_done = true; } else S.state = QZK_LS_HDR;
+                    walking = false;
+                    continue;
+                }
+                const qzk_rec *q = recs + ((uint64_t)(sidx * K + s.target) * QZK_SPEC_NREC + s.cidx);
+                cur = s.target; from_rec = true;
+                c_nlit = qzk_ld32_l2(&q->nlit); c_nseq = qzk_ld32_l2(&q->nseq); c_lrun = qzk_ld32_l2(&q->lrun); c_olen = qzk_ld32_l2(&q->olen);
             }
-            if (!ok) { seg_status = QZK_INF_ESPEC; seg_done = true; }
-            if (ok && total_out > sg.out_cap) { seg_status = QZK_INF_ESPEC; seg_done = true; why = 30; }   /* the serial kernel says EOUT */
+            if (j == 0 && h_mode != 0) {
+                if (!ok) { seg_status = bad_status < 0 ? bad_status : QZK_INF_ESPEC; seg_done = true; if (!why) why = 25; }
+                if (ok && total_out > sg.out_cap) { seg_status = QZK_INF_ESPEC; seg_done = true; why = 30; }   /* the serial kernel says EOUT */
+            }
         }
     }
     /* ---- lane 0: the segment's result ---- */
     if (live && j == 0) {
         qzk_infres r; r.status = seg_status; r.in_used = 0; r.out_len = 0; r.nblocks = S.nblocks;
-        if (seg_status >= 0) {
-            if (O.lrun && nel < QZK_CHAIN_MAXEL) {                  /* stored bytes at the very end: a piece of their own */
-                qzk_chain_el e; e.sub = 0; e.seq_first = O.nseq; e.seq_count = 1; e.lit_first = QZK_NLIT(O) - O.lrun; e.lrun_skip = 0;
-                C->el[nel++] = e;
-                qzk_tok_seq(&O, 0u, 0u);
-            } else if (O.lrun) r.status = QZK_INF_ESPEC;
-            qzk_tok_flush(&O);
-            r.in_used = S.b.pos - (uint32_t)(S.b.bc >> 3); r.out_len = total_out;
-        }
-        if (r.status < 0) { r.status = QZK_INF_ESPEC; nel = 0; r.nblocks = why ? why : 40; }
+        if (seg_status >= 0) { r.in_used = S.b.pos - (uint32_t)(S.b.bc >> 3); r.out_len = total_out; }
+        if (r.status < 0) { nel = 0; r.nblocks = why ? why : 40; }                 /* ESPEC: for the serial kernel; anything else: the segment's error */
         C->nel = nel; C->pad = 0;
         res[sidx] = r;
     }

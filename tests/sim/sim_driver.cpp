@@ -308,7 +308,7 @@ static void two_phase_serial(const uint8_t *comp, uint8_t *out, const qzk_infseg
     std::vector<qzk_seq> seqs(sqt + 8);
     /* 16 segments per workgroup; the emulator wants whole waves, the kernel bounds-checks */
     sim::launch((nsegs + 15) / 16, 64, 0, [&] {
-        if (threadIdx.x < 16) qzk_inflate_tok_kernel<16>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data());
+        if (threadIdx.x < 16) qzk_inflate_tok_kernel<16>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data(), nullptr, 0u, 1u);
     });
     /* phase B the way the host streams output: launches over index lists (here: the segments in reverse, two parts) */
     std::vector<uint32_t> ord(nsegs);
@@ -345,13 +345,15 @@ static int two_phase_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *s
     for (uint32_t i = 0; i < nsegs; i++)
         for (int j = 0; j < K; j++) {
             ts[(size_t)i * K + j].lit_off = lt; ts[(size_t)i * K + j].seq_off = sqt;
-            lt += QZK_SPEC_LITCAP(segs[i].out_cap, K); sqt += QZK_SPEC_SEQCAP(segs[i].out_cap, K);
+            lt += QZK_SPEC_LITCAP(segs[i].out_cap, K, j); sqt += QZK_SPEC_SEQCAP(segs[i].out_cap, K, j);
         }
     std::vector<uint8_t> lits(lt + 64, 0xee);
     std::vector<qzk_seq> seqs(sqt + 8);
     const uint32_t spw = 64 / K;
     sim::launch((nsegs + spw - 1) / spw, 64, 0, [&] {
-        qzk_inflate_spec_kernel<K>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data(), recs.data());
+        static uint32_t epoch = 0;
+        if (threadIdx.x == 0 && blockIdx.x == 0) epoch++;
+        qzk_inflate_spec_kernel<K>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data(), recs.data(), epoch + 1);
     });
     sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
         qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), (uint32_t)K, lits.data(), seqs.data(), chains.data(), nullptr, 0);
@@ -376,6 +378,9 @@ static int two_phase_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *s
 
 extern "C" {
 
+#ifdef QZK_SPEC_STATS
+uint32_t *sim_spec_stats() { return qzk_spec_stats; }
+#endif
 int sim_inflate_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs, int K)
 {
     if (K == 2) return two_phase_spec<2>(comp, out, segs, res, nsegs);

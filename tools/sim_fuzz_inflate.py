@@ -24,6 +24,14 @@ if not os.path.exists(so):
 S = C.CDLL(so)
 for f in (S.sim_inflate, S.sim_inflate_lane):
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+S.sim_inflate_spec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+handed_back = [0, 0]
+
+
+def spec(K):
+    def fn(comp, out, segs, res, n):
+        handed_back[0] += S.sim_inflate_spec(comp, out, segs, res, n, K); handed_back[1] += n
+    return fn
 seg_dt = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
 res_dt = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
 
@@ -68,7 +76,7 @@ while time.time() - t0 < budget:
         segs, io, oo = [], 0, 0
         for pc, k in zip(pieces, cuts):
             segs.append((io, oo, len(comp) - io, k, 0, len(pc))); io += len(pc); oo += k
-        for fn in (S.sim_inflate, S.sim_inflate_lane):
+        for fn in (S.sim_inflate, S.sim_inflate_lane, spec(rng.choice([2, 4, 8]))):
             got, res, tail = run(fn, comp, segs, n)
             ok &= got == src and bool((res["status"] >= 0).all()) and tail == b"\xaa" * 64
             ok &= [int(r["in_used"]) for r in res] == [len(pc) for pc in pieces]
@@ -77,4 +85,5 @@ while time.time() - t0 < budget:
     else:
         n_ok += 1
     seed += 1
-print("up to seed %d: %d ok, %d mismatches %s" % (seed - 1, n_ok, len(bad), bad))
+print("up to seed %d: %d ok, %d mismatches %s; K lanes per segment: %d of %d segments handed back to the serial kernel" %
+      (seed - 1, n_ok, len(bad), bad, handed_back[0], handed_back[1]))
