@@ -31,14 +31,13 @@
 #include "qzk_inflate_spec.h"
 #include "qzk_checksum.h"
 
-/* the two-phase path needs ~21 + 1-2 ms whatever the segment count up to one round of lanes (phase A is one lane's chain
- * through its segment), the wave kernel ~12-17 ms per round of up to 6144 resident segments (bound by the CUs' scalar
- * units): the two phases win from ~6200 segments on (round 3, 64 KB segments: 384 MiB 22.9 ms both ways, 512 MiB 22.8
- * against 27.3; round 2's phases, 26 + 12 ms, crossed at 10 500) */
-#define QZD_LANE_MIN_SEGS 6200u
-/* segments above 64 KB: a lane's chain grows with its segment, a wave's time by less - 8192 segments of 128 KB take
- * 54 ms with a wave each and 66 ms in two phases; round 2's crossover stays for them */
-#define QZD_LANE_MIN_SEGS_BIG 10500u
+/* Which kernel for how many segments (round 4, profiles/r4_inflate_crossover.txt; 64 KB segments of the bench data): one
+ * wave per segment (K3) takes ~12.5 ms for anything up to ~1000 segments and grows from there (17 ms at 4096, 27 at
+ * 8192: the CUs' scalar units); the two phases with four lanes per segment take 10-12 ms from 256 segments to 32768 (a
+ * lane's chain through its quarter of a segment) - they win from ~1000 segments on.  Segments of 128 KB: twice the chain,
+ * 24 ms either way at 2048 segments, 30 against 55 ms at 8192. */
+#define QZD_LANE_MIN_SEGS 1024u
+#define QZD_LANE_MIN_SEGS_BIG 2048u
 #define QZD_LANE_MIN(seg_bytes) ((seg_bytes) <= 65536u + 64u ? QZD_LANE_MIN_SEGS : QZD_LANE_MIN_SEGS_BIG)
 #define QZD_LANE_SEGS_PER_WAVE 16u
 /* lanes per segment of phase A (QATZIP_AMD_INFLATE_K = 1, 2, 4, 8 overrides; 1 = the serial phase A).  The LDS seats
@@ -60,8 +59,14 @@ static uint32_t spec_lanes(const qzk_infseg *hs, uint32_t nsegs)
 /* positions p (relative to d_src) such that src[p-4..p) == 00 00 FF FF.  A thread takes sixteen byte positions a trip:
  * five dwords (the last one for the three bytes that reach into the next piece), sixteen funnel shifts - a quarter of
  * the load instructions of one dword per position (0.74 -> ~0.3 ms for the 0.8 GB of a 2 GiB call). */
+#ifdef QZK_SPEC_PROF
+extern __device__ unsigned long long qzk_stamp[8];
+#endif
 __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list, uint32_t cap, uint32_t *count)
 {
+#ifdef QZK_SPEC_PROF
+    if ((threadIdx.x & 63) == 0) { atomicMin(&qzk_stamp[0], (unsigned long long)__builtin_amdgcn_s_memrealtime()); }
+#endif
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
     for (uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; b + 4 <= n; b += stride) {
         uint32_t d[5];
@@ -667,6 +672,36 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
     lap("chain check / rest");
     if (h_crc) { rc = qzd_crc32(c, d_dst, total_out, h_crc); lap("crc32"); return rc; }
     return QZD_OK;
+}
+
+#ifdef QZK_SPEC_PROF
+extern "C" int qzd_spec_prof(unsigned long long *out, uint32_t nwaves)
+{
+    static unsigned long long zero[8192][8];
+    if (!out) {                                                     /* reset */
+        unsigned long long st[8] = {~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0};
+        hipMemcpyToSymbol(HIP_SYMBOL(qzk_stamp), st, sizeof(st), 0, hipMemcpyHostToDevice);
+        hipMemcpyToSymbol(HIP_SYMBOL(qzk_stamp_b), st, 16, 0, hipMemcpyHostToDevice);
+        return hipMemcpyToSymbol(HIP_SYMBOL(qzk_spec_prof), zero, sizeof(zero), 0, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+    }
+    if (nwaves == 0xffffffffu) {
+        hipMemcpyFromSymbol(out, HIP_SYMBOL(qzk_stamp), 64, 0, hipMemcpyDeviceToHost);
+        return hipMemcpyFromSymbol(out + 4, HIP_SYMBOL(qzk_stamp_b), 16, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(qzk_spec_prof), (size_t)(nwaves < 8192 ? nwaves : 8192) * 64, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
+/* developer aid: resident workgroups per CU the runtime grants phase A's kernels */
+extern "C" int qzd_inflate_occupancy(int out[4])
+{
+    int a = -1, b = -1, c4 = -1, d = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, qzk_inflate_tok_kernel<16, QZD_TOK_OCC>, 16, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, qzk_inflate_spec_kernel<4>, 64, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&c4, qzk_inflate_spec_kernel<8>, 64, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, qzk_lz_resolve_kernel, 64 * QZK_RES_WAVES, 0);
+    out[0] = a; out[1] = b; out[2] = c4; out[3] = d;
+    return 0;
 }
 
 extern "C" int qzd_last_inflate_timing(qzd_ctx *c, float ms[4])

@@ -28,6 +28,12 @@
 #define QZK_INFLATE_LANE_H
 #include "qzk_inflate.h"
 
+#ifdef QZ_SIM
+#define QZK_PIN(x) ((void)0)
+#else
+#define QZK_PIN(x) asm volatile("" : "+v"(x))       /* the value is needed HERE: a pending load is waited for at this point */
+#endif
+
 /* root tables (the per-symbol lookups) live in LDS; the canonical ranges for longer codes and the code lengths
  * stay in a per-segment HBM record */
 #ifndef QZK_LLROOT
@@ -52,6 +58,12 @@
 #define QZK_LANE_ROOTSZ ((1 << QZK_LLROOT) + QZK_SIDE_BYTES / 2)
 #define QZK_DROOT8(droot) ((uint8_t *)(droot))
 #define QZK_LPOOL(droot) ((uint8_t *)(droot) + (1 << QZK_LDROOT))
+
+#ifdef QZ_SIM
+QZ_DEV uint32_t qzk_rev15(uint32_t v) { return qzk_rev(v & 0x7fffu, 15); }
+#else
+QZ_DEV uint32_t qzk_rev15(uint32_t v) { return __builtin_bitreverse32(v) >> 17; }      /* the low 15 bits, reversed */
+#endif
 
 typedef struct {
     uint16_t lsorted[288], dsorted[32];
@@ -159,11 +171,11 @@ typedef struct { uint64_t lit_off; uint64_t seq_off; } qzk_tokseg;             /
 #define QZK_INF_ESPEC (-6)         /* speculative phase A could not finish this segment: decode it serially */
 #define QZK_PIECE_RAW 0xffffffffu  /* qzk_chain_el.sub: not a sub-stream but seq_count stored bytes at input offset seq_first */
 typedef struct { uint32_t sub, seq_first, seq_count, lit_first, lrun_skip; } qzk_chain_el;
-#define QZK_CHAIN_MAXEL 24        /* pieces per segment (K per Huffman block of the segment) */
+#define QZK_CHAIN_MAXEL 40        /* pieces per segment (K per Huffman block of the segment, and per round that continues one) */
 typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chain;
 /* scratch a segment needs: literals <= out_cap (+ staging slack), sequences <= out_cap / 3 (+ tail) */
 #define QZK_TOK_LITCAP(out_cap) ((((uint64_t)(out_cap) + 31) & ~(uint64_t)31) + 32)
-#define QZK_TOK_SEQCAP(out_cap) ((uint64_t)(out_cap) / 3 + 2)
+#define QZK_TOK_SEQCAP(out_cap) (((uint64_t)(out_cap) / 3 + 3) & ~(uint64_t)1)      /* even: sequences leave in aligned pairs */
 
 enum { QZK_LS_HDR = 0, QZK_LS_SYM, QZK_LS_RAW, QZK_LS_DONE };
 #ifndef QZK_LIT_RUN
@@ -185,45 +197,51 @@ QZ_DEV int qzk_ldecode_long(qzk_lbits *b, int rootbits, const uint16_t *sorted, 
     return sym;
 }
 
-/* The literal/length codes longer than the root table, without a loop and without memory: for each length l the
- * canonical codes of that length are the interval [first[l], first[l] + count[l]) of the l leading bits read MSB first,
- * so a lane keeps the six intervals of l = 10..15 in registers (LR[0..5] = first | limit << 15, LR[6..8] = index - first,
- * two per word) and tests all of them on the next 15 bits at once; what is left is ONE load of the symbol from the
- * segment's sorted list.  (The ranges in the per-segment HBM record cost a lane two dependent loads per length tried -
- * and the fifteen other lanes of its wave wait with it: with rare long codes in every segment nearly every trip of a
- * wave had one.) */
-/* ROOT = bits of the root table; lengths ROOT+1 .. 15 => N = 15 - ROOT ranges in N + (N + 1) / 2 words */
-#define QZK_LT_WORDS(ROOT) ((15 - (ROOT)) + (16 - (ROOT)) / 2)
+/* The codes longer than the root table, without a loop and without memory.  Canonical codes read MSB first and
+ * left-justified to 15 bits are ordered by length: the codes of length l fill [limit(l - 1), limit(l)) with
+ * limit(l) = (first[l] + count[l]) << (15 - l).  So the length of the code in the next 15 bits V is ROOT + 1 + the number of
+ * limits at or below V, and its index in the sorted symbol list V >> (15 - l) plus index[l] - first[l].  A lane keeps, for
+ * the N = 15 - ROOT lengths above the root, one word each: limit << 16 | (index - first) & 0xffff - comparing
+ * V << 16 | 0xffff against the word is the comparison of V against the limit - so a long code costs a compare, an add with
+ * carry and a select per length (round 3 tested the N intervals one by one: three times the instructions, on a path some
+ * lane of a wave takes in nearly every trip).  V at or above the last limit is no code at all (incomplete sets). */
+#define QZK_LT_WORDS(ROOT) (15 - (ROOT))
 #define QZK_LR_WORDS QZK_LT_WORDS(QZK_LLROOT)
 #define QZK_DR_WORDS QZK_LT_WORDS(QZK_LDROOT)
 template <int ROOT>
 QZ_DEV void qzk_longtab_load_t(uint32_t *LR, const uint16_t *first_, const uint16_t *count_, const uint16_t *index_, int maxlen)
 {
     constexpr int N = 15 - ROOT;
+    (void)maxlen;
+#pragma unroll
     for (int k = 0; k < N; k++) {
         const int l = ROOT + 1 + k;
-        uint32_t first = 0, limit = 0, d = 0;
-        if (l <= maxlen) { first = first_[l]; limit = first + count_[l]; d = ((uint32_t)index_[l] - first) & 0xffffu; }
-        LR[k] = first | (limit << 15);
-        if (k & 1) LR[N + (k >> 1)] |= d << 16; else LR[N + (k >> 1)] = d;
+        const uint32_t first = first_[l], limit = (first + count_[l]) << (15 - l);
+        LR[k] = limit << 16 | (((uint32_t)index_[l] - first) & 0xffffu);
     }
 }
+/* (length, index in the sorted list) of the long code at the head of bb; length 0: no such code */
+template <int ROOT>
+QZ_DEV void qzk_long_interval(uint64_t bb, const uint32_t *LR, uint32_t *sel_l, uint32_t *sel_i)
+{
+    constexpr int N = 15 - ROOT;
+    const uint32_t V = qzk_rev15((uint32_t)bb), VH = V << 16 | 0xffffu;
+    uint32_t n = 0, w = LR[0];
+#pragma unroll
+    for (int k = 0; k < N - 1; k++) { const bool ge = VH >= LR[k]; n += ge ? 1u : 0u; w = ge ? LR[k + 1] : w; }
+    const uint32_t l = (uint32_t)ROOT + 1u + n;
+    *sel_l = VH >= LR[N - 1] ? 0u : l;
+    *sel_i = ((V >> (15u - l)) + w) & 0xffffu;
+}
 /* CHECKBC: the reader may hold fewer valid bits than the code is long (the careful reader at the end of the input; the hot
- * loop's trips start with >= 56).  Lengths above the block's longest code have an empty interval (qzk_longtab_load_t), so
- * they need no test of their own. */
+ * loop's trips start with >= 56) */
 template <int ROOT, bool CHECKBC = true>
 QZ_DEV int qzk_ldecode_long_reg_t(qzk_lbits *b, const uint32_t *LR, const uint16_t *sorted, int maxlen)
 {
-    constexpr int N = 15 - ROOT;
     (void)maxlen;
-    const uint32_t V = qzk_rev((uint32_t)b->bb & 0x7fffu, 15);
-    uint32_t sel_l = 0, sel_i = 0;
-    for (int k = N - 1; k >= 0; k--) {                          /* longest first: the shortest hit is kept */
-        const int l = ROOT + 1 + k;
-        const uint32_t first = LR[k] & 0x7fffu, limit = LR[k] >> 15, c = V >> (15 - l);
-        const uint32_t d = (LR[N + (k >> 1)] >> (16 * (k & 1))) & 0xffffu;
-        if ((!CHECKBC || l <= b->bc) && c >= first && c < limit) { sel_l = (uint32_t)l; sel_i = (c + d) & 0xffffu; }
-    }
+    uint32_t sel_l, sel_i;
+    qzk_long_interval<ROOT>(b->bb, LR, &sel_l, &sel_i);
+    if (CHECKBC && (int)sel_l > b->bc) sel_l = 0;
     int sym = -1;
     if (sel_l) { QZK_DROP(b, sel_l); sym = sorted[sel_i]; }
     return sym;
@@ -340,10 +358,24 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
 #ifndef QZK_TOK_TRIPS
 #define QZK_TOK_TRIPS 256           /* trips of the hot loop before the wave looks at its parked lanes again */
 #endif
+/* Round 4: a lane's tokens reach memory in ALIGNED 16-BYTE PIECES.  Round 3 stored what a trip decoded at once - a dword of
+ * literals, an 8-byte sequence - and read its input 8 unaligned bytes a trip: three scattered accesses per lane and trip,
+ * and the counters said that is what phase A was made of (TA busy 67 %, TD busy 85-91 % of the kernel's time, the vector
+ * ALUs a fifth; profiles/r4_phaseA_pmc.txt) - the texture path serves about one scattered lane-address in four cycles,
+ * whatever its size.  Now the literals of a trip go into a 16-byte register buffer that leaves as one dwordx4 store when it
+ * is full (every ~5 trips), sequences leave in pairs, the input comes through a register window refilled 16 aligned bytes
+ * at a time (qzk_win, every ~4.5 trips): 0.8 accesses per lane and trip instead of 3, paid for with ~60 ALU instructions.
+ * What is staged: the literal bytes [lw & ~15, lw) in l0..l3 (l4: what ran over into the next piece), the sequence of an
+ * odd count in q0.  qzk_tok_drain() stores what is complete; qzk_tok_finish() what is left. */
+typedef uint32_t qzk_u32x4 __attribute__((vector_size(16)));
 typedef struct {
     uint8_t *lp; qzk_seq *sq;
     uint32_t lrun, nseq;                /* literals since the last sequence, sequences so far */
     uint32_t lw;                        /* literal bytes so far */
+    uint32_t l0, l1, l2, l3, l4;        /* the literal piece being filled */
+    uint32_t lfull;                     /* 1: l0..l3 are a complete piece waiting to be stored (it begins at lw_piece) */
+    uint64_t q0, q1;                    /* the sequence pair being filled */
+    uint32_t qfull;                     /* 1: q0, q1 are a complete pair waiting to be stored (sequences nseq - 2, nseq - 1) */
     bool count_only;
 } qzk_tok_out;
 #define QZK_NLIT(O_) ((O_).lw)              /* literal bytes appended so far */
@@ -352,36 +384,145 @@ QZ_DEV void qzk_tok_init(qzk_tok_out *O, uint8_t *lp, qzk_seq *sq, bool count_on
 {
     O->lp = lp; O->sq = sq; O->count_only = count_only;
     O->lrun = 0; O->nseq = 0; O->lw = 0;
+    O->l0 = O->l1 = O->l2 = O->l3 = O->l4 = 0; O->lfull = 0; O->q0 = O->q1 = 0; O->qfull = 0;
 }
-/* append k (1..QZK_LIT_RUN) literals packed in v, lowest byte first, nothing above them */
-QZ_DEV void qzk_tok_lits(qzk_tok_out *O, uint64_t v, uint32_t k)
+/* store the complete pieces (the literal piece ends at the last 16-byte boundary at or below lw; the pair at nseq) */
+QZ_DEV void qzk_tok_drain(qzk_tok_out *O)
+{
+    if (O->lfull) {
+        qzk_u32x4 v; v[0] = O->l0; v[1] = O->l1; v[2] = O->l2; v[3] = O->l3;
+#ifndef QZK_X_NOMEM
+        *(qzk_u32x4 *)(O->lp + ((O->lw & ~15u) - 16u)) = v;
+#endif
+        O->l0 = O->l4; O->l1 = 0; O->l2 = 0; O->l3 = 0; O->l4 = 0; O->lfull = 0;
+    }
+    if (O->qfull) {
+        qzk_u32x4 v; v[0] = (uint32_t)O->q0; v[1] = (uint32_t)(O->q0 >> 32); v[2] = (uint32_t)O->q1; v[3] = (uint32_t)(O->q1 >> 32);
+#ifndef QZK_X_NOMEM
+        *(qzk_u32x4 *)((uint64_t *)O->sq + (O->nseq - 2u)) = v;
+#endif
+        O->qfull = 0;
+    }
+}
+/* append k (0..4) literals packed in v, lowest byte first, NOTHING above them; a piece that fills up waits in l0..l3 (lfull)
+ * for the next drain - so at most one append between two drains may cross a 16-byte boundary: the callers drain first */
+QZ_DEV void qzk_tok_lits4(qzk_tok_out *O, uint32_t v, uint32_t k)
 {
     if (!O->count_only) {
-        if (QZK_LIT_RUN > 4) qzk_st64u(O->lp + O->lw, v); else ((qz_u32u *)(O->lp + O->lw))->v = (uint32_t)v;
+        const uint32_t c = O->lw & 15u, di = c >> 2;
+        const uint64_t t = (uint64_t)v << (8u * (c & 3u));
+        const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+        O->l0 |= di == 0 ? lo : 0u;
+        O->l1 |= di == 1 ? lo : di == 0 ? hi : 0u;
+        O->l2 |= di == 2 ? lo : di == 1 ? hi : 0u;
+        O->l3 |= di == 3 ? lo : di == 2 ? hi : 0u;
+        O->l4 |= di == 3 ? hi : 0u;
+        O->lfull = c + k >= 16u ? 1u : O->lfull;
         O->lw += k;
     }
     O->lrun += k;
 }
+/* the general form: k (1..8) literals, any state of the staging (the cold paths: the careful reader, stored bytes) */
+QZ_DEV void qzk_tok_lits(qzk_tok_out *O, uint64_t v, uint32_t k)
+{
+    const uint32_t k0 = k < 4 ? k : 4;
+    qzk_tok_drain(O);
+    qzk_tok_lits4(O, (uint32_t)(k0 < 4 ? v & ((1ull << (8 * k0)) - 1) : v & 0xffffffffull), k0);
+    if (k > 4) { qzk_tok_drain(O); qzk_tok_lits4(O, (uint32_t)((v >> 32) & ((k < 8 ? 1ull << (8 * (k - 4)) : 1ull << 32) - 1)), k - 4); }
+}
 QZ_DEV void qzk_tok_byte(qzk_tok_out *O, uint32_t byte) { qzk_tok_lits(O, byte, 1); }
 /* append the low k (1..8) bytes of v */
-QZ_DEV void qzk_tok_bytes(qzk_tok_out *O, uint64_t v, uint32_t k)
+QZ_DEV void qzk_tok_bytes(qzk_tok_out *O, uint64_t v, uint32_t k) { qzk_tok_lits(O, v, k); }
+/* a sequence record (lrun literals, then a match; mlen 0: literals only), with the drain its pair may need first */
+QZ_DEV void qzk_tok_seq_rec(qzk_tok_out *O, uint64_t rec)
 {
-    if (!O->count_only) { qzk_st64u(O->lp + O->lw, v); O->lw += k; }
-    O->lrun += k;
+    if (!O->count_only) {
+        if (O->nseq & 1u) { O->q1 = rec; O->qfull = 1; } else O->q0 = rec;
+    }
+    O->nseq++; O->lrun = 0;
 }
 QZ_DEV void qzk_tok_seq(qzk_tok_out *O, uint32_t mlen, uint32_t dm1)
 {
-    if (!O->count_only) ((uint64_t *)O->sq)[O->nseq] = (uint64_t)O->lrun | (uint64_t)mlen << 32 | (uint64_t)dm1 << 48;
-    O->nseq++; O->lrun = 0;
+    qzk_tok_drain(O);
+    qzk_tok_seq_rec(O, (uint64_t)O->lrun | (uint64_t)mlen << 32 | (uint64_t)dm1 << 48);
 }
-/* everything is in memory as soon as it is appended: the round / flush points of the callers are kept as names */
 QZ_DEV void qzk_tok_round_flush(qzk_tok_out *O) { (void)O; }
-QZ_DEV void qzk_tok_flush(qzk_tok_out *O) { (void)O; }
+/* everything staged goes to memory (the staging stays valid: more may be appended afterwards) */
+QZ_DEV void qzk_tok_flush(qzk_tok_out *O)
+{
+    if (O->count_only) return;
+    qzk_tok_drain(O);
+    if (O->lw & 15u) { qzk_u32x4 v; v[0] = O->l0; v[1] = O->l1; v[2] = O->l2; v[3] = O->l3; *(qzk_u32x4 *)(O->lp + (O->lw & ~15u)) = v; }
+    if (O->nseq & 1u) ((uint64_t *)O->sq)[O->nseq - 1u] = O->q0;
+}
 
 QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
 {
     if (O->count_only) return;
     if (O->lrun) qzk_tok_seq(O, 0u, 0u);
+    qzk_tok_flush(O);
+}
+
+/* The input side of the same idea: a lane's next 32..48 bytes of input in registers.  w0..w7 hold the 32 bytes at `base` (a
+ * multiple of 16 from the lane's first aligned address), n0..n3 the 16 after them, asked for when the window last moved;
+ * the 8 bytes at any position in [base, base + 16) are three of w0..w5 and two funnel shifts.  qzk_win_step() moves the
+ * window when the position has left its first half: it reads n0..n3 (a load a whole window step old), and the load for the
+ * next step goes out LAST - behind the drain's stores - so that the wait in front of the read never meets anything younger
+ * than a trip.  (Named registers, not arrays: a select over an array becomes an indexed load from scratch.) */
+typedef struct { uint32_t w0, w1, w2, w3, w4, w5, w6, w7, n0, n1, n2, n3; uint32_t base; } qzk_win;
+QZ_DEV uint32_t qzk_win_edge(const uint8_t *p, int32_t q)       /* the dword at p + q, bytes before p read as zero */
+{
+    uint32_t v = 0;
+    for (int j = 0; j < 4; j++) if (q + j >= 0) v |= (uint32_t)p[q + j] << (8 * j);
+    return v;
+}
+QZ_DEV void qzk_win_init(qzk_win *W, const uint8_t *p, uint32_t pos)
+{
+    /* aligned to 16 in memory: (p + base) % 16 == 0, base <= pos < base + 16.  base may be "negative" (before p) by up to 15
+     * bytes: the buffers start well inside their allocation's first page only by luck, so the first piece is read bytewise
+     * where it would begin before p */
+    const uint32_t mis = (uint32_t)((uintptr_t)p & 15u);
+    const uint32_t base = ((pos + mis) & ~15u) - mis;           /* wraps below zero when pos + mis < 16 and mis != 0 */
+    W->base = base;
+    if ((int32_t)base < 0) {
+        W->w0 = qzk_win_edge(p, (int32_t)base); W->w1 = qzk_win_edge(p, (int32_t)base + 4);
+        W->w2 = qzk_win_edge(p, (int32_t)base + 8); W->w3 = qzk_win_edge(p, (int32_t)base + 12);
+    } else { const qzk_u32x4 a = *(const qzk_u32x4 *)(p + base); W->w0 = a[0]; W->w1 = a[1]; W->w2 = a[2]; W->w3 = a[3]; }
+    const qzk_u32x4 b = *(const qzk_u32x4 *)(p + (int32_t)base + 16), c = *(const qzk_u32x4 *)(p + (int32_t)base + 32);
+    W->w4 = b[0]; W->w5 = b[1]; W->w6 = b[2]; W->w7 = b[3];
+    W->n0 = c[0]; W->n1 = c[1]; W->n2 = c[2]; W->n3 = c[3];
+}
+/* move the window if pos has left its first half (returns whether: the caller issues the next load after its stores) */
+QZ_DEV bool qzk_win_step(qzk_win *W, uint32_t pos)
+{
+    const bool mv = pos - W->base >= 16u;
+    if (mv) {
+        W->w0 = W->w4; W->w1 = W->w5; W->w2 = W->w6; W->w3 = W->w7;
+        W->w4 = W->n0; W->w5 = W->n1; W->w6 = W->n2; W->w7 = W->n3;
+        W->base += 16u;
+    }
+    return mv;
+}
+QZ_DEV void qzk_win_load(qzk_win *W, const uint8_t *p, bool mv)
+{
+#ifdef QZK_X_NOMEM         /* timing experiments only: no memory traffic in the loop (the decode then runs on what the window held) */
+    (void)p; (void)mv;
+#else
+    if (mv) { const qzk_u32x4 c = *(const qzk_u32x4 *)(p + (int32_t)W->base + 32); W->n0 = c[0]; W->n1 = c[1]; W->n2 = c[2]; W->n3 = c[3]; }
+#endif
+}
+/* the 8 bytes at pos, base <= pos < base + 16 */
+QZ_DEV uint64_t qzk_win_get(const qzk_win *W, uint32_t pos)
+{
+    const uint32_t o = pos - W->base, d = o >> 2, sh = 8u * (o & 3u);
+    /* (pinned: a select over values the compiler can trace to one struct becomes an indexed load from a scratch copy) */
+    uint32_t x0 = W->w0, x1 = W->w1, x2 = W->w2, x3 = W->w3, x4 = W->w4, x5 = W->w5;
+    QZK_PIN(x0); QZK_PIN(x1); QZK_PIN(x2); QZK_PIN(x3); QZK_PIN(x4); QZK_PIN(x5);
+    const uint32_t a = d == 0 ? x0 : d == 1 ? x1 : d == 2 ? x2 : x3;
+    const uint32_t b = d == 0 ? x1 : d == 1 ? x2 : d == 2 ? x3 : x4;
+    const uint32_t c = d == 0 ? x2 : d == 1 ? x3 : d == 2 ? x4 : x5;
+    const uint64_t ab = (uint64_t)a | (uint64_t)b << 32, bc = (uint64_t)b | (uint64_t)c << 32;
+    return (uint64_t)(uint32_t)(ab >> sh) | (uint64_t)(uint32_t)(bc >> sh) << 32;
 }
 
 /* one symbol from an already refilled bit buffer; structured (no early exits) so that it compiles to predicated
@@ -462,11 +603,6 @@ QZ_DEV void qzk_lane_symbol(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T
  *   - selects instead of branches on the common path; what is rare (a long code, the end of a block, an error) sits in
  *     blocks the wave skips when no lane needs them.
  * Same tokens as qzk_lane_symbol<false, true> (the careful reader and the speculative decoders keep using that one). */
-#ifdef QZ_SIM
-#define QZK_PIN(x) ((void)0)
-#else
-#define QZK_PIN(x) asm volatile("" : "+v"(x))       /* the value is needed HERE: a pending load is waited for at this point */
-#endif
 typedef struct { uint64_t w0, w1, w2; } qzk_dsyms;       /* <= 30 distance symbols in canonical order, five bits each, twelve per word
                                                            * (named words, not an array: the compiler turns a select over an array
                                                            * into an indexed load from scratch) */
@@ -482,24 +618,6 @@ QZ_DEV void qzk_dsyms_load(qzk_dsyms *DS, const uint16_t *dsorted, const uint16_
     for (int l = 1; l <= 15; l++) n += dcount[l];
     if (n > 30) n = 30;
     DS->w0 = qzk_dsyms_word(dsorted, n, 0); DS->w1 = qzk_dsyms_word(dsorted, n, 1); DS->w2 = qzk_dsyms_word(dsorted, n, 2);
-}
-
-/* the long half of a code: (length, canonical index) from the register intervals; length 0 = no such code */
-template <int ROOT>
-QZ_DEV void qzk_long_interval(uint64_t bb, const uint32_t *LR, uint32_t *sel_l, uint32_t *sel_i)
-{
-    constexpr int N = 15 - ROOT;
-    const uint32_t V = qzk_rev((uint32_t)bb & 0x7fffu, 15);
-    uint32_t sl = 0, si = 0;
-#pragma unroll
-    for (int k = N - 1; k >= 0; k--) {                          /* longest first: the shortest hit is kept */
-        const int l = ROOT + 1 + k;
-        const uint32_t first = LR[k] & 0x7fffu, limit = LR[k] >> 15, c = V >> (15 - l);
-        const uint32_t d = (LR[N + (k >> 1)] >> (16 * (k & 1))) & 0xffffu;
-        const bool hit = c >= first && c < limit;
-        sl = hit ? (uint32_t)l : sl; si = hit ? ((c + d) & 0xffffu) : si;
-    }
-    *sel_l = sl; *sel_i = si;
 }
 
 template <int NX>      /* NX: literals a trip may take behind its first symbol (none when !allow: the speculative decoders near a mark) */
@@ -519,7 +637,10 @@ QZ_DEV void qzk_lane_trip(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, 
         if (sl != 0) {
             if (pr < (uint32_t)QZK_LPOOL_N && pv != 0xffu) sym = (int)pv;
             else { sym = T->lsorted[si]; QZK_PIN(sym); }       /* a long length code, END_BLOCK, a literal the pool has no room for;
-                                                                 * pinned: the wait for this load belongs in here, not where the paths meet */
+                                                                 * pinned: the wait for this load belongs in here, not where the paths meet.
+                                                                 * (Asking for it and sitting the trip out instead - the symbol at hand when
+                                                                 * the next trip begins - was measured: 4 % slower, the extra trips cost
+                                                                 * more than the wait) */
         }
     }
     bb >>= l; bc -= (int)l;
@@ -569,19 +690,15 @@ QZ_DEV void qzk_lane_trip(qzk_lane_st *S, qzk_tok_out *O, const qzk_inf_tab *T, 
         run = run && (e2 - 1u) < 4095u && (int)l2 <= bc && lk < room;
         const uint32_t take = run ? l2 : 0u;
         bb >>= take; bc -= (int)take;
-        if (NX > 3) { if (lk < 4) lv |= run ? (e2 >> 4) << (8 * lk) : 0u; else lv_hi |= run ? (uint64_t)(e2 >> 4) << (8 * lk) : 0ull; }
-        else lv |= run ? (e2 >> 4) << (8 * lk) : 0u;
+        lv |= run ? (e2 >> 4) << (8 * lk) : 0u;
         lk += run ? 1u : 0u;
     }
-    /* the trip's two stores, always both */
-#ifndef QZK_X_NOSEQ
-    ((uint64_t *)O->sq)[O->nseq] = rec;
-#endif
-    O->nseq += nrec; O->lrun = nrec ? 0u : O->lrun;
-#ifndef QZK_X_NOLIT
-    if (NX > 3) qzk_st64u(O->lp + O->lw, (uint64_t)lv | lv_hi); else ((qz_u32u *)(O->lp + O->lw))->v = lv;
-#endif
-    O->lw += lk; O->lrun += lk; S->op += lk;
+    /* the trip's tokens go into the staging (the caller drained it before the trip: one append may complete a piece) */
+    static_assert(NX <= 3, "a trip's literals are one dword of the staging");
+    (void)lv_hi;
+    if (nrec) qzk_tok_seq_rec(O, rec);
+    qzk_tok_lits4(O, lv, lk);
+    S->op += lk;
     S->b.bb = bb; S->b.bc = bc;
 }
 
@@ -624,23 +741,23 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
 
     while (S.state != QZK_LS_DONE) {
         qzk_lbits *b = &S.b;
-        if (S.state == QZK_LS_SYM && b->pos + 16 <= b->end && !O.count_only) {
-            /* ---- the hot loop.  Branch-free refill: the 8 bytes at the read position are always already in flight
-             * (pw), each trip ORs them in above the valid bits, steps over the bytes that fitted and issues the load
-             * for the next trip, whose latency the symbol decode then covers; >= 56 valid bits per trip is a whole
-             * symbol (15 + 5 + 15 + 13).  Bounded (QZK_TOK_TRIPS trips) so that lanes parked in a cold state - the next
-             * block's header - get their turn. ---- */
+        if (S.state == QZK_LS_SYM && b->pos + 64 <= b->end && !O.count_only) {
+            /* ---- the hot loop.  Every trip starts with the lane's memory traffic, such as it is: the input window moves on
+             * when the read position has left its first half (reading the 16 bytes asked for at the last move), the token
+             * pieces that are complete are stored, and the load for the window's next move goes out last - whatever a trip
+             * waits for is a whole trip old.  Then a branch-free refill: the 8 bytes at the read position come out of the
+             * window, are ORed in above the valid bits, the position steps over the bytes that fitted; >= 56 valid bits per
+             * trip is a whole symbol (15 + 5 + 15 + 13).  Bounded (QZK_TOK_TRIPS trips) so that lanes parked in a cold
+             * state - the next block's header - get their turn. ---- */
             b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;     /* hand whole bytes back */
-            uint64_t pw = qzk_ld64u(b->p + b->pos);
-            /* every trip ends with its two stores behind the load for the next one, so the top of the loop waits for all
-             * but the two newest memory operations - provided the way INTO the loop looks the same: two stores to the slots
-             * the first trip overwrites anyway */
-            ((uint64_t *)O.sq)[O.nseq] = 0; ((qz_u32u *)(O.lp + O.lw))->v = 0;
+            qzk_win W; qzk_win_init(&W, b->p, b->pos);
             const uint64_t hist = S.through ? sg.out_off : 0;
-            for (int trip = 0; trip < QZK_TOK_TRIPS && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
-                b->bb |= pw << b->bc;
+            for (int trip = 0; trip < QZK_TOK_TRIPS && S.state == QZK_LS_SYM && b->pos + 64 <= b->end; trip++) {
+                const bool mv = qzk_win_step(&W, b->pos);
+                qzk_tok_drain(&O);
+                qzk_win_load(&W, b->p, mv);
+                b->bb |= qzk_win_get(&W, b->pos) << b->bc;
                 b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
-                pw = qzk_ld64u(b->p + b->pos);
                 qzk_lane_trip<QZK_LIT_RUN - 1>(&S, &O, T, lroot, droot, hist, LR, DR, &DS);
 #ifdef QZK_INF_PROF
                 prof_trips++;
@@ -760,6 +877,9 @@ QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
     }
 }
 
+#ifdef QZK_SPEC_PROF
+__device__ unsigned long long qzk_stamp_b[2];
+#endif
 /* one wave per segment; QZK_RES_WAVES segments per workgroup (one: single-wave workgroups).  ts_stride sub-streams per segment (1 after the serial
  * phase A, K after the speculative one); the chain says which pieces of which sub-streams make up the segment.  The
  * output-dependent checks (capacity, history) live here because a speculative sub-decoder does not know its offset. */
@@ -784,7 +904,7 @@ QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
 #define QZK_RES_LIM 3072
 #endif
 #define QZK_RES_BUF (QZK_RES_LIM + 32)
-typedef uint32_t qzk_res_u32x4 __attribute__((vector_size(16)));
+typedef qzk_u32x4 qzk_res_u32x4;
 
 QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                 const qzk_tokseg *ts, uint32_t ts_stride, const uint8_t *lits, const qzk_seq *seqs,
@@ -793,6 +913,9 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8
     /* `order`: the launch covers `count` segments picked by index (a range of the OUTPUT, so that it can leave for the
      * host while the next range is resolved); NULL: all nsegs in array order */
     QZ_LDS __attribute__((aligned(16))) uint8_t obuf_all[QZK_RES_WAVES][QZK_RES_BUF];
+#ifdef QZK_SPEC_PROF
+    if ((threadIdx.x & 63) == 0) atomicMin(&qzk_stamp_b[0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     uint8_t *const ob = obuf_all[threadIdx.x >> 6];
     const int lane = qz_lane();
     const uint32_t widx = blockIdx.x * QZK_RES_WAVES + (threadIdx.x >> 6);

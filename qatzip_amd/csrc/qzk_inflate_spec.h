@@ -69,6 +69,16 @@ QZ_DEV uint32_t qzk_ld32_l2(const uint32_t *p) { return __hip_atomic_load(p, __A
 #ifdef QZK_SPEC_STATS
 static uint32_t qzk_spec_stats[1 << 20];
 #endif
+#ifdef QZK_SPEC_PROF           /* profiling builds only (tools/prof_spec.py): shader clocks of the hot loop's parts, per wave */
+__device__ unsigned long long qzk_spec_prof[8192][8];
+__device__ unsigned long long qzk_stamp[8];     /* wall-clock (100 MHz) first entry / last exit of: marker scan, phase A, phase B */
+#define QZK_STAMP_IN(k) do { if ((threadIdx.x & 63) == 0) atomicMin(&qzk_stamp[2 * (k)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#define QZK_STAMP_OUT(k) do { if ((threadIdx.x & 63) == 0) atomicMax(&qzk_stamp[2 * (k) + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#define QZK_PCLK() ((unsigned long long)__builtin_readcyclecounter())
+#define QZK_SPROF(k) do { const unsigned long long c_ = QZK_PCLK(); pacc[k] += c_ - pt; pt = c_; } while (0)
+#else
+#define QZK_SPROF(k) ((void)0)
+#endif
 template <int K>
 QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                   qzk_inf_tab *tabs, const qzk_tokseg *ts /* [nsegs * K] */, uint8_t *lits, qzk_seq *seqs,
@@ -76,6 +86,9 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
 {
     constexpr int SPW = 64 / K;                                     /* segments per wave */
     QZ_LDS uint16_t roots[SPW][QZK_LANE_ROOTSZ];
+#ifdef QZK_SPEC_PROF
+    QZK_STAMP_IN(1);
+#endif
 
     const int lane = (int)threadIdx.x, g = lane / K, j = lane % K, gbase = lane - j;
     const uint32_t sidx = blockIdx.x * SPW + (uint32_t)g;
@@ -97,7 +110,11 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
     qzk_tok_init(&O, lits + ts[slot].lit_off, seqs + ts[slot].seq_off, false);
     /* checked on the trips that leave a mark: the margin is what QZK_SPEC_EVERY trips can add */
     const uint32_t lit_cap = (uint32_t)QZK_SPEC_LITCAP(sg.out_cap, K, j) - 96 - QZK_SPEC_EVERY * 8, seq_cap = (uint32_t)QZK_SPEC_SEQCAP(sg.out_cap, K, j) - 10 - QZK_SPEC_EVERY;
-    const uint32_t limit_bits = 8u * (sg.pad != 0 && sg.pad < sg.in_len ? sg.pad : sg.in_len);
+    /* where the segment's input is taken to end: the host's hint (the next candidate's start), moved on by lane 0 when the
+     * decode gets there and the segment goes on - 00 00 FF FF inside a segment's own data cuts its hint short, and a lane 0
+     * left to decode the rest alone was a whole serial chain at the end of the launch (profiles/r4_phaseA_timeline.txt) */
+    const uint32_t end_bits = sg.in_len > 0x1fffffffu ? 0xffffffffu : 8u * sg.in_len;
+    uint32_t limit_bits = 8u * (sg.pad != 0 && sg.pad < sg.in_len ? sg.pad : sg.in_len);
     uint32_t LR[QZK_LR_WORDS], DR[QZK_DR_WORDS];
     for (int i = 0; i < QZK_LR_WORDS; i++) LR[i] = 0;
     for (int i = 0; i < QZK_DR_WORDS; i++) DR[i] = 0;
@@ -108,9 +125,13 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
     int seg_status = QZK_INF_ESPEC;                                 /* set to FINAL / FLUSH when the segment ends well */
     uint32_t why = 0;                                               /* developer aid: why the segment was handed back */
     bool seg_done = !live;                                          /* lane 0: nothing more to do for this segment */
-    uint32_t cont_at = 0; bool cont = false;                        /* lane 0: the block goes on at this bit (a lane on the chain ran out of scratch) */
+    uint32_t cont_at = 0; bool cont = false, cont_past = false;                        /* lane 0: the block goes on at this bit (a lane on the chain ran out of scratch) */
     uint32_t c_last = 0, c_lmax = 0, c_dmax = 0, c_lbase = 0;       /* ... with the tables it has */
 
+#ifdef QZK_SPEC_PROF
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = QZK_PCLK();
+    const unsigned long long p_begin = __builtin_amdgcn_s_memrealtime();       /* the 100 MHz clock every wave agrees on */
+#endif
     for (uint32_t round = 0;; round++) {
         /* ---- 1. lane 0: block headers and stored blocks up to the next Huffman block ---- */
         uint32_t h_mode = 0, h_end = 0, h_span = 0, h_last = 0, h_lmax = 0, h_dmax = 0, h_lbase = 0;
@@ -119,6 +140,10 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
              * (the lane whose scratch is full stops at its first trip and is on nobody's chain) */
             cont = false;
             h_mode = 2; h_end = cont_at; h_last = c_last; h_lmax = c_lmax; h_dmax = c_dmax; h_lbase = c_lbase;
+            if (cont_past) {                                        /* a lane on the chain ran past the hint: as much again as the segment has taken so far */
+                const uint32_t more = cont_at > 131072u ? cont_at : 131072u;      /* (16 KB at least: every round adds pieces) */
+                limit_bits = end_bits - cont_at > more ? cont_at + more : end_bits;
+            }
             uint32_t share = limit_bits > cont_at ? limit_bits - cont_at : 0;
             h_span = share > QZK_SPEC_MINBITS * K ? share / K : 0;
         } else if (j == 0) {
@@ -158,16 +183,18 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 }
             }
         }
+        QZK_SPROF(0);                                               /* [0] headers */
         qz_wave_sync();                                             /* the tables (LDS) and their ranges (the segment's record) are the group's now */
         h_mode = qz_shfl(h_mode, gbase); h_end = qz_shfl(h_end, gbase); h_span = qz_shfl(h_span, gbase); h_last = qz_shfl(h_last, gbase);
         h_lmax = qz_shfl(h_lmax, gbase); h_dmax = qz_shfl(h_dmax, gbase); h_lbase = qz_shfl(h_lbase, gbase);
+        limit_bits = qz_shfl(limit_bits, gbase);
         if (qz_ballot(h_mode != 0) == 0) break;                     /* every group of the wave has finished */
 
         /* ---- 2. the group decodes the block ---- */
         bool active = h_mode != 0 && (j == 0 || h_span != 0);
         if (active && (j > 0 || h_mode == 2)) {                     /* my guessed start (lane 0 stands behind the header, or goes to where the chain broke) */
             const uint32_t at = h_end + (uint32_t)j * h_span;
-            if (j > 0 && (at + 64 >= limit_bits || (at >> 3) + 16 > S.b.end || QZK_NLIT(O) > lit_cap || O.nseq > seq_cap)) active = false;
+            if (j > 0 && (at + 64 >= limit_bits || (at >> 3) + 64 > S.b.end || QZK_NLIT(O) > lit_cap || O.nseq > seq_cap)) active = false;
             else {
                 qzk_lseek(&S.b, at >> 3);
                 qzk_lrefill(&S.b);
@@ -178,10 +205,16 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
         S.lmax = (int)h_lmax; S.dmax = (int)h_dmax; S.lbase = h_lbase;
         if (h_mode != 0) { qzk_longtab_load(LR, DR, T, S.lmax, S.dmax); qzk_dsyms_load(&DS, T->dsorted, T->dcount); }
         S.state = QZK_LS_SYM;
+        QZK_SPROF(1);                                               /* [1] starts and tables */
         const uint32_t tag = (epoch << 6) | (round & 63u);
         /* a lane that started beyond the end of the block (the block was shorter than guessed) or that never falls into
          * step decodes garbage: the end of the segment's input stops it; lane 0 is always right */
         const uint32_t give_up = j == 0 ? 0xffffffffu : limit_bits + 64;
+        /* lane 0 knows where in the segment's output it stands, so a match that reaches back before the segment stops it at
+         * once (the others are checked by phase B).  It is what ends the decode of a candidate that is no segment - 00 00 FF FF
+         * inside compressed data: without it lane 0, which nothing else bounds, read garbage until 64 KB of output had come
+         * together, a whole serial chain begun when the launch was nearly over (profiles/r4_phaseA_timeline.txt: 8 of 23 ms) */
+        const uint64_t hist = j == 0 ? 0ull : (uint64_t)1 << 40;
         /* whose trail I am looking at: `target` (none before my own share ends), its mark `cursor`, that mark's position
          * `rp` (0xffffffff: none within sight) */
         uint32_t target = (uint32_t)j, cursor = 0, rp = 0xffffffffu;
@@ -200,7 +233,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
          * top of the loop counts those two, and a third store in front of them only makes it wait for an older one. */
 #define QZK_SPEC_PRE() \
         const uint32_t at_ = 8u * S.b.pos - (uint32_t)S.b.bc; \
-        const bool due_ = ntrip < QZK_SPEC_DENSE || (ntrip & (QZK_SPEC_EVERY - 1)) == 0; \
+        const bool due_ = ntrip < QZK_SPEC_DENSE || (ntrip & (QZK_SPEC_EVERY - 1)) == 0;    /* (the lanes of a wave count together) */ \
         ntrip++; \
         if (due_) { \
             if (ridx + 1 < QZK_SPEC_NREC) { \
@@ -236,20 +269,29 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
         while (qz_ballot(active) != 0) {
             if (active) {
                 qzk_lbits *b = &S.b;
-                if (b->pos + 16 <= b->end) {
+                if (b->pos + 64 <= b->end) {
                     b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;
-                    uint64_t pw = qzk_ld64u(b->p + b->pos);
-                    /* the way into the loop carries the loop's own two stores (the wait at its top counts them) */
-                    ((uint64_t *)O.sq)[O.nseq] = 0; ((qz_u32u *)(O.lp + O.lw))->v = 0;
-                    for (int trip = 0; trip < QZK_TOK_TRIPS && st.kind == QZK_ST_RUN && S.state == QZK_LS_SYM && b->pos + 16 <= b->end; trip++) {
+                    qzk_win W; qzk_win_init(&W, b->p, b->pos);
+#ifdef QZK_SPEC_PROF
+                    const unsigned long long pl0 = QZK_PCLK();
+#endif
+                    for (int trip = 0; trip < QZK_TOK_TRIPS && st.kind == QZK_ST_RUN && S.state == QZK_LS_SYM && b->pos + 64 <= b->end; trip++) {
+                        const bool mv = qzk_win_step(&W, b->pos);   /* the lane's memory traffic first (qzk_inflate_lane.h): window, pieces, next load */
+                        qzk_tok_drain(&O);
+                        qzk_win_load(&W, b->p, mv);
                         QZK_SPEC_PRE();
                         if (st.kind == QZK_ST_RUN) {
-                            b->bb |= pw << b->bc;
+                            b->bb |= qzk_win_get(&W, b->pos) << b->bc;
                             b->pos += (uint32_t)(63 - b->bc) >> 3; b->bc |= 56;
-                            pw = qzk_ld64u(b->p + b->pos);
-                            qzk_lane_trip<QZK_LIT_RUN - 1>(&S, &O, T, lroot, droot, (uint64_t)1 << 40, LR, DR, &DS, allow);
+                                qzk_lane_trip<QZK_LIT_RUN - 1>(&S, &O, T, lroot, droot, hist, LR, DR, &DS, allow);
+    #ifdef QZK_SPEC_PROF
+                            pacc[7]++;
+#endif
                         }
                     }
+#ifdef QZK_SPEC_PROF
+                    pacc[6] += QZK_PCLK() - pl0;                    /* this lane's clocks inside the hot loop */
+#endif
                     b->pos -= (uint32_t)(b->bc >> 3); b->bc &= 7; b->bb &= (1ull << b->bc) - 1;
                     const uint32_t keep = (uint32_t)b->bc; const uint64_t low = b->bb;
                     qzk_lseek(b, b->pos);
@@ -260,7 +302,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                         (void)allow;
                         if (st.kind == QZK_ST_RUN) {
                             qzk_lrefill(b);
-                            qzk_lane_symbol<true, false>(&S, &O, T, lroot, droot, (uint64_t)1 << 40);
+                            qzk_lane_symbol<true, false>(&S, &O, T, lroot, droot, hist);
                         }
                     }
                 }
@@ -278,6 +320,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
             }
         }
 #undef QZK_SPEC_PRE
+        QZK_SPROF(2);                                               /* [2] the decode phase of the round (to its slowest lane) */
 #ifdef QZK_SPEC_STATS          /* emulator builds only (tools/spec_stats.py): trips of every lane and round */
         if (live && round < 8) qzk_spec_stats[(sidx * K + (uint32_t)j) * 8 + round] = ntrip | st.kind << 28;
 #endif
@@ -312,7 +355,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 if (broke) {
                     /* the lane's sub-stream is full (or it ran past the input it was told of): its piece stands, and the block
                      * goes on from where it stopped in a round of its own - lane 0's sub-stream has room for all of it */
-                    ok = true; cont = true; cont_at = s.at;
+                    ok = true; cont = true; cont_at = s.at; cont_past = s.cidx == 1u;
                     c_last = h_last; c_lmax = h_lmax; c_dmax = h_dmax; c_lbase = h_lbase;
                     walking = false;
                     continue;
@@ -328,12 +371,25 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 cur = s.target; from_rec = true;
                 c_nlit = qzk_ld32_l2(&q->nlit); c_nseq = qzk_ld32_l2(&q->nseq); c_lrun = qzk_ld32_l2(&q->lrun); c_olen = qzk_ld32_l2(&q->olen);
             }
+            QZK_SPROF(3);
             if (j == 0 && h_mode != 0) {
                 if (!ok) { seg_status = bad_status < 0 ? bad_status : QZK_INF_ESPEC; seg_done = true; if (!why) why = 25; }
                 if (ok && total_out > sg.out_cap) { seg_status = QZK_INF_ESPEC; seg_done = true; why = 30; }   /* the serial kernel says EOUT */
             }
         }
     }
+    if (live) qzk_tok_flush(&O);                                    /* what my sub-stream still holds in registers */
+#ifdef QZK_SPEC_PROF
+    QZK_STAMP_OUT(1);
+    QZK_SPROF(3);                                                   /* [3] chain walks and the rest */
+    if (blockIdx.x < 8192) {
+        if (lane == 0) { for (int k = 0; k < 4; k++) qzk_spec_prof[blockIdx.x][k] = pacc[k];
+                         qzk_spec_prof[blockIdx.x][5] = p_begin << 32 | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull); }   /* begin | end */
+        atomicMax(&qzk_spec_prof[blockIdx.x][4], pacc[6]);          /* the lane longest in the hot loop: its clocks there ... */
+        atomicMax(&qzk_spec_prof[blockIdx.x][6], pacc[7]);          /* ... the most trips of a lane ... */
+        atomicAdd(&qzk_spec_prof[blockIdx.x][7], pacc[7]);          /* ... all lanes' trips */
+    }
+#endif
     /* ---- lane 0: the segment's result ---- */
     if (live && j == 0) {
         qzk_infres r; r.status = seg_status; r.in_used = 0; r.out_len = 0; r.nblocks = S.nblocks;

@@ -53,3 +53,14 @@ order = np.argsort(-serial)
 for i in order[:12]:
     print("  seg %3d comp %6d serial %6d -> %6d  rounds:" % (i, len(pieces[i]), serial[i], per_round_max[i]),
           " | ".join(" ".join("%d%s" % (trips[i, j, r], "RSEX"[kinds[i, j, r]]) for j in range(K)) for r in range(8) if trips[i, :, r].any()))
+
+# wave view: the host seats segments by compressed size, sixteen (64 / K) to a wave; a wave's rounds end with their slowest lane
+spw = 64 // K
+o = np.argsort(-np.array([len(p) >> 5 for p in pieces]), kind="stable")
+print("waves of %d segments, largest compressed first: trips = sum over rounds of the slowest lane of the wave" % spw)
+for w in range(0, NCH - spw + 1, spw):
+    ids = o[w:w + spw]
+    wt = trips[ids].max(axis=(0, 1)).sum()
+    print("  wave %2d: comp %6d..%6d  serial max %6d  wave trips %6d  (rounds %s)  best case (every segment alone) %6d" %
+          (w // spw, len(pieces[ids[-1]]), len(pieces[ids[0]]), serial[ids].max(), wt,
+           " ".join(str(int(x)) for x in trips[ids].max(axis=(0, 1)) if x), per_round_max[ids].max()))
