@@ -223,8 +223,10 @@ uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 /* the same folded over the per-chunk CRC-32s of an n-byte buffer cut every chunk_sz bytes (host arrays) */
 uint32_t qzd_crc32_fold(const uint32_t *h_crc, uint32_t nchunks, uint32_t chunk_sz, uint64_t n);
 
-/* GPU time (ms) of the last qzd_inflate_stream call: [0] inflate kernels, [1] crc kernels, [2] the part of [0]
- * spent in the match-resolve phase of the two-phase path (0 on the wave-per-segment path), [3] reserved (0) */
+/* GPU time (ms) of the last qzd_inflate_stream call: [0] the inflate step, first launch to last (on the two-phase path the
+ * host's walk through phase A's results lies inside it), [1] crc kernels, [2] phase B of the two-phase path (the
+ * match-resolve kernel; 0 on the wave-per-segment path), [3] phase A (the Huffman-decoding kernel, with the launch for any
+ * segment handed back to the one-lane kernel; 0 on the wave-per-segment path) */
 int qzd_last_inflate_timing(qzd_ctx *ctx, float ms[4]);
 
 #ifdef __cplusplus

@@ -44,9 +44,13 @@
  * sixteen segments' tables per wave, so four lanes per segment fill the wave: the lanes share the tables, start at evenly
  * spaced bits and fall into step with each other (qzk_inflate_spec.h) */
 #define QZD_SPEC_LANES 4u
+/* up to half a launch of four-lane waves (1024 of them, one per SIMD) the phase ends with its longest chain, and eight lanes
+ * per segment make that a tenth shorter (profiles/r4_inflate_crossover.txt); a full chip is better served by four */
+#define QZD_SPEC_LANES_FEW 8u
+#define QZD_SPEC_FEW_SEGS 16384u
 static uint32_t spec_lanes(const qzk_infseg *hs, uint32_t nsegs)
 {
-    uint32_t K = QZD_SPEC_LANES;
+    uint32_t K = nsegs <= QZD_SPEC_FEW_SEGS ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
     const char *ke = getenv("QATZIP_AMD_INFLATE_K");
     if (ke) { int v = atoi(ke); if (v == 1 || v == 2 || v == 4 || v == 8) K = (uint32_t)v; }
     /* it needs a compressed-length hint (qzk_infseg.pad) and segments that write output and begin with no history */
@@ -204,6 +208,8 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         HIPCHK(c, hipStreamSynchronize(st));
         HIPCHK(c, hipGetLastError());
         memcpy(h_res, st_res, rb);
+        float ta = 0;
+        if (hipEventElapsedTime(&ta, c->ev[1][1], c->ev[1][0]) == hipSuccess) c->inf_ms[3] += ta;   /* phase A's kernel(s) */
         return QZD_OK;
     }
     if (stream_out) { memcpy(st_ord, c->so_nat, (size_t)nsegs * 4); HIPCHK(c, hipMemcpyAsync(ord_d, st_ord, (size_t)nsegs * 4, hipMemcpyHostToDevice, st)); }
@@ -240,6 +246,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     memcpy(h_res, st_res, rb);
     float t = 0;
     if (hipEventElapsedTime(&t, c->ev[1][0], c->ev[1][2]) == hipSuccess) c->inf_ms[2] += t;     /* phase B share */
+    if (hipEventElapsedTime(&t, c->ev[1][1], c->ev[1][0]) == hipSuccess) c->inf_ms[3] += t;     /* phase A's kernel(s) */
     return QZD_OK;
 }
 
@@ -501,7 +508,7 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
     if (!c || !d_src || !h_in_used || !h_out_len) return QZD_ERR_PARAM;
     if (n == 0 || n > 0xffffffffull) return QZD_ERR_PARAM;
     hipSetDevice(c->device);
-    c->inf_ms[0] = c->inf_ms[1] = c->inf_ms[2] = 0;
+    c->inf_ms[0] = c->inf_ms[1] = c->inf_ms[2] = c->inf_ms[3] = 0;
     *h_in_used = 0; *h_out_len = 0;
     /* QATZIP_AMD_TRACE=1: wall-clock of the host-side steps on stderr (developer aid) */
     static const bool trace = getenv("QATZIP_AMD_TRACE") != NULL;
@@ -707,6 +714,6 @@ extern "C" int qzd_inflate_occupancy(int out[4])
 extern "C" int qzd_last_inflate_timing(qzd_ctx *c, float ms[4])
 {
     if (!c || !ms) return QZD_ERR_PARAM;
-    ms[0] = c->inf_ms[0]; ms[1] = c->inf_ms[1]; ms[2] = c->inf_ms[2]; ms[3] = 0;
+    ms[0] = c->inf_ms[0]; ms[1] = c->inf_ms[1]; ms[2] = c->inf_ms[2]; ms[3] = c->inf_ms[3];
     return QZD_OK;
 }

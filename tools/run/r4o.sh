@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+export PYTHONPATH=$GRAFT_REPO_ROOT
+for k in 8; do
+  QATZIP_AMD_TRACE=1 QATZIP_AMD_INFLATE_K=$k timeout 90 python tools/inflate_var_run.py 4096:64 2048:64 1024:64 1024:128 1024:16 64:64 2>&1 | grep -v "qzd_inflate_stream" | sort | uniq -c | sort -rn | sed "s/default  */K=$k  /"
+done
