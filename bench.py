@@ -348,74 +348,121 @@ def view(qz, buf, off, n):
     return v
 
 
-def one_stream_leg(ctx, qz, pg, rank, world, d_src, shard_mb, steps):
-    """config 5's shape, timed: every rank deflates ONE shard of a logical buffer (shard_mb MiB each: 8 ranks x 511 MiB is
-    the largest member gzip-ext holds), the compressed shards travel to rank 0's HBM, rank 0 folds the CRCs and closes
-    the member - `steps` members per transport, max-over-ranks time between barriers.  Both transports are measured
-    (IPC window with peer copies / RCCL send-recv group) and the faster one is the leg's headline; a transport that cannot
-    start on this box reports its error instead.  Rank 0 checks every member's header and trailer against the ranks' own
-    CPU CRC-32s and a prefix of its payload against the oracle (outside the timed loop)."""
+def one_stream_leg(ctx, qz, pg, rank, world, d_src, slice_mb, members, steps):
+    """BASELINE config 5 as written, timed: a logical buffer of `members` x (world x slice_mb MiB) - 16 members of 8 x 511 MiB
+    = 64 GB on an 8-GPU node; a gzip-ext header describes less than 4 GiB, so the buffer is a SEQUENCE of members - dealt to
+    the ranks like a striped volume (shard.member_plan).  Every member is built by all ranks: each deflates its shard on its
+    GPU, the compressed shards travel to rank 0's HBM, rank 0 folds the CRCs, closes the member and appends it to the output;
+    member m + 1 is deflated while member m's shards are on the wire (shard.OneStream.run_members: the transport has its
+    own context and thread, two staging buffers).  `steps` passes per transport between barriers, max-over-ranks time,
+    deflate included.  Both transports are measured (IPC window with peer copies / RCCL all-gather + send-recv group) and the
+    faster one is the leg's headline; a transport that cannot start on this box reports its error (and RCCL's own log)
+    instead.  Rank 0 checks, outside the timed loop: every member's header and trailer against the plan and against the
+    ranks' own CPU CRC-32s of member 0, and a prefix of member 0's payload against the oracle."""
     import zlib
     from qatzip_amd import shard
     # the ranks of this leg share one node by contract: RCCL's bootstrap sockets may use the loopback interface (the
     # container's hostname need not resolve); a launcher that knows better sets the variable itself
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-    n = shard_mb << 20
-    src = view(qz, d_src, 0, n)
-    host = d_src.download(n) if n <= (1 << 30) else None
+    rccl_log = "/tmp/qatzip_amd_rccl_%d.log" % os.getpid()
+    os.environ.setdefault("NCCL_DEBUG", "WARN"); os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+    sl = slice_mb << 20
+    total = members * world * sl
+    plan = shard.member_plan(total, world, CHUNK, sl)
+    mine = shard.local_offsets(plan, rank)
+    need = sum(n for _, n in mine)
+    # this rank's shards, back to back: the bench buffer, repeated when the plan is longer than it (synthetic either way)
+    if need <= d_src.nbytes:
+        src = view(qz, d_src, 0, need)
+        own = None
+    else:
+        own = src = ctx.alloc(need)
+        for off in range(0, need, d_src.nbytes):
+            ctx._chk(ctx.L.qzd_d2d(ctx.h, src.ptr + off, d_src.ptr, min(d_src.nbytes, need - off)))
+    n0 = mine[0][1]
+    host = src.download(n0) if n0 <= (1 << 30) else None
     my_crc = zlib.crc32(host.tobytes()) & 0xffffffff if host is not None else 0
-    out = {"ranks": world, "shard_MiB": shard_mb, "member_raw_MiB": shard_mb * world, "steps": steps}
+    out = {"ranks": world, "members": len(plan), "slice_MiB": slice_mb, "member_raw_MiB": world * slice_mb,
+           "buffer_GB": round(total / 1e9, 2), "steps": steps}
+    d_out = ctx.alloc(total // 2 + (1 << 26)) if rank == 0 else None      # the bench data compresses to < 0.4: half is room enough
     best = None
     for transport in ("ipc", "rccl"):
         try:
-            one = shard.OneStream(ctx, pg, rank, world, n, CHUNK, 1, transport)
+            one = shard.OneStream(ctx, pg, rank, world, sl, CHUNK, 1, transport)
             if one.error:
                 out[transport] = {"error": one.error[:200]}
                 continue
-            r = one.run(src, want_member=True)                       # warm-up + the member that is checked
+            r = one.run_members(src, plan, d_out)                    # warm-up + the pass that is checked
             if "error" in r:
                 out[transport] = {"error": r["error"][:200]}
                 one.close()
                 continue
-            recs = shard.all_gather_records(pg, shard.pack_record(n, r["comp_len"], my_crc), world) if world > 1 else [(n, r["comp_len"], my_crc)]
+            recs = shard.all_gather_records(pg, shard.pack_record(n0, 0, my_crc), world) if world > 1 else [(n0, 0, my_crc)]
             verified = None
             if rank == 0:
-                mb = r["stream"]
-                verified = shard.member_is_consistent(mb, recs)
-                if verified and host is not None:
-                    import oracle_lib as O
-                    k = min(n, 4 << 20) // CHUNK * CHUNK
-                    exp = O.sw_compress("RAW", host[:k].tobytes(), CHUNK, 1, last=0 if (world > 1 or k < n) else 1, cap=k * 9 // 8 + 65536)[2]
-                    verified = mb[24:24 + len(exp)] == exp
+                verified = r["raw_bytes"] == total and len(r["member_bytes"]) == len(plan)
+                pos = 0
+                for m, mb_len in enumerate(r["member_bytes"]):         # every member: header sizes and ISIZE against the plan
+                    raw_m = sum(n for _, n in plan[m])
+                    hdr = d_out.download(24, pos).tobytes(); tr = d_out.download(8, pos + mb_len - 8).tobytes()
+                    verified = verified and hdr[:4] == b"\x1f\x8b\x08\x04" and hdr[12:14] == b"QZ" and \
+                        int.from_bytes(hdr[16:20], "little") == raw_m and int.from_bytes(hdr[20:24], "little") == mb_len - 32 and \
+                        int.from_bytes(tr[4:], "little") == raw_m & 0xffffffff
+                    if m == 0 and host is not None:                    # member 0: its CRC-32 from the ranks' own, a prefix against the oracle
+                        crc = 0
+                        for i, (rl, _, c) in enumerate(recs):
+                            crc = c if i == 0 else shard.crc32_combine(crc, c, rl)
+                        verified = verified and int.from_bytes(tr[:4], "little") == crc
+                        import oracle_lib as O
+                        k = min(n0, 4 << 20) // CHUNK * CHUNK
+                        exp = O.sw_compress("RAW", host[:k].tobytes(), CHUNK, 1, last=0 if (world > 1 or k < n0) else 1, cap=k * 9 // 8 + 65536)[2]
+                        verified = verified and d_out.download(len(exp), 24).tobytes() == exp
+                    pos += mb_len
             barrier(pg)
             t0 = time.perf_counter()
-            tg = 0.0
+            tg = td = tov = 0.0
             ok = True
             for _ in range(steps):
-                r2 = one.run(src)
+                r2 = one.run_members(src, plan, d_out)
                 ok = ok and "error" not in r2
-                tg += r2.get("gather_ms", 0.0)
+                tg += r2.get("gather_ms", 0.0); td += r2.get("deflate_ms", 0.0); tov += r2.get("overlapped_ms", 0.0)
             barrier(pg)
             dt = allreduce(pg, time.perf_counter() - t0, "MAX")
-            tg = allreduce(pg, tg, "MAX")
+            tg = allreduce(pg, tg, "MAX"); tov = allreduce(pg, tov, "MAX"); td = allreduce(pg, td, "MAX")
             one.close()
             if not ok:
                 out[transport] = {"error": "a member of the timed loop failed"}
                 continue
-            res = {"GBps": round(world * n * steps / dt / 1e9, 3), "ms_per_member": round(dt / steps * 1e3, 2),
-                   "gather_ms_per_member": round(tg / steps, 2), "gather_share": round(tg / steps / (dt / steps * 1e3), 3)}
+            res = {"GBps": round(total * steps / dt / 1e9, 3), "ms_per_pass": round(dt / steps * 1e3, 2),
+                   "ms_per_member": round(dt / steps / len(plan) * 1e3, 2), "deflate_ms_per_member": round(td / steps / len(plan), 2),
+                   "gather_ms_per_member": round(tg / steps / len(plan), 2),
+                   "gather_ms_beside_a_deflate_per_member": round(tov / steps / len(plan), 2),
+                   "gather_share": round(max(0.0, tg - tov) / steps / (dt / steps * 1e3), 3)}
             if rank == 0:
-                res.update({"member_bytes": r["member_bytes"], "crc32": r["crc32"], "verified": bool(verified)})
+                res.update({"out_bytes": r["out_bytes"], "verified": bool(verified)})
             out[transport] = res
             if best is None or res["GBps"] > out[best]["GBps"]:
                 best = transport
         except Exception as e:   # noqa: BLE001 - a transport that does not work here must not cost the other one
             out[transport] = {"error": repr(e)[:200]}
+        if transport == "rccl" and "error" in out.get("rccl", {}):
+            try:                                                     # what RCCL itself had to say (NCCL_DEBUG=WARN into a file of ours)
+                with open(os.environ.get("NCCL_DEBUG_FILE", rccl_log)) as f:
+                    lines = [ln.strip() for ln in f if ln.strip()]
+                out["rccl"]["rccl_log"] = " | ".join(lines[-3:])[:400]
+            except OSError:
+                pass
     out["transport"] = best
     if best:
         out["GBps"] = out[best]["GBps"]
+        out["overlapped"] = out[best]["gather_ms_beside_a_deflate_per_member"] > 0
     out["note"] = ("ipc = peer copies into an IPC window in rank 0's HBM (xGMI between GPUs); rccl = ncclAllGather of the records + "
-                   "ncclSend/ncclRecv group; uncompressed bytes of the member / max-over-ranks time, deflate included")
+                   "ncclSend/ncclRecv group; uncompressed bytes of all members / max-over-ranks time, deflate included; "
+                   "gather_share = the part of a pass its gathers take that no deflate ran beside")
+    if own is not None:
+        own.free()
+    if d_out is not None:
+        d_out.free()
     return out
 
 
@@ -434,6 +481,7 @@ def main():
     ap.add_argument("--extra-mb", type=int, default=1024, help="bytes of the extra legs, MiB")
     ap.add_argument("--api-mb", type=int, default=2047, help="bytes of the one qzCompress / qzDecompress call of the API leg, MiB "
                     "(qatzip.h lengths are 32-bit)")
+    ap.add_argument("--members", type=int, default=0, help="members of the one-stream leg (multi-rank runs; default 16 from 8 ranks on, else 4)")
     ap.add_argument("--no-probe", action="store_true", help="skip the lone 12288-chunk K1 launch after the timed region "
                     "(the rocprofv3 --pmc passes: every K1 launch of the run is then a whole 2 GiB call)")
     args = ap.parse_args()
@@ -525,13 +573,18 @@ def main():
 
             def leg():
                 try:
-                    # 8 ranks x 511 MiB: the largest member a gzip-ext header can describe (both sizes are 32-bit)
-                    box["one"] = one_stream_leg(ctx, qatzip_amd, pg, rank, world, d_src, min(512, 4095 // world, args.mb), max(1, args.steps))
+                    # 8 ranks x 511 MiB: the largest member a gzip-ext header can describe (both sizes are 32-bit); sixteen of
+                    # them are BASELINE config 5's 64 GB.  Fewer ranks (a one-GPU box exercising the path): four members.
+                    for d in d_comp:
+                        d.free()
+                    d_back.free()
+                    members = args.members or (16 if world >= 8 else 4)
+                    box["one"] = one_stream_leg(ctx, qatzip_amd, pg, rank, world, d_src, min(511, 4095 // world, args.mb), members, max(1, args.steps))
                 except Exception as e:   # noqa: BLE001 - the headline must survive a box without peer access
                     box["one"] = {"error": str(e)[:200]}
             th = threading.Thread(target=leg, daemon=True)
             th.start()
-            th.join(float(os.environ.get("QATZIP_AMD_BENCH_LEG_TIMEOUT", "150")))
+            th.join(float(os.environ.get("QATZIP_AMD_BENCH_LEG_TIMEOUT", "240")))
             if th.is_alive():
                 one = {"error": "the one-member leg did not finish in time on rank %d (a transport is waiting for a rank that is not coming)" % rank}
                 hard_exit = True

@@ -55,6 +55,7 @@ void *qzd_dev_alloc(qzd_ctx *ctx, size_t n);
 void qzd_dev_free(qzd_ctx *ctx, void *d_p);
 int qzd_h2d(qzd_ctx *ctx, void *d_dst, const void *h_src, size_t n);
 int qzd_d2h(qzd_ctx *ctx, void *h_dst, const void *d_src, size_t n);
+int qzd_d2d(qzd_ctx *ctx, void *d_dst, const void *d_src, size_t n);      /* on the context's copy stream; returns when done */
 void *qzd_host_alloc_pinned(size_t n);
 void qzd_host_free_pinned(void *p);
 

@@ -51,6 +51,7 @@ def load(build_if_missing=True):
     L.qzd_crc32.argtypes = [vp, u8p, C.c_uint64, C.POINTER(C.c_uint32)]
     L.qzd_crc32_ranges.argtypes = [vp, u8p, vp, C.c_uint32, vp]
     L.qzd_last_inflate_timing.argtypes = [vp, C.POINTER(C.c_float * 4)]
+    L.qzd_d2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.qzd_lz4_compress_frames.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
     L.qzd_lz4_compress_frames_hw.argtypes = L.qzd_lz4_compress_frames.argtypes
     L.qzd_lz4_compress_linked.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]

@@ -315,6 +315,15 @@ extern "C" int qzd_d2h(qzd_ctx *c, void *h, const void *d, size_t n)
     HIPCHK(c, hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
     return QZD_OK;
 }
+/* device to device, within the context's GPU (or from a peer's memory it can reach); returns when the copy is done */
+extern "C" int qzd_d2d(qzd_ctx *c, void *d_dst, const void *d_src, size_t n)
+{
+    if (!c || (n && (!d_dst || !d_src))) return QZD_ERR_PARAM;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(d_dst, d_src, n, hipMemcpyDeviceToDevice, c->st[1]));
+    HIPCHK(c, hipStreamSynchronize(c->st[1]));
+    return QZD_OK;
+}
 extern "C" void *qzd_host_alloc_pinned(size_t n)
 {
     void *p = NULL;

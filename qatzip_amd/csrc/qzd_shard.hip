@@ -36,8 +36,13 @@ struct qzd_shard {
 };
 
 #define QZD_SHARD_HDR 24u
-static size_t win_bytes(uint32_t world, uint64_t cap) { return (size_t)world * sizeof(qzd_shard_rec) + QZD_SHARD_HDR + cap + 8 + 256; }
-static uint8_t *win_payload(qzd_shard *s) { return s->win + (size_t)s->world * sizeof(qzd_shard_rec) + QZD_SHARD_HDR; }
+/* two sets of records, used alternately by the streams (seq & 1): ranks run one stream ahead of each other at most - a
+ * rank publishes its record for stream n + 1 as soon as its own shard is coded, while the root may still be collecting
+ * stream n, but nobody gets past waiting for the root's record of n + 1, which the root writes when n is closed */
+#define QZD_SHARD_SETS 2u
+static size_t win_bytes(uint32_t world, uint64_t cap) { return (size_t)QZD_SHARD_SETS * world * sizeof(qzd_shard_rec) + QZD_SHARD_HDR + cap + 8 + 256; }
+static uint8_t *win_payload(qzd_shard *s) { return s->win + (size_t)QZD_SHARD_SETS * s->world * sizeof(qzd_shard_rec) + QZD_SHARD_HDR; }
+static qzd_shard_rec *win_recs(qzd_shard *s, uint32_t seq) { return (qzd_shard_rec *)s->win + (size_t)(seq & (QZD_SHARD_SETS - 1)) * s->world; }
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
@@ -51,7 +56,7 @@ extern "C" int qzd_shard_root_create(qzd_ctx *c, uint32_t world, uint64_t cap_by
     s->ctx = c; s->rank = 0; s->world = world; s->cap = cap_bytes; s->owner = true; s->win = NULL;
     const size_t nb = win_bytes(world, cap_bytes);
     if (hipMalloc(&s->win, nb) != hipSuccess) { delete s; return QZD_ERR_HIP; }
-    hipMemset(s->win, 0, (size_t)world * sizeof(qzd_shard_rec) + QZD_SHARD_HDR);
+    hipMemset(s->win, 0, (size_t)QZD_SHARD_SETS * world * sizeof(qzd_shard_rec) + QZD_SHARD_HDR);
     hipDeviceSynchronize();
     hipIpcMemHandle_t h;
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the 64 bytes of the ABI");
@@ -102,7 +107,7 @@ extern "C" int qzd_shard_put(qzd_shard *s, const uint8_t *d_comp, uint64_t comp_
     if (!s || seq == 0 || (comp_len && !d_comp)) return QZD_ERR_PARAM;
     qzd_ctx *c = s->ctx;
     hipSetDevice(c->device);
-    qzd_shard_rec *recs = (qzd_shard_rec *)s->win;
+    qzd_shard_rec *recs = win_recs(s, seq);
     qzd_shard_rec mine; mine.raw_len = raw_len; mine.comp_len = comp_len; mine.crc = crc32; mine.seq = seq; mine.done = 0; mine.pad = 0;
     HIPCHK(c, hipMemcpy(recs + s->rank, &mine, sizeof(mine), hipMemcpyHostToDevice));
     /* exclusive scan over the ranks before me: poll their records until they carry this stream's number */
@@ -153,7 +158,7 @@ extern "C" int qzd_shard_finish(qzd_shard *s, uint32_t seq, double timeout_s, in
     if (!s || s->rank != 0 || !d_stream || !stream_len) return QZD_ERR_PARAM;
     qzd_ctx *c = s->ctx;
     hipSetDevice(c->device);
-    qzd_shard_rec *recs = (qzd_shard_rec *)s->win;
+    qzd_shard_rec *recs = win_recs(s, seq);
     qzd_shard_rec *h = (qzd_shard_rec *)malloc((size_t)s->world * sizeof(qzd_shard_rec));
     if (!h) return QZD_ERR_HIP;
     const double t0 = now_s();
@@ -194,33 +199,50 @@ extern "C" int qzd_shard_finish(qzd_shard *s, uint32_t seq, double timeout_s, in
  * single-GPU user of libqatzip_amd.so never loads half a gigabyte of collectives.  bench.py measures both transports
  * and reports the faster one; a box where RCCL cannot start (ranks sharing a device, no peer access) keeps the window. */
 #include <dlfcn.h>
+/* The library is looked up at run time, so its header is no reason for libqatzip_amd.so not to build: where
+ * <rccl/rccl.h> is missing (a ROCm install without the development package) the few types and enumerators the calls
+ * below need are stated here, as the ABI has them. */
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+#endif
 
 struct qzd_rccl_api {
     void *so;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *);
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*CommAbort)(ncclComm_t);
     ncclResult_t (*GroupStart)(void);
     ncclResult_t (*GroupEnd)(void);
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     const char *(*GetErrorString)(ncclResult_t);
+    char why[200];                  /* why the library is not there (dlerror() at the time, kept: the call clears it) */
 };
 static qzd_rccl_api g_rccl;
 static pthread_once_t g_rccl_once = PTHREAD_ONCE_INIT;
 static void rccl_load(void)
 {
     void *so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!so) {
+        const char *e = dlerror();
+        snprintf(g_rccl.why, sizeof(g_rccl.why), "%s", e ? e : "dlopen(librccl.so.1) failed");
+        so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    }
     if (!so) return;
 #define QZD_SYM(f) *(void **)&g_rccl.f = dlsym(so, "nccl" #f)
-    QZD_SYM(GetUniqueId); QZD_SYM(CommInitRank); QZD_SYM(CommDestroy); QZD_SYM(GroupStart); QZD_SYM(GroupEnd);
+    QZD_SYM(GetUniqueId); QZD_SYM(CommInitRank); QZD_SYM(CommDestroy); QZD_SYM(CommAbort); QZD_SYM(GroupStart); QZD_SYM(GroupEnd);
     QZD_SYM(Send); QZD_SYM(Recv); QZD_SYM(AllGather); QZD_SYM(GetErrorString);
 #undef QZD_SYM
     if (g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.GroupStart && g_rccl.GroupEnd &&
         g_rccl.Send && g_rccl.Recv && g_rccl.AllGather && g_rccl.GetErrorString) g_rccl.so = so;
+    else snprintf(g_rccl.why, sizeof(g_rccl.why), "librccl lacks an entry point this library calls");
 }
 static bool rccl_ready(void) { pthread_once(&g_rccl_once, rccl_load); return g_rccl.so != NULL; }
 
@@ -232,9 +254,34 @@ struct qzd_rccl {
     uint8_t *win;                   /* root: [24-byte header | payload cap | 8-byte trailer] */
     qzd_shard_rec *d_recs;          /* world + 1 records: [0..world) gathered, [world] mine */
     qzd_shard_rec *h_recs;          /* pinned mirror */
+    double timeout_s;               /* how long a wait for the other ranks may take (QATZIP_AMD_RCCL_TIMEOUT, default 60) */
 };
 #define RCCLCHK(c, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
     snprintf((c)->err, sizeof((c)->err), "%s -> %s", #call, g_rccl.GetErrorString(r_)); return QZD_ERR_HIP; } } while (0)
+/* inside ncclGroupStart / ncclGroupEnd: the group is closed on the way out, whatever happened in it */
+#define RCCLCHK_G(c, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    snprintf((c)->err, sizeof((c)->err), "%s -> %s", #call, g_rccl.GetErrorString(r_)); g_rccl.GroupEnd(); return QZD_ERR_HIP; } } while (0)
+
+/* RCCL's waits are on the device: a rank that never arrives leaves the others' kernels spinning and a plain
+ * hipStreamSynchronize() waiting with them for ever.  The host polls the stream instead, and when the time is up the
+ * communicator is aborted (the kernels leave) and the call fails everywhere it was waiting. */
+static int rccl_wait(qzd_rccl *s, hipStream_t st, const char *what)
+{
+    qzd_ctx *c = s->ctx;
+    const double t0 = now_s();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return QZD_OK;
+        if (e != hipErrorNotReady) { snprintf(c->err, sizeof(c->err), "RCCL gather (%s): %s", what, hipGetErrorString(e)); return QZD_ERR_HIP; }
+        if (now_s() - t0 > s->timeout_s) {
+            snprintf(c->err, sizeof(c->err), "RCCL gather: rank %u waited %.0f s in %s for a rank that did not come; communicator aborted",
+                     s->rank, s->timeout_s, what);
+            if (s->comm && g_rccl.CommAbort) { g_rccl.CommAbort(s->comm); s->comm = NULL; }
+            return QZD_ERR_HIP;
+        }
+        struct timespec ts = {0, 50000}; nanosleep(&ts, NULL);
+    }
+}
 
 extern "C" int qzd_rccl_unique_id(uint8_t id_out[128])
 {
@@ -251,8 +298,7 @@ extern "C" void qzd_rccl_close(qzd_rccl *s)
 {
     if (!s) return;
     hipSetDevice(s->ctx->device);
-    hipDeviceSynchronize();
-    if (s->comm) g_rccl.CommDestroy(s->comm);
+    if (s->comm) { hipDeviceSynchronize(); g_rccl.CommDestroy(s->comm); }
     if (s->win) hipFree(s->win);
     if (s->d_recs) hipFree(s->d_recs);
     if (s->h_recs) hipHostFree(s->h_recs);
@@ -264,11 +310,13 @@ extern "C" int qzd_rccl_create(qzd_ctx *c, uint32_t rank, uint32_t world, const 
 {
     if (!c || !out || !id || world == 0 || rank >= world || world > 4096) return QZD_ERR_PARAM;
     *out = NULL;
-    if (!rccl_ready()) { snprintf(c->err, sizeof(c->err), "librccl.so.1 not found: %s", dlerror() ? dlerror() : "?"); return QZD_ERR_UNSUPPORTED; }
+    if (!rccl_ready()) { snprintf(c->err, sizeof(c->err), "librccl.so.1 not usable: %s", g_rccl.why[0] ? g_rccl.why : "?"); return QZD_ERR_UNSUPPORTED; }
     hipSetDevice(c->device);
     qzd_rccl *s = new (std::nothrow) qzd_rccl();
     if (!s) return QZD_ERR_HIP;
     s->ctx = c; s->rank = rank; s->world = world; s->cap = cap_bytes; s->comm = NULL; s->win = NULL; s->d_recs = NULL; s->h_recs = NULL;
+    const char *te = getenv("QATZIP_AMD_RCCL_TIMEOUT");
+    s->timeout_s = te && atof(te) > 0 ? atof(te) : 60.0;
     if (hipMalloc(&s->d_recs, (size_t)(world + 1) * sizeof(qzd_shard_rec)) != hipSuccess ||
         hipHostMalloc((void **)&s->h_recs, (size_t)(world + 1) * sizeof(qzd_shard_rec), hipHostMallocDefault) != hipSuccess ||
         (rank == 0 && hipMalloc(&s->win, QZD_SHARD_HDR + cap_bytes + 8 + 256) != hipSuccess)) {
@@ -288,36 +336,40 @@ extern "C" int qzd_rccl_create(qzd_ctx *c, uint32_t rank, uint32_t world, const 
 
 /* every rank: my shard (raw-deflate stream of my chunk range, its CRC-32) joins the member in the root's HBM.  On the
  * root *d_stream / *stream_len describe the finished member (valid until the next gather or qzd_rccl_close); the other
- * ranks get NULL / 0.  Returns when this rank's part is done (its stream is synchronised). */
+ * ranks get NULL / 0.  Returns when this rank's part is done (its stream is synchronised).  Every decision that sends a
+ * rank down a different path is taken from the gathered records, which all ranks hold alike - the root's capacity
+ * travels in its record - so that no rank leaves while the others wait for it; waits are bounded (rccl_wait). */
 extern "C" int qzd_rccl_gather(qzd_rccl *s, const uint8_t *d_comp, uint64_t comp_len, uint64_t raw_len, uint32_t crc32, int level,
                                uint8_t **d_stream, uint64_t *stream_len, uint32_t *crc_out, uint64_t *raw_total)
 {
     if (!s || (comp_len && !d_comp)) return QZD_ERR_PARAM;
     qzd_ctx *c = s->ctx;
+    if (!s->comm) { snprintf(c->err, sizeof(c->err), "RCCL gather: the communicator was aborted by an earlier timeout"); return QZD_ERR_HIP; }
     hipSetDevice(c->device);
     hipStream_t st = c->st[0];
     qzd_shard_rec *mine = s->h_recs + s->world;
-    mine->raw_len = raw_len; mine->comp_len = comp_len; mine->crc = crc32; mine->seq = 1; mine->done = 0; mine->pad = 0;
+    mine->raw_len = raw_len; mine->comp_len = comp_len; mine->crc = crc32; mine->seq = 1; mine->done = 0;
+    mine->pad = (uint32_t)(s->cap >> 12);                           /* my buffer's capacity in 4 KiB units: the root's is what counts */
     HIPCHK(c, hipMemcpyAsync(s->d_recs + s->world, mine, sizeof(*mine), hipMemcpyHostToDevice, st));
     RCCLCHK(c, g_rccl.AllGather(s->d_recs + s->world, s->d_recs, sizeof(qzd_shard_rec), ncclUint8, s->comm, st));
     HIPCHK(c, hipMemcpyAsync(s->h_recs, s->d_recs, (size_t)s->world * sizeof(qzd_shard_rec), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    uint64_t raw = 0, comp = 0, my_off = 0; uint32_t crc = 0;
+    int rc = rccl_wait(s, st, "the all-gather of the records");
+    if (rc) return rc;
+    uint64_t raw = 0, comp = 0; uint32_t crc = 0;
     for (uint32_t r = 0; r < s->world; r++) {
-        if (r == s->rank) my_off = comp;
         crc = r == 0 ? s->h_recs[r].crc : qzd_crc32_combine(crc, s->h_recs[r].crc, s->h_recs[r].raw_len);
         raw += s->h_recs[r].raw_len; comp += s->h_recs[r].comp_len;
     }
+    /* the same verdict on every rank: nobody posts a send the root will not receive */
     if (raw > 0xffffffffull || comp > 0xffffffffull) { snprintf(c->err, sizeof(c->err), "a gzip-ext member holds less than 4 GiB"); return QZD_ERR_PARAM; }
-    if (comp > s->cap) { snprintf(c->err, sizeof(c->err), "RCCL gather: root buffer too small"); return QZD_ERR_DSTCAP; }
-    (void)my_off;
+    if (comp > ((uint64_t)s->h_recs[0].pad << 12)) { snprintf(c->err, sizeof(c->err), "RCCL gather: root buffer too small"); return QZD_ERR_DSTCAP; }
     if (s->rank == 0) {
         uint8_t *pay = s->win + QZD_SHARD_HDR;
         if (comp_len) HIPCHK(c, hipMemcpyAsync(pay, d_comp, comp_len, hipMemcpyDeviceToDevice, st));
         RCCLCHK(c, g_rccl.GroupStart());
         uint64_t off = s->h_recs[0].comp_len;
         for (uint32_t r = 1; r < s->world; r++) {
-            if (s->h_recs[r].comp_len) RCCLCHK(c, g_rccl.Recv(pay + off, s->h_recs[r].comp_len, ncclUint8, (int)r, s->comm, st));
+            if (s->h_recs[r].comp_len) RCCLCHK_G(c, g_rccl.Recv(pay + off, s->h_recs[r].comp_len, ncclUint8, (int)r, s->comm, st));
             off += s->h_recs[r].comp_len;
         }
         RCCLCHK(c, g_rccl.GroupEnd());
@@ -325,16 +377,18 @@ extern "C" int qzd_rccl_gather(qzd_rccl *s, const uint8_t *d_comp, uint64_t comp
         member_frame(ht, ht + 24, level, raw, comp, crc);
         HIPCHK(c, hipMemcpyAsync(s->win, ht, 24, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(pay + comp, ht + 24, 8, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        rc = rccl_wait(s, st, "the receives");
+        if (rc) return rc;
         if (d_stream) *d_stream = s->win;
         if (stream_len) *stream_len = QZD_SHARD_HDR + comp + 8;
     } else {
         if (comp_len) {
             RCCLCHK(c, g_rccl.GroupStart());
-            RCCLCHK(c, g_rccl.Send(d_comp, comp_len, ncclUint8, 0, s->comm, st));
+            RCCLCHK_G(c, g_rccl.Send(d_comp, comp_len, ncclUint8, 0, s->comm, st));
             RCCLCHK(c, g_rccl.GroupEnd());
         }
-        HIPCHK(c, hipStreamSynchronize(st));
+        rc = rccl_wait(s, st, "the send");
+        if (rc) return rc;
         if (d_stream) *d_stream = NULL;
         if (stream_len) *stream_len = 0;
     }

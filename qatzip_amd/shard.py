@@ -14,6 +14,52 @@ def shard_chunks(nchunks: int, world: int, rank: int):
     return b, b + q + (1 if rank < r else 0)
 
 
+GZIP_EXT_MAX = (1 << 32) - 1        # both size fields of a gzip-ext header are 32-bit (src/qatzip_gzip.c:98-118)
+
+
+def member_plan(total_bytes: int, world: int, chunk: int, slice_bytes: int = 511 << 20):
+    """BASELINE config 5 as a plan.  A logical buffer of 4 GiB or more is more than one gzip-ext member, so it becomes M
+    members and is dealt to the ranks like a striped volume: member m is the logical range [m * world * slice,
+    (m + 1) * world * slice), cut into `world` contiguous shards of whole chunks, shard r on rank r (the last member
+    takes what is left: shard_chunks() spreads its chunks, the buffer's ragged end goes to the last rank that holds
+    any).  All GPUs work on every member, a member's shards lie in rank order, and the members in order decode to the
+    buffer in order - qzDecompress reads a sequence of members as it reads what qzCompress writes call after call.
+    Returns per member [(logical offset, bytes)] by rank; world * slice stays below 4 GiB."""
+    assert total_bytes >= 0 and world >= 1 and chunk >= 1
+    cap = (GZIP_EXT_MAX // world) // chunk * chunk               # what a member's raw-size field allows per rank
+    sl = max(chunk, min(slice_bytes, cap) // chunk * chunk)
+    plan, base = [], 0
+    while True:
+        left = total_bytes - base
+        if left >= world * sl:
+            plan.append([(base + r * sl, sl) for r in range(world)])
+            base += world * sl
+            if base == total_bytes:
+                break
+            continue
+        nch = (left + chunk - 1) // chunk                        # the last member: whole chunks per rank, the tail on the last
+        shards = []
+        for r in range(world):
+            b, e = shard_chunks(nch, world, r)
+            lo, hi = min(left, b * chunk), min(left, e * chunk)
+            shards.append((base + lo, hi - lo))
+        if left > 0 or not plan:
+            plan.append(shards)
+        break
+    return plan
+
+
+def local_offsets(plan, rank: int):
+    """where rank `rank` keeps its shard of each member when its shards lie back to back in its own memory:
+    [(local offset, bytes)] per member"""
+    out, off = [], 0
+    for shards in plan:
+        n = shards[rank][1]
+        out.append((off, n))
+        off += n
+    return out
+
+
 def _gf2_times(mat, vec):
     s = 0
     i = 0
@@ -116,6 +162,9 @@ class OneStream:
         self.error = None
         self.seq = 0
         self.cap = world * (_lib.max_deflate_len(shard_bytes, chunk) + 64)
+        # the transport has a context of its own (its own streams): run_members() keeps a gather on the wire while the next
+        # member is being deflated on ctx
+        self.tctx = tctx = _lib.Context(ctx.device)
         err = None
         if transport == "rccl":
             idb = C.create_string_buffer(128)
@@ -125,15 +174,15 @@ class OneStream:
             if not _all_ok(pg, err is None):
                 self.error = err or "rank 0 could not make an RCCL id"
                 return
-            if L.qzd_rccl_create(ctx.h, rank, world, uid, self.cap, C.byref(self.h)) != 0:
-                err = "rccl init: " + L.qzd_last_error(ctx.h).decode()
+            if L.qzd_rccl_create(tctx.h, rank, world, uid, self.cap, C.byref(self.h)) != 0:
+                err = "rccl init: " + L.qzd_last_error(tctx.h).decode()
         else:
             hbuf = C.create_string_buffer(64)
-            if rank == 0 and L.qzd_shard_root_create(ctx.h, world, self.cap, hbuf, C.byref(self.h)) != 0:
-                err = "root window: " + L.qzd_last_error(ctx.h).decode()
+            if rank == 0 and L.qzd_shard_root_create(tctx.h, world, self.cap, hbuf, C.byref(self.h)) != 0:
+                err = "root window: " + L.qzd_last_error(tctx.h).decode()
             handle = broadcast_bytes(pg, hbuf.raw if rank == 0 else None, 64, 0) if world > 1 else hbuf.raw
-            if rank != 0 and err is None and L.qzd_shard_attach(ctx.h, rank, world, handle, self.cap, C.byref(self.h)) != 0:
-                err = "attach: " + L.qzd_last_error(ctx.h).decode()
+            if rank != 0 and err is None and L.qzd_shard_attach(tctx.h, rank, world, handle, self.cap, C.byref(self.h)) != 0:
+                err = "attach: " + L.qzd_last_error(tctx.h).decode()
         if not _all_ok(pg, err is None):
             self.error = err or "another rank could not set the %s transport up" % transport
             self.close()
@@ -159,20 +208,26 @@ class OneStream:
             clen, crcs = ctx.deflate_raw(d_src, n, chunk, self.level, 1 if rank == world - 1 else 0, self.d_comp)
             crcs = np.ascontiguousarray(crcs, dtype=np.uint32)  # the shard's CRC-32 from its chunks' (crc32_combine algebra)
             crc = L.qzd_crc32_fold(crcs.ctypes.data, len(crcs), chunk, n)
-            t1 = time.perf_counter()
+        except Exception as e:   # noqa: BLE001
+            err = "deflate: " + str(e)[:150]
+        t1 = time.perf_counter()
+        # agreement BEFORE the gather: a rank whose deflate failed must not leave the others waiting on the device
+        if not _all_ok(self.pg, err is None):
+            return {"error": err or "another rank's deflate failed"}
+        try:
             dptr, slen, fcrc, raw = C.c_void_p(), C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
             if self.transport == "rccl":
                 if L.qzd_rccl_gather(self.h, self.d_comp.ptr, clen, n, crc, self.level, C.byref(dptr), C.byref(slen),
                                      C.byref(fcrc), C.byref(raw)) != 0:
-                    err = "gather: " + L.qzd_last_error(ctx.h).decode()
+                    err = "gather: " + L.qzd_last_error(self.tctx.h).decode()
             else:
                 if L.qzd_shard_put(self.h, self.d_comp.ptr, clen, n, crc, self.seq, self.timeout_s, None) != 0:
-                    err = "put: " + L.qzd_last_error(ctx.h).decode()
+                    err = "put: " + L.qzd_last_error(self.tctx.h).decode()
                 elif rank == 0 and L.qzd_shard_finish(self.h, self.seq, self.timeout_s, self.level, C.byref(dptr), C.byref(slen),
                                                       C.byref(fcrc), C.byref(raw)) != 0:
-                    err = "finish: " + L.qzd_last_error(ctx.h).decode()
+                    err = "finish: " + L.qzd_last_error(self.tctx.h).decode()
         except Exception as e:   # noqa: BLE001
-            err = "deflate: " + str(e)[:150]
+            err = "gather: " + str(e)[:150]
         t2 = time.perf_counter()
         if not _all_ok(self.pg, err is None):
             return {"error": err or "another rank failed"}
@@ -187,12 +242,120 @@ class OneStream:
             self.pg.barrier()                                   # nobody starts the next member before rank 0 has read this one
         return out
 
+    def run_members(self, d_src, plan, d_out=None, depth=2):
+        """The members of `plan` (member_plan(); this rank's shards lie back to back in d_src, local_offsets()), PIPELINED: while
+        member m's shards are on the wire, member m + 1 is being deflated - the transport has a context (streams) of its
+        own and a thread of its own, two staging buffers alternate.  The ranks agree after every deflate that all of them are
+        going into the gather (a rank that failed never leaves the others waiting on the device); the transports' own
+        waits are bounded.  Rank 0 appends every finished member to d_out (a DevBuf in its HBM) when given one.
+        -> {"members", "raw_bytes", "out_bytes", "ms", "deflate_ms", "gather_ms", "overlapped_ms", "member_bytes": [...]}
+        or {"error"}.  (overlapped_ms: time the gather thread was busy while the main thread was deflating.)"""
+        import ctypes as C
+        import queue
+        import threading
+        import time
+        import numpy as np
+        from . import _lib
+        L, ctx, rank, world, chunk = self.L, self.ctx, self.rank, self.world, self.chunk
+        M = len(plan)
+        mine = local_offsets(plan, rank)
+        nmax = max(n for _, n in mine)
+        if nmax > self.n:
+            return {"error": "a slice of the plan is larger than the shard this OneStream was made for"}
+        bufs = [self.d_comp] + [ctx.alloc(_lib.max_deflate_len(self.n, chunk)) for _ in range(max(1, depth) - 1)]
+        free = [threading.Semaphore(1) for _ in bufs]
+        work = queue.Queue()
+        gat = {"err": None, "ms": 0.0, "busy": [], "members": [], "out": 0, "raw": 0}
+
+        def gather_thread():
+            while True:
+                item = work.get()
+                if item is None:
+                    return
+                m, b, n, clen, crc = item
+                t0 = time.perf_counter()
+                try:
+                    if gat["err"] is None:
+                        self.seq += 1
+                        dptr, slen, fcrc, raw = C.c_void_p(), C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+                        if self.transport == "rccl":
+                            if L.qzd_rccl_gather(self.h, bufs[b].ptr, clen, n, crc, self.level, C.byref(dptr), C.byref(slen),
+                                                 C.byref(fcrc), C.byref(raw)) != 0:
+                                gat["err"] = "member %d gather: %s" % (m, L.qzd_last_error(self.tctx.h).decode())
+                        else:
+                            if L.qzd_shard_put(self.h, bufs[b].ptr, clen, n, crc, self.seq, self.timeout_s, None) != 0:
+                                gat["err"] = "member %d put: %s" % (m, L.qzd_last_error(self.tctx.h).decode())
+                            elif rank == 0 and L.qzd_shard_finish(self.h, self.seq, self.timeout_s, self.level, C.byref(dptr),
+                                                                  C.byref(slen), C.byref(fcrc), C.byref(raw)) != 0:
+                                gat["err"] = "member %d finish: %s" % (m, L.qzd_last_error(self.tctx.h).decode())
+                        if gat["err"] is None and rank == 0:
+                            if d_out is not None:
+                                if gat["out"] + slen.value > d_out.nbytes:
+                                    gat["err"] = "member %d: the output buffer is full" % m
+                                elif L.qzd_d2d(self.tctx.h, d_out.ptr + gat["out"], dptr.value, slen.value) != 0:
+                                    gat["err"] = "member %d: copy out of the window failed" % m
+                            gat["members"].append(slen.value); gat["out"] += slen.value; gat["raw"] += raw.value
+                except Exception as e:   # noqa: BLE001
+                    gat["err"] = "member %d: %s" % (m, str(e)[:120])
+                finally:
+                    t1 = time.perf_counter()
+                    gat["ms"] += (t1 - t0) * 1e3; gat["busy"].append((t0, t1))
+                    free[b].release()
+
+        th = threading.Thread(target=gather_thread, daemon=True)
+        th.start()
+        if self.pg is not None:
+            self.pg.barrier()
+        t_begin = time.perf_counter()
+        t_defl, defl_spans, err = 0.0, [], None
+        for m, (off, n) in enumerate(mine):
+            b = m % len(bufs)
+            free[b].acquire()                                   # the gather of member m - depth has let go of this buffer
+            t0 = time.perf_counter()
+            clen = crc = 0
+            try:
+                v = _lib.DevBuf.__new__(_lib.DevBuf); v.ctx, v.nbytes, v.ptr = ctx, n, d_src.ptr + off
+                # the member's stream closes with the shard of the last rank that holds any of it (rank 0 for an empty member)
+                closer = max([r for r in range(world) if plan[m][r][1]] or [0])
+                if n or rank == closer:
+                    clen, crcs = ctx.deflate_raw(v, n, chunk, self.level, 1 if rank == closer else 0, bufs[b])
+                    crcs = np.ascontiguousarray(crcs, dtype=np.uint32)
+                    crc = L.qzd_crc32_fold(crcs.ctypes.data, len(crcs), chunk, n)
+            except Exception as e:   # noqa: BLE001
+                err = "member %d deflate: %s" % (m, str(e)[:150])
+            t1 = time.perf_counter()
+            t_defl += (t1 - t0) * 1e3; defl_spans.append((t0, t1))
+            # every rank learns here whether every rank is going into the gather of this member (nobody waits on the device
+            # for a rank that failed); a transport that failed on an earlier member ends the run the same way
+            if not _all_ok(self.pg, err is None and gat["err"] is None):
+                free[b].release()
+                err = err or gat["err"] or "another rank failed before member %d" % m
+                break
+            work.put((m, b, n, clen, crc))
+        work.put(None)
+        th.join()
+        t_end = time.perf_counter()
+        ok = _all_ok(self.pg, err is None and gat["err"] is None)
+        for extra in bufs[1:]:
+            extra.free()
+        if not ok:
+            return {"error": err or gat["err"] or "another rank failed"}
+        if self.pg is not None:
+            self.pg.barrier()
+        overl = sum(max(0.0, min(g1, d1) - max(g0, d0)) for g0, g1 in gat["busy"] for d0, d1 in defl_spans) * 1e3
+        out = {"members": M, "ms": (t_end - t_begin) * 1e3, "deflate_ms": t_defl, "gather_ms": gat["ms"], "overlapped_ms": overl}
+        if rank == 0:
+            out.update({"raw_bytes": gat["raw"], "out_bytes": gat["out"], "member_bytes": gat["members"]})
+        return out
+
     def close(self):
         if self.h:
             (self.L.qzd_rccl_close if self.transport == "rccl" else self.L.qzd_shard_close)(self.h)
             self.h = None
         if getattr(self, "d_comp", None) is not None:
             self.d_comp.free(); self.d_comp = None
+        if getattr(self, "tctx", None) is not None and self.tctx is not self.ctx:
+            self.tctx.close(); self.tctx = None
 
 
 def member_is_consistent(member: bytes, records) -> bool:

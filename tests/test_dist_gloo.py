@@ -74,3 +74,79 @@ def test_two_ranks_build_one_stream():
     gz = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0]) + b"QZ\x08\x00" + struct.pack("<II", raw, total) + \
         bytes(stream) + struct.pack("<II", crc, raw)
     assert gz == O.sw_compress("GZIP_EXT", src, 16384, 1)[2]
+
+
+# ---- config 5 as written: a buffer of more than one member, M members of `world` shards each (shard.member_plan) ----
+def test_member_plan_covers_the_buffer_in_order():
+    for total, world, chunk, sl in ((8 * (8176 << 20), 8, 65536, 511 << 20), (3 * (5 * 65536) + 17, 3, 65536, 2 * 65536), (0, 2, 4096, 8192),
+                                    (1 << 20, 1, 16384, 1 << 18), (8 * (1 << 32) + 12345, 8, 65536, 1 << 30), (70000, 4, 65536, 65536)):
+        plan = S.member_plan(total, world, chunk, sl)
+        flat = [x for m in plan for x in m]
+        assert all(len(m) == world for m in plan)
+        assert sum(n for _, n in flat) == total
+        assert [o for o, _ in flat] == [sum(n for _, n in flat[:i]) for i in range(len(flat))]          # the logical buffer, in order
+        assert all(o % chunk == 0 for o, n in flat if n) and all(sum(n for _, n in m) <= 0xffffffff for m in plan)
+        for m in plan:                                                                                  # whole chunks, but for the member's last bytes
+            nz = [n for _, n in m if n]
+            assert all(n % chunk == 0 for n in nz[:-1])
+        for r in range(world):
+            loc = S.local_offsets(plan, r)
+            assert [o for o, _ in loc] == [sum(n for _, n in loc[:i]) for i in range(len(loc))]
+    assert len(S.member_plan(8 * (8176 << 20), 8, 65536)) == 16                                         # BASELINE config 5: 16 members
+
+
+HW_M, SL_M, TOTAL_M = 16384, 3 * 16384, 2 * (7 * 16384) + 333        # three members over two ranks: 6 + 6 + (2 chunks and a bit)
+
+
+def _member_worker(rank, world, port, q):
+    sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = S.member_plan(TOTAL_M, world, HW_M, SL_M)
+    logical = datagen.gen_bytes("silesia", TOTAL_M, 9)
+    members = []
+    for m, shards in enumerate(plan):
+        off, n = shards[rank]
+        mine = logical[off:off + n]                                    # the striped volume: my shard of member m
+        last_holder = max(r for r in range(world) if shards[r][1] or r == 0)
+        rc, used, comp, _ = O.sw_compress("RAW", mine, HW_M, 1, last=1 if rank == last_holder else 0) if (n or rank == last_holder) else (0, 0, b"", 0)
+        assert rc == 0 and used == len(mine)
+        recs = S.all_gather_records(dist, S.pack_record(len(mine), len(comp), zlib.crc32(mine)), world)
+        offs, raw, total, crc = S.fold_records(recs)
+        members.append((offs[rank], comp, raw, total, crc))
+    q.put((rank, members))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_members_from_two_ranks_are_what_the_software_path_writes():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_member_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    logical = datagen.gen_bytes("silesia", TOTAL_M, 9)
+    plan = S.member_plan(TOTAL_M, world, HW_M, SL_M)
+    assert len(plan) == 3
+    out, expect, pos = b"", b"", 0
+    for m, shards in enumerate(plan):
+        _, _, raw, total, crc = got[0][m]
+        stream = bytearray(total)
+        for r in range(world):
+            off, comp, *_ = got[r][m]
+            stream[off:off + len(comp)] = comp
+        out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 4, 255, 12, 0]) + b"QZ\x08\x00" + struct.pack("<II", raw, total) + \
+            bytes(stream) + struct.pack("<II", crc, raw)
+        n_m = sum(n for _, n in shards)
+        expect += O.sw_compress("GZIP_EXT", logical[pos:pos + n_m], HW_M, 1)[2]    # one qzCompress call per member, in order
+        pos += n_m
+    assert pos == len(logical) and out == expect
+    rc, used, back = O.sw_decompress("GZIP_EXT", out, len(logical) + 64)            # and the sequence decodes to the buffer, in order
+    assert rc == 0 and used == len(out) and back == logical

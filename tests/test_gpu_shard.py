@@ -104,3 +104,72 @@ def test_rccl_transport_between_gpus():
     got, whole, exp = _run(world, 1, "rccl", True)
     for tag, stream, raw, ndev, err in got:
         assert tag == "ok" and not err and stream == exp
+
+
+# ---- BASELINE config 5 as written: a buffer of several members, every member built by all ranks, member m + 1 deflated while
+# member m's shards are on the wire (OneStream.run_members) ----
+CH_M, SLICE_M = 65536, 3 * 65536
+
+
+def _members_worker(rank, world, port, total, transport, q):
+    sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+    import numpy as np
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import qatzip_amd
+    from qatzip_amd import shard as S
+    ndev = qatzip_amd.load().qzd_device_count()
+    ctx = qatzip_amd.Context(rank % ndev)
+    logical = datagen.gen("silesia", total, 78)
+    plan = S.member_plan(total, world, CH_M, SLICE_M)
+    mine = np.concatenate([logical[o:o + n] for o, n in (m[rank] for m in plan)] + [np.zeros(0, np.uint8)])   # my shards, back to back
+    d_src = ctx.alloc(max(1, mine.size)); d_src.upload(mine)
+    d_out = ctx.alloc(total * 9 // 8 + 4096 * len(plan)) if rank == 0 else None
+    one = S.OneStream(ctx, dist, rank, world, max(n for m in plan for _, n in m), CH_M, 1, transport)
+    if one.error:
+        if rank == 0:
+            q.put(("error", one.error))
+    else:
+        res = one.run_members(d_src, plan, d_out)
+        if rank == 0:
+            q.put(("ok", d_out.download(res["out_bytes"]).tobytes() if "error" not in res else None, res))
+        one.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@pytest.mark.parametrize("world,total", [(3, 3 * (3 * SLICE_M) + 2 * CH_M + 4321), (2, 4 * (2 * SLICE_M))])
+def test_members_of_a_larger_buffer_follow_each_other_like_calls(world, total):
+    """>= 3 members x 3 ranks (sharing this box's GPU: the IPC window is the same path): the concatenation is, byte for
+    byte, what the software path writes for one qzCompress call per member (src/qatzip_sw.c:77-256, the in-order retire it
+    stands for: src/qatzip.c:1691-1718), and qzDecompress reads the sequence back to the buffer"""
+    import qatzip_amd.api as A
+    from qatzip_amd import shard as S
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33600 + (os.getpid() + 11 * world) % 2000
+    ps = [ctx.Process(target=_members_worker, args=(r, world, port, total, "ipc", q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    tag, stream, res = q.get(timeout=300)
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    assert tag == "ok" and "error" not in res, res
+    logical = datagen.gen_bytes("silesia", total, 78)
+    plan = S.member_plan(total, world, CH_M, SLICE_M)
+    assert res["members"] == len(plan) >= 3 and res["raw_bytes"] == total
+    exp, pos = b"", 0
+    for m in plan:
+        n_m = sum(n for _, n in m)
+        exp += O.sw_compress("GZIP_EXT", logical[pos:pos + n_m], CH_M, 1, cap=n_m * 9 // 8 + 65536)[2]
+        pos += n_m
+    assert stream == exp, (len(stream), len(exp))
+    s = A.Session(A.QZ_DEFLATE_GZIP_EXT, CH_M)
+    rc, used, back = s.decompress(stream, total + 64)
+    s.close()
+    assert rc == 0 and used == len(stream) and back == logical
+    print("%d members from %d ranks: %d -> %d bytes; deflate %.1f ms, gathers %.1f ms of which %.1f ms beside a deflate" %
+          (res["members"], world, total, len(stream), res["deflate_ms"], res["gather_ms"], res["overlapped_ms"]))
