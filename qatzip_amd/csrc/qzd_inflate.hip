@@ -176,8 +176,15 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         const dim3 grid((nsegs + spw - 1) / spw), blk(64);
         static uint32_t spec_epoch = 0;                             /* tags the marks of a launch: scratch left by an earlier one is not mistaken for them */
         const uint32_t epoch = ++spec_epoch;
+        /* how far a block's last lane may run beyond its share before the rest is shared out again (a round more): segments
+         * above 64 KB hold several blocks of very different length and pay for every lane left alone; small launches end
+         * with their longest lane; a full launch of 64 KB segments is better off without the extra rounds
+         * (profiles/r4_inflate_crossover.txt) */
+        uint32_t over = hs[0].out_cap > 65536u + 64u ? 2u : nsegs <= 4096u ? 1u : 1000u;
+        const char *ov = getenv("QATZIP_AMD_INFLATE_OVER");
+        if (ov && atoi(ov) > 0) over = (uint32_t)atoi(ov);
 #define QZD_SPEC_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_spec_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
-                                             ts_d, lit_d, seq_d, ch_d, rec_d, epoch)
+                                             ts_d, lit_d, seq_d, ch_d, rec_d, epoch, over)
         if (K == 2) QZD_SPEC_LAUNCH(2); else if (K == 4) QZD_SPEC_LAUNCH(4); else QZD_SPEC_LAUNCH(8);
 #undef QZD_SPEC_LAUNCH
         /* what that kernel hands back (QZK_INF_ESPEC: a sub-stream outgrew its scratch, too many pieces) goes through the

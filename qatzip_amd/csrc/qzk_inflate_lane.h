@@ -171,7 +171,7 @@ typedef struct { uint64_t lit_off; uint64_t seq_off; } qzk_tokseg;             /
 #define QZK_INF_ESPEC (-6)         /* speculative phase A could not finish this segment: decode it serially */
 #define QZK_PIECE_RAW 0xffffffffu  /* qzk_chain_el.sub: not a sub-stream but seq_count stored bytes at input offset seq_first */
 typedef struct { uint32_t sub, seq_first, seq_count, lit_first, lrun_skip; } qzk_chain_el;
-#define QZK_CHAIN_MAXEL 40        /* pieces per segment (K per Huffman block of the segment, and per round that continues one) */
+#define QZK_CHAIN_MAXEL 64        /* pieces per segment (K per Huffman block of the segment, and per round that continues one) */
 typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chain;
 /* scratch a segment needs: literals <= out_cap (+ staging slack), sequences <= out_cap / 3 (+ tail) */
 #define QZK_TOK_LITCAP(out_cap) ((((uint64_t)(out_cap) + 31) & ~(uint64_t)31) + 32)

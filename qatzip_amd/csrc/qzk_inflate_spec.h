@@ -82,7 +82,8 @@ __device__ unsigned long long qzk_stamp[8];     /* wall-clock (100 MHz) first en
 template <int K>
 QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                   qzk_inf_tab *tabs, const qzk_tokseg *ts /* [nsegs * K] */, uint8_t *lits, qzk_seq *seqs,
-                                  qzk_chain *chains, qzk_rec *recs /* [nsegs * K * QZK_SPEC_NREC] */, uint32_t epoch)
+                                  qzk_chain *chains, qzk_rec *recs /* [nsegs * K * QZK_SPEC_NREC] */, uint32_t epoch,
+                                  uint32_t over_shares /* shares beyond its own the last lane of a block may decode before the rest is shared out again */)
 {
     constexpr int SPW = 64 / K;                                     /* segments per wave */
     QZ_LDS uint16_t roots[SPW][QZK_LANE_ROOTSZ];
@@ -125,7 +126,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
     int seg_status = QZK_INF_ESPEC;                                 /* set to FINAL / FLUSH when the segment ends well */
     uint32_t why = 0;                                               /* developer aid: why the segment was handed back */
     bool seg_done = !live;                                          /* lane 0: nothing more to do for this segment */
-    uint32_t cont_at = 0; bool cont = false, cont_past = false;                        /* lane 0: the block goes on at this bit (a lane on the chain ran out of scratch) */
+    uint32_t cont_at = 0, prev_span = 0; bool cont = false, cont_past = false, cont_grow = false;                        /* lane 0: the block goes on at this bit (a lane on the chain ran out of scratch) */
     uint32_t c_last = 0, c_lmax = 0, c_dmax = 0, c_lbase = 0;       /* ... with the tables it has */
 
 #ifdef QZK_SPEC_PROF
@@ -145,6 +146,9 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 limit_bits = end_bits - cont_at > more ? cont_at + more : end_bits;
             }
             uint32_t share = limit_bits > cont_at ? limit_bits - cont_at : 0;
+            /* the block was longer than guessed (its last lane went a share beyond its own and was stopped there): what is
+             * shared out now is twice as much, not all the rest - the guess doubles until it covers the block */
+            if (cont_grow && prev_span != 0 && 2u * K * prev_span < share) share = 2u * K * prev_span;
             h_span = share > QZK_SPEC_MINBITS * K ? share / K : 0;
         } else if (j == 0) {
             while (!seg_done && h_mode == 0) {
@@ -184,6 +188,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
             }
         }
         QZK_SPROF(0);                                               /* [0] headers */
+        if (j == 0 && h_span != 0) prev_span = h_span;
         qz_wave_sync();                                             /* the tables (LDS) and their ranges (the segment's record) are the group's now */
         h_mode = qz_shfl(h_mode, gbase); h_end = qz_shfl(h_end, gbase); h_span = qz_shfl(h_span, gbase); h_last = qz_shfl(h_last, gbase);
         h_lmax = qz_shfl(h_lmax, gbase); h_dmax = qz_shfl(h_dmax, gbase); h_lbase = qz_shfl(h_lbase, gbase);
@@ -210,6 +215,10 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
         /* a lane that started beyond the end of the block (the block was shorter than guessed) or that never falls into
          * step decodes garbage: the end of the segment's input stops it; lane 0 is always right */
         const uint32_t give_up = j == 0 ? 0xffffffffu : limit_bits + 64;
+        /* the last lane decodes to the end of the block, however much longer than guessed the block is - but not alone for
+         * long: a share beyond its own it stops, and what is left of the block is shared out again (a round of its own, the
+         * guess doubled).  Blocks of one segment differ: 32767 symbols are a few KB of matches or 36 KB of literals. */
+        const uint32_t over = h_span != 0 && j == K - 1 && over_shares < 1000u ? h_end + ((uint32_t)K + over_shares) * h_span : 0xffffffffu;
         /* lane 0 knows where in the segment's output it stands, so a match that reaches back before the segment stops it at
          * once (the others are checked by phase B).  It is what ends the decode of a candidate that is no segment - 00 00 FF FF
          * inside compressed data: without it lane 0, which nothing else bounds, read garbage until 64 KB of output had come
@@ -240,8 +249,8 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 qzk_rec r_; r_.pos = at_; r_.nlit = QZK_NLIT(O); r_.nseq = O.nseq; r_.lrun = O.lrun; r_.olen = S.op; r_.tag = tag; r_.pad0 = r_.pad1 = 0; \
                 myrec[ridx++] = r_; \
             } \
-            if (st.kind == QZK_ST_RUN && (QZK_NLIT(O) > lit_cap || O.nseq > seq_cap || at_ >= give_up)) { \
-                st.kind = QZK_ST_REDO; st.cidx = at_ >= give_up ? 1u : 2u; st.at = at_; } \
+            if (st.kind == QZK_ST_RUN && (QZK_NLIT(O) > lit_cap || O.nseq > seq_cap || at_ >= give_up || at_ >= over)) { \
+                st.kind = QZK_ST_REDO; st.cidx = at_ >= give_up ? 1u : at_ >= over ? 4u : 2u; st.at = at_; } \
             if (rp == 0xffffffffu && target != (uint32_t)j) wake = 0;           /* the neighbour may have written since */ \
         } \
         if (at_ >= wake) { \
@@ -337,7 +346,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 s.nlit0 = qz_shfl(st.nlit0, src); s.nseq0 = qz_shfl(st.nseq0, src); s.olen0 = qz_shfl(st.olen0, src);
                 s.nlit = qz_shfl(st.nlit, src); s.nseq = qz_shfl(st.nseq, src); s.olen = qz_shfl(st.olen, src);
                 if (!walking) continue;
-                const bool broke = s.kind == QZK_ST_REDO && (s.cidx == 1u || s.cidx == 2u) && cur != 0;
+                const bool broke = s.kind == QZK_ST_REDO && (s.cidx == 1u || s.cidx == 2u || s.cidx == 4u) && cur != 0;
                 if (s.kind != QZK_ST_SYNC && s.kind != QZK_ST_EOB && !broke) {
                     /* a lane on the chain decodes the true stream: what stopped it (cidx 3: bad data, the end of the input, the
                      * capacity) is the segment's own error; lane 0 out of scratch (its sub-stream holds a whole segment) or
@@ -355,7 +364,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 if (broke) {
                     /* the lane's sub-stream is full (or it ran past the input it was told of): its piece stands, and the block
                      * goes on from where it stopped in a round of its own - lane 0's sub-stream has room for all of it */
-                    ok = true; cont = true; cont_at = s.at; cont_past = s.cidx == 1u;
+                    ok = true; cont = true; cont_at = s.at; cont_past = s.cidx == 1u; cont_grow = s.cidx == 4u;
                     c_last = h_last; c_lmax = h_lmax; c_dmax = h_dmax; c_lbase = h_lbase;
                     walking = false;
                     continue;

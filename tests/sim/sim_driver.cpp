@@ -353,7 +353,7 @@ static int two_phase_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *s
     sim::launch((nsegs + spw - 1) / spw, 64, 0, [&] {
         static uint32_t epoch = 0;
         if (threadIdx.x == 0 && blockIdx.x == 0) epoch++;
-        qzk_inflate_spec_kernel<K>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data(), recs.data(), epoch + 1);
+        qzk_inflate_spec_kernel<K>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data(), recs.data(), epoch + 1, (uint32_t)(getenv("QZSIM_OVER") ? atoi(getenv("QZSIM_OVER")) : 1));
     });
     sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
         qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), (uint32_t)K, lits.data(), seqs.data(), chains.data(), nullptr, 0);

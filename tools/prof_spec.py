@@ -28,7 +28,10 @@ os.environ["QATZIP_AMD_INFLATE"] = "lane"
 ctx.inflate_stream(d_c, clen, d_o, ck << 10, want_crc=False)
 assert ctx.L.qzd_spec_prof(None, C.c_uint32(0)) == 0           # reset (the atomics accumulate)
 ctx.inflate_stream(d_c, clen, d_o, ck << 10, want_crc=False)
-nw = min(8192, (n // (ck << 10) + 15) // 16 + 1)               # + 1: a candidate that is no segment makes one more
+nseg = n // (ck << 10)
+K = int(os.environ.get("QATZIP_AMD_INFLATE_K", "8" if nseg <= 16384 else "4"))
+spw = 64 // K
+nw = min(8192, (nseg + spw - 1) // spw + 1)                   # + 1: a candidate that is no segment makes one more
 buf = np.zeros((nw, 8), np.uint64)
 assert ctx.L.qzd_spec_prof(buf.ctypes.data_as(C.c_void_p), C.c_uint32(nw)) == 0
 b = buf.astype(np.float64)
@@ -42,6 +45,7 @@ for w, label in ((slice(None), "all waves"), (np.argsort(-tot)[:max(1, nw // 16)
     print("    inside the rounds: the busiest lane is in the hot loop %.1f %% of the round time; its trips %.0f a wave, %.0f clocks a trip;"
           " %.0f trips a lane on average" %
           (100 * x[:, 4].sum() / x[:, 2].sum(), x[:, 6].mean(), x[:, 4].sum() / x[:, 6].sum(), x[:, 7].sum() / 64 / len(x)))
+    print("    (K = %d lanes per segment, %d segments a wave)" % (K, spw))
 # waves in launch order (the host seats the largest compressed segments first): clocks by position in the launch
 q = max(1, nw // 16)
 print("  by place in the launch (sixteenths): mean / max M clocks a wave, mean headers %")
