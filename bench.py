@@ -236,27 +236,75 @@ def api_leg(base, tile, mb):
     return res
 
 
-def raw_sweep(ctx, qz, d_src, mb):
-    """BASELINE config 3: raw deflate + raw inflate, hw_buff_sz 16 / 64 / 128 KB, data resident in HBM"""
+def src_sha256():
+    """SHA-256 over the kernel and host sources of the library (qatzip_amd/csrc, names and contents): what a committed profile
+    was taken from - a PMC figure is only quoted for the code it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "qatzip_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(fname, command_has, kernels):
+    """HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction) of the kernels whose names start
+    with one of `kernels`, summed, from the committed rocprofv3 --pmc summary profiles/<fname> (tools/pmc_summary.py) - or
+    None when the file is missing, was taken from other sources than the ones that are running (src_sha256) or from another
+    command.  Never stale: null rather than a number measured on different code."""
+    try:
+        with open(os.path.join(ROOT, "profiles", fname)) as f:
+            pj = json.load(f)
+        if pj.get("src_sha256") != src_sha256() or not all(w in pj.get("command", "") for w in command_has):
+            return None
+        tot = 0
+        for pre in kernels:
+            ks = [k for k in pj["kernels"] if k.startswith(pre)]
+            if not ks:
+                return None
+            tot += pj["kernels"][max(ks, key=lambda k: pj["kernels"][k]["hbm_bytes_fetch_x2"])]["hbm_bytes_fetch_x2"]   # the whole-call launch
+        return tot
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def raw_sweep(ctx, qz, d_src, mb, sizes=(16384, 65536, 131072)):
+    """BASELINE config 3: raw deflate + raw inflate, hw_buff_sz 16 / 64 / 128 KB, data resident in HBM.  Beside the call
+    rates: the kernels' own time by HIP events (K1 with K2 and the CRC in its waves; the inflate kernels), the fraction of
+    the HBM peak their algorithmic bytes (U + C) make of it, and the HBM traffic of the committed PMC passes of this leg
+    (profiles/r4_raw<K>_pmc.json, null when they were taken from other code)."""
     n = mb << 20
     out = {}
     d_c = ctx.alloc(qz.max_deflate_len(n, 16384))
     d_b = ctx.alloc(n + 4096)
-    for hw in (16384, 65536, 131072):
+    for hw in sizes:
         best_c = best_d = None
         for _ in range(2):
+            ctx.k1_stats(reset=True)
             ctx.sync(); t0 = time.perf_counter()
             ctx.deflate_raw_async(view(qz, d_src, 0, n), n, hw, 1, 1, d_c); ctx.sync()
             t1 = time.perf_counter()
             cl = ctx.result()
+            k1_ms, k1_l, _ = ctx.k1_stats()
             t2 = time.perf_counter()
             iu, ol, _ = ctx.inflate_stream(d_c, cl, d_b, hw, want_crc=False)
             t3 = time.perf_counter()
             assert iu == cl and ol == n
-            best_c = min(best_c or 1e9, t1 - t0); best_d = min(best_d or 1e9, t3 - t2)
+            inf = ctx.inflate_timing()
+            if best_c is None or t1 - t0 < best_c:
+                best_c, kc = t1 - t0, k1_ms
+            if best_d is None or t3 - t2 < best_d:
+                best_d, kd = t3 - t2, (inf[3] + inf[2]) if inf[3] > 0 else inf[0]
         k1 = ctx.timing()
-        out["%dK" % (hw >> 10)] = {"compress_GBps": round(n / best_c / 1e9, 2), "decompress_GBps": round(n / best_d / 1e9, 2),
-                                   "ratio": round(cl / n, 4), "lz77_ms_first_batch": round(k1[0], 2)}
+        tag = "%dK" % (hw >> 10)
+        alg = float(n + cl)
+        out[tag] = {"compress_GBps": round(n / best_c / 1e9, 2), "decompress_GBps": round(n / best_d / 1e9, 2),
+                    "ratio": round(cl / n, 4), "lz77_ms_first_batch": round(k1[0], 2),
+                    "deflate_kernel_ms": round(kc, 2), "deflate_frac": round(alg / (kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kc > 0 else None,
+                    "inflate_kernel_ms": round(kd, 2), "inflate_frac": round(alg / (kd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kd > 0 else None,
+                    "deflate_traffic": pmc_traffic("r4_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),), ("qzk_lz77_pull_kernel",)),
+                    "inflate_traffic": pmc_traffic("r4_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),),
+                                                   ("qzk_inflate_spec_kernel", "qzk_lz_resolve_kernel"))}
     assert ctx.crc32(d_b, n) == ctx.crc32(view(qz, d_src, 0, n), n)
     d_c.free(); d_b.free()
     out["bytes_MiB"] = mb
@@ -274,6 +322,7 @@ def lz4_leg(ctx, qz, d_src, mb):
         t0 = time.perf_counter()
         cl, lens = ctx.lz4_compress_frames(view(qz, d_src, 0, n), n, d_c, CHUNK)
         t1 = time.perf_counter()
+        kc = ctx.timing()[3]                                            # the call's kernels, first to last, by HIP events
         offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
         segs = np.zeros(nfr, qz._lib.LZ4SEG_DT)
         segs["in_off"] = offs; segs["out_off"] = np.arange(nfr, dtype=np.int64) * CHUNK; segs["in_len"] = lens; segs["out_cap"] = CHUNK
@@ -281,12 +330,20 @@ def lz4_leg(ctx, qz, d_src, mb):
         t2 = time.perf_counter()
         ctx._chk(ctx.L.qzd_lz4_decompress_frames(ctx.h, d_c.ptr, d_b.ptr, segs.ctypes.data, nfr, res.ctypes.data))
         t3 = time.perf_counter()
+        kd = ctx.timing()[3]
         assert (res["status"] == 0).all() and (res["out_len"] == CHUNK).all()
         best_c = min(best_c or 1e9, t1 - t0); best_d = min(best_d or 1e9, t3 - t2)
     assert ctx.crc32(d_b, n) == ctx.crc32(view(qz, d_src, 0, n), n)
     d_c.free(); d_b.free()
+    alg = float(n + cl)
     return {"bytes_MiB": mb, "compress_GBps": round(n / best_c / 1e9, 2), "decompress_GBps": round(n / best_d / 1e9, 2),
-            "ratio": round(cl / n, 4), "note": "64 KB frames, XXH32 content checksum made and verified in-kernel, host call to host return"}
+            "ratio": round(cl / n, 4),
+            "compress_kernel_ms": round(kc, 2), "compress_frac": round(alg / (kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kc > 0 else None,
+            "decompress_kernel_ms": round(kd, 2), "decompress_frac": round(alg / (kd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kd > 0 else None,
+            "compress_traffic": pmc_traffic("r4_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4c_pull_kernel",)),
+            "decompress_traffic": pmc_traffic("r4_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4d_kernel",)),
+            "note": "64 KB frames, XXH32 content checksum made and verified in-kernel; call rates host call to host return, "
+                    "kernel_ms / frac = (U + C) over the kernels' HIP-event time over the HBM peak"}
 
 
 def sessions_leg(qz, dev, d_src, total, steps):
@@ -613,19 +670,12 @@ def main():
 
     if rank == 0:
         # HBM traffic per K1 launch: PMC counters cannot be read from inside this process; they come from the committed
-        # rocprofv3 --pmc passes of this same command (profiles/r3_pmc.json, tools/pmc_summary.py): FETCH_SIZE and
-        # WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note; quoted only when the
-        # profiled command had the same launch mix (same --mb, same chunks per launch: a device-resident call is ONE launch
-        # of the fused K1+K2+CRC kernel, 65536 chunks for 4 GiB) - null otherwise, never stale.
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r3_pmc.json")) as f:
-                pj = json.load(f)
-            pk = pj["kernels"].get(pj.get("k1_key", ""))
-            if pk and pj.get("bench_mb") == args.mb and pj.get("k1_launch_chunks") == round(k1_chunks / max(k1_launches, 1)):
-                traffic = pk["hbm_bytes_fetch_x2"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # rocprofv3 --pmc passes of this same command (profiles/r4_pmc.json, tools/profile_round.sh + tools/pmc_summary.py:
+        # FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note) and are quoted
+        # only when that file was taken from the sources that are running now (SHA-256 over qatzip_amd/csrc) with this
+        # command's --mb - null otherwise, never stale.
+        traffic = pmc_traffic("r4_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_lz77_pull_kernel",))
+        traffic_dec = pmc_traffic("r4_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_inflate_spec_kernel", "qzk_lz_resolve_kernel"))
         value = 2.0 * raw_total * args.steps / dt / 1e9
         ratio = comp_total / raw_total
         # algorithmic bytes of the K1 launches of the timed region: every input byte read once, every compressed byte
@@ -663,12 +713,15 @@ def main():
         # the decode side's kernels of the last call (phase A + phase B of the two-phase inflate, or the wave-per-segment
         # kernel), by the same rule: algorithmic bytes (compressed bytes read + plain bytes written) / their HIP-event time
         dec_alg = float(comp_len[-1]) + float(call_n[-1])
-        if inf_ms[0] > 0:
-            res["roofline_decode"] = {"bound": "hbm", "kernel": "qzk_inflate_tok_kernel + qzk_lz_resolve_kernel",
-                                      "achieved": round(dec_alg / (inf_ms[0] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(dec_alg / (inf_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                                      "algorithmic_bytes": int(dec_alg), "launch_ms": round(inf_ms[0], 3),
-                                      "of_which_resolve_ms": round(inf_ms[2], 3), "call_MiB": call_n[-1] >> 20}
+        dec_ms = inf_ms[3] + inf_ms[2] if inf_ms[3] > 0 else inf_ms[0]          # phase A + phase B kernels (or the wave-per-segment kernel)
+        if dec_ms > 0:
+            res["roofline_decode"] = {"bound": "hbm", "kernel": "qzk_inflate_spec_kernel<4> (phase A: Huffman decoding, four lanes per segment) + "
+                                                                "qzk_lz_resolve_kernel (phase B: matches)",
+                                      "achieved": round(dec_alg / (dec_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(dec_alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic_dec,
+                                      "algorithmic_bytes": int(dec_alg), "launch_ms": round(dec_ms, 3),
+                                      "phase_A_ms": round(inf_ms[3], 3), "phase_B_ms": round(inf_ms[2], 3),
+                                      "inflate_step_ms_with_host_walk": round(inf_ms[0], 3), "call_MiB": call_n[-1] >> 20}
         res["config"].update(extra)
         if "pcie_h2d_GBps" in extra and "api_compress_GBps" in extra:
             # the host-to-host API against what bounds it: input over the link while the kernels run, output back

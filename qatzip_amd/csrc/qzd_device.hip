@@ -641,7 +641,23 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
      * once and takes its chunks as they land - the pieces of the copy go out behind it and the host raises the launch's
      * watermark (c->h_wm, pinned) as each completes (qzk_wait_input).  No batch boundaries, so no tails but the last one,
      * and the parse runs beside the whole copy instead of beside all but the first batch of it. */
-    const bool stream_in = h_src && fuse && !cdesc && n >= (64ull << 20) && c->h_wm && !getenv("QATZIP_AMD_HOST_BATCHED");
+    /* The launch fills every register file and then WAITS for the copy: that is only safe when the copy needs none of the
+     * compute units and cannot stall behind the host - page-locked source memory moved by a copy engine.  A pageable
+     * source (staged by the runtime piece by piece), a source that is not the caller's pinned memory, or a process that
+     * has switched the copy engines off (HSA_ENABLE_SDMA=0: copies become kernels, which cannot run beside the resident
+     * waves) take the batched pipeline; so does the retry of a call whose launch gave up waiting (c->no_stream_in,
+     * qzd_deflate_raw_from_host). */
+    bool stream_in = h_src && fuse && !cdesc && n >= (64ull << 20) && c->h_wm && !c->no_stream_in && !getenv("QATZIP_AMD_HOST_BATCHED");
+    if (stream_in) {
+        const char *sd = getenv("HSA_ENABLE_SDMA");
+        if (sd && sd[0] == '0') stream_in = false;
+    }
+    if (stream_in) {
+        hipPointerAttribute_t a0, a1;
+        const bool p0 = hipPointerGetAttributes(&a0, h_src) == hipSuccess && a0.type == hipMemoryTypeHost;
+        const bool p1 = p0 && hipPointerGetAttributes(&a1, h_src + n - 1) == hipSuccess && a1.type == hipMemoryTypeHost;
+        if (!p1) { (void)hipGetLastError(); stream_in = false; }     /* (an unregistered pointer is an error to the query: cleared) */
+    }
     if (stream_in) { BATCH = nchunks; first_env = 0; c->h_wm[0] = 0; c->h_wm[1] = 0; }
     /* a launch that waits for its input must hear from the host on every way out of this function: whatever returns
      * early (a HIP error between the launch and the copy) leaves the watermark at "giving up" */
@@ -885,7 +901,19 @@ extern "C" int qzd_deflate_raw_from_host(qzd_ctx *c, const uint8_t *h_src, uint8
     if (rc) return rc;
     rc = qzd_sync(c);
     if (rc) return rc;
-    if (c->h_wm && c->h_wm[1]) { c->h_wm[1] = 0; snprintf(c->err, sizeof(c->err), "the launch waited for its input in vain"); return QZD_ERR_HIP; }
+    /* A launch fed while it runs gives up when its input stops coming for about a second (a wave says so in h_wm[1]) or
+     * when a wave waited in vain for the chunks before its own (overflow bit 1): the copy stalled - a preempted host
+     * thread, a source that was paged out under it.  Nothing is lost but time: the call goes through the batched
+     * pipeline, which waits for nothing. */
+    const bool gave_up = (c->h_wm && c->h_wm[1]) || (*c->h_overflow & 2u);
+    if (gave_up) {
+        if (c->h_wm) c->h_wm[1] = 0;
+        c->no_stream_in = true;
+        rc = deflate_enqueue(c, d_stage, n, chunk_sz, level, last, d_dst, dst_cap, NULL, h_src);
+        if (!rc) rc = qzd_sync(c);
+        c->no_stream_in = false;
+        if (rc) return rc;
+    }
     return qzd_result(c, h_out_len, h_chunk_crc, c->last_nchunks);
 }
 

@@ -53,6 +53,7 @@ struct qzd_ctx {
     uint32_t *d_cdesc; uint32_t cdesc_cap;          /* per-slot descriptors of a coalesced launch (qzd_deflate_slots) */
     uint8_t *d_lane; size_t lane_cap;               /* device-only scratch of the one-chunk-per-lane compress path (K1b) */
     float inf_ms[4];
+    bool no_stream_in;              /* this call is the batched retry of a launch that gave up waiting for its input */
     /* device arrays of the last two-phase inflate (phase A done, phase B still to run): two_phase() / two_phase_resolve() */
     struct { void *segs, *res, *ts, *lits, *seqs, *chains; uint32_t *ord; uint32_t nsegs, K; } tp;
     char err[256];

@@ -3,6 +3,8 @@
 /opt/skills/guides/MI355X_MICROARCH.md prescribes) into profiles/<round>_pmc.json.
 
 usage: tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> <K1 launch chunks> "<profiled command>"
+The summary carries the SHA-256 of the library's sources (bench.src_sha256) at the time it is written - run it before the
+sources change again: bench.py quotes a traffic figure only for the code it was measured on.
 Units: rocprofv3 reports both counters in KiB.  gfx950 correction (guide, §HBM): FETCH_SIZE counts 128-B requests
 as 64 B for wide coalesced streaming reads => x2; calibrated here on qzk_crc_kernel, a pure 16-B/lane streaming read
 whose byte count is known.  For gather-heavy kernels the factor is between 1 and 2; both figures are kept."""
@@ -29,7 +31,10 @@ def main():
     bench_mb = int(cmd.split("--mb")[1].split()[0]) if "--mb" in cmd else 4096
     fetch, nf = load(fd, "FETCH_SIZE")
     write, nw = load(wd, "WRITE_SIZE")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- " + cmd,
+           "src_sha256": bench.src_sha256(),
            "unit": "bytes per launch (average over the launches of the run)", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k[0].startswith("qzk_"):
