@@ -562,7 +562,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
          * takes about half the time one wave needs).  QATZIP_AMD_K1=wide / pull forces one of them. */
         const char *k1 = getenv("QATZIP_AMD_K1");
         const bool force_wide = k1 && k1[0] == 'w', force_pull = k1 && k1[0] == 'p';
-        if (chunk_sz <= 65536 && (force_wide || (!force_pull && nchunks <= c->cus))) {
+        if (chunk_sz <= 65536 && (force_wide || (!force_pull && nchunks <= c->cus + c->cus / 2))) {      /* measured crossover: profiles/r4_k1_crossover.txt */
             if (h_src && n) HIPCHK(c, hipMemcpy((void *)d_src, h_src, n, hipMemcpyHostToDevice));
             return deflate_wide_path(c, d_src, n, chunk_sz, last, d_dst, dst_cap, nchunks, cdesc);
         }

@@ -194,7 +194,14 @@ QZ_DEV void qzx_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, u
         if (4 * i < n) { v = qzk_ld32g_fast(src, coff + 4 * i, src_len); if (4 * i + 4 > n) v &= (1u << (8 * (n - 4 * i))) - 1u; }
         L->in32[i] = v;
     }
-    for (uint32_t i = tid; i < 32768; i += QZX_W) ((uint32_t *)head)[i] = 0;
+    {   /* 16 bytes a store, one running pointer (the unrolled form kept 32 addresses alive: 64 registers, spilled - the
+         * kernel's 284 bytes of scratch in round 3) */
+        typedef uint32_t qzx_u32x4 __attribute__((vector_size(16)));
+        const qzx_u32x4 z = {0, 0, 0, 0};
+        qzx_u32x4 *hp = (qzx_u32x4 *)head + tid;
+#pragma unroll 1
+        for (uint32_t i = tid; i < 65536 * 2 / 16; i += QZX_W, hp += QZX_W) *hp = z;
+    }
     qzx_drain_stores();
     uint32_t ws = 0, nsym = 0, nfull = 0, cur_bstart = 0, can_store = 0;      /* workgroup-uniform */
     mt->bstart[0] = 0;

@@ -14,7 +14,7 @@ base = datagen.gen("silesia", 96 << 20, 20250523)
 ctx = qatzip_amd.Context(0)
 d_src = ctx.alloc(base.size); d_src.upload(base)
 d_c = ctx.alloc(qatzip_amd.max_deflate_len(base.size, 65536))
-for mb in (4, 8, 16, 24, 32, 40, 48, 64, 96):
+for mb in (4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 64, 96):
     n = mb << 20
     row = []
     for k in ("pull", "wide"):
