@@ -66,6 +66,11 @@ def sw_compress(fmt: int, src: bytes, hw: int = 65536, level: int = 1, last: int
         out = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, xfl, 3]) + raw
         return out + (struct.pack("<II", crc, len(src) & 0xffffffff) if last else b"")
     if fmt == FMT_GZIP_EXT:
+        if libz_pinned():
+            # the whole member - header with its 'Q','Z' extra field included - written by libz itself through its C API, driven
+            # as qzDeflateSWCompress drives it (libz_gzip_ext below); the typed-out header that follows is what it is equal to
+            # (tests/test_oracle.py::test_gzip_ext_members_written_by_libz_itself) and what runs where libz.so.1 is missing
+            return libz_gzip_ext(src, hw, level, last)
         sizes = struct.pack("<II", len(src), len(raw)) if last else b"\0" * 8
         out = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, xfl, 255, 12, 0]) + b"QZ\x08\x00" + sizes + raw
         return out + (struct.pack("<II", crc, len(src) & 0xffffffff) if last else b"")
@@ -165,3 +170,82 @@ def lz4_compress_block(src: bytes, cap: int) -> bytes:
     dst = ctypes.create_string_buffer(max(cap, 1))
     r = lib.LZ4_compress_default(src, dst, len(src), cap)
     return dst.raw[:r]
+
+
+# ---------------------------------------------------------------- libz itself, through its C API (ctypes)
+# The functions above go through CPython's zlib module, which cannot hand deflate() a gzip header of the caller's: the 24
+# bytes in front of a GZIP_EXT stream were typed out here.  This drives the system libz exactly as qzDeflateSWCompress does
+# (src/qatzip_sw.c:61-75, 147-166, 178-253): deflateInit2_(level, Z_DEFLATED, 15 + 16, MAX_MEM_LEVEL, Z_DEFAULT_STRATEGY),
+# deflateSetHeader() with the 12-byte 'Q','Z' extra field and os = 255, one deflate(Z_FULL_FLUSH) per hw_buff_sz chunk
+# into the caller's whole destination, deflate(Z_FINISH) on the last, then the two size fields patched into the header
+# zlib wrote - so that zlib writes every byte of the member, header included.
+class _ZStream(ctypes.Structure):
+    _fields_ = [("next_in", ctypes.c_void_p), ("avail_in", ctypes.c_uint), ("total_in", ctypes.c_ulong),
+                ("next_out", ctypes.c_void_p), ("avail_out", ctypes.c_uint), ("total_out", ctypes.c_ulong),
+                ("msg", ctypes.c_char_p), ("state", ctypes.c_void_p), ("zalloc", ctypes.c_void_p), ("zfree", ctypes.c_void_p),
+                ("opaque", ctypes.c_void_p), ("data_type", ctypes.c_int), ("adler", ctypes.c_ulong), ("reserved", ctypes.c_ulong)]
+
+
+class _GzHeader(ctypes.Structure):
+    _fields_ = [("text", ctypes.c_int), ("time", ctypes.c_ulong), ("xflags", ctypes.c_int), ("os", ctypes.c_int),
+                ("extra", ctypes.c_void_p), ("extra_len", ctypes.c_uint), ("extra_max", ctypes.c_uint),
+                ("name", ctypes.c_void_p), ("name_max", ctypes.c_uint), ("comment", ctypes.c_void_p), ("comm_max", ctypes.c_uint),
+                ("hcrc", ctypes.c_int), ("done", ctypes.c_int)]
+
+
+_libz = None
+
+
+def libz():
+    global _libz
+    if _libz is None:
+        try:
+            lib = ctypes.CDLL("libz.so.1")
+            lib.zlibVersion.restype = ctypes.c_char_p
+            lib.deflateInit2_.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_char_p, ctypes.c_int]
+            lib.deflateSetHeader.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            lib.deflate.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            lib.deflateEnd.argtypes = [ctypes.c_void_p]
+            _libz = lib
+        except OSError:
+            _libz = False
+    return _libz or None
+
+
+def libz_pinned():
+    lib = libz()
+    return bool(lib) and lib.zlibVersion() == b"1.2.11"
+
+
+def libz_gzip_ext(src: bytes, hw: int = 65536, level: int = 1, last: int = 1) -> bytes:
+    """one qzDeflateSWCompress(DEFLATE_GZIP_EXT) call: every byte, the header included, written by libz"""
+    lib = libz()
+    Z_DEFLATED, Z_FULL_FLUSH, Z_FINISH, Z_OK, Z_STREAM_END = 8, 3, 4, 0, 1
+    strm = _ZStream()
+    ver = lib.zlibVersion()
+    assert lib.deflateInit2_(ctypes.byref(strm), level, Z_DEFLATED, 15 + 16, 9, 0, ver, ctypes.sizeof(_ZStream)) == Z_OK
+    extra = ctypes.create_string_buffer(b"QZ" + struct.pack("<HII", 8, 0, 0), 12)      # g_extra_field: 'Q','Z', x2_len 8, src_sz 0, dest_sz 0
+    hdr = _GzHeader()                                                                 # gen_qatzip_hdr: zeroed, extra, os = 255
+    hdr.extra = ctypes.cast(extra, ctypes.c_void_p); hdr.extra_len = 12; hdr.os = 255
+    assert lib.deflateSetHeader(ctypes.byref(strm), ctypes.byref(hdr)) == Z_OK
+    cap = len(src) * 9 // 8 + 1024 * (len(src) // hw + 2)
+    dst = ctypes.create_string_buffer(cap)
+    inb = ctypes.create_string_buffer(src, max(len(src), 1))
+    pos, n = 0, len(src)
+    while True:
+        send = min(hw, n - pos)
+        strm.next_in = ctypes.cast(ctypes.byref(inb, pos), ctypes.c_void_p); strm.avail_in = send
+        strm.next_out = ctypes.cast(ctypes.byref(dst, strm.total_out), ctypes.c_void_p); strm.avail_out = cap - strm.total_out
+        pos += send
+        fin = pos == n and last == 1
+        rc = lib.deflate(ctypes.byref(strm), Z_FINISH if fin else Z_FULL_FLUSH)
+        assert rc == (Z_STREAM_END if fin else Z_OK) and strm.avail_in == 0, rc
+        if pos == n:
+            break
+    out = bytearray(dst.raw[:strm.total_out])
+    if last == 1:                                                                     # src/qatzip_sw.c:238-243
+        out[16:20] = struct.pack("<I", strm.total_in & 0xffffffff)
+        out[20:24] = struct.pack("<I", (strm.total_out - 24 - 8) & 0xffffffff)
+    lib.deflateEnd(ctypes.byref(strm))
+    return bytes(out)

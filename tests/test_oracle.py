@@ -128,3 +128,26 @@ def test_live_fuzz_against_system_zlib():
             for fmt, rf in (("GZIP", R.FMT_GZIP), ("GZIP_EXT", R.FMT_GZIP_EXT), ("ZLIB", R.FMT_ZLIB)):
                 assert O.sw_compress(fmt, src, hw, lvl)[2] == R.sw_compress(rf, src, hw, lvl), (kind, hw, lvl, fmt)
             assert R.sw_compress(R.FMT_GZIP, src, hw, lvl) == R.gzip_stream_check(src, hw, lvl)
+
+
+def test_gzip_ext_members_written_by_libz_itself():
+    """the pin, tightened (round 4): the goldens' GZIP_EXT members go through CPython's zlib module, which cannot pass deflate()
+    a gzip header, so tests/refcalls.py typed the 24 header bytes out.  Here the system libz 1.2.11 writes the whole member
+    through its C API exactly as qzDeflateSWCompress drives it (deflateSetHeader with the 'Q','Z' extra field, os 255,
+    src/qatzip_sw.c:61-75,158-166) - and it is, byte for byte, the typed-out form and the oracle's."""
+    import refcalls as R
+    if not R.libz_pinned():
+        pytest.skip("needs the system libz at the pinned version (build container)")
+    n_cases = 0
+    for kind in datagen.KINDS:
+        for n, hw, level, last in ((0, 65536, 1, 1), (1, 65536, 1, 1), (70000, 65536, 1, 1), (200000, 65536, 1, 1), (200000, 16384, 1, 0),
+                                   (300001, 131072, 6, 1), (65536, 65536, 9, 1), (131072, 65536, 3, 0)):
+            if kind == "lzmix" and n > 70000:
+                continue
+            src = datagen.gen_bytes(kind, n, 31 + n_cases)
+            got = R.libz_gzip_ext(src, hw, level, last)
+            assert got == R.sw_compress(R.FMT_GZIP_EXT, src, hw, level, last), (kind, n, hw, level, last)
+            rc, used, out, _ = O.sw_compress("GZIP_EXT", src, hw, level, last=last)
+            assert rc == 0 and used == n and out == got, (kind, n, hw, level, last)
+            n_cases += 1
+    assert n_cases > 50
