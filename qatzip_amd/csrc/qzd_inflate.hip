@@ -31,32 +31,46 @@
 #include "qzk_inflate_spec.h"
 #include "qzk_checksum.h"
 
-/* Which kernel for how many segments (round 4, profiles/r4_inflate_crossover.txt; 64 KB segments of the bench data): one
- * wave per segment (K3) takes ~12.5 ms for anything up to ~1000 segments and grows from there (17 ms at 4096, 27 at
- * 8192: the CUs' scalar units); the two phases with four lanes per segment take 10-12 ms from 256 segments to 32768 (a
- * lane's chain through its quarter of a segment) - they win from ~1000 segments on.  Segments of 128 KB: twice the chain,
- * 24 ms either way at 2048 segments, 30 against 55 ms at 8192. */
+/* Which kernel for how many segments (round 4, profiles/r4_inflate_crossover.txt; segments of the bench data).
+ * With a compressed-length hint per segment the two phases with K lanes per segment (qzk_inflate_spec.h) win at every size
+ * measured, from one megabyte (16 segments of 64 KB: 4.7 against 9.3 ms) to four gigabytes: a segment's serial chain is cut
+ * in K, and one wave per segment (K3) takes ~9-12 ms for a 64 KB segment however few there are.  Without hints (a foreign
+ * stream's flush points, count-only passes) phase A is one lane per segment, and that wins from ~1000 segments on (K3: 17 ms
+ * at 4096 segments of 64 KB, 27 at 8192 - the CUs' scalar units; 128 KB segments: 24 ms either way at 2048, 30 against 55 at 8192). */
 #define QZD_LANE_MIN_SEGS 1024u
 #define QZD_LANE_MIN_SEGS_BIG 2048u
 #define QZD_LANE_MIN(seg_bytes) ((seg_bytes) <= 65536u + 64u ? QZD_LANE_MIN_SEGS : QZD_LANE_MIN_SEGS_BIG)
 #define QZD_LANE_SEGS_PER_WAVE 16u
-/* lanes per segment of phase A (QATZIP_AMD_INFLATE_K = 1, 2, 4, 8 overrides; 1 = the serial phase A).  The LDS seats
- * sixteen segments' tables per wave, so four lanes per segment fill the wave: the lanes share the tables, start at evenly
- * spaced bits and fall into step with each other (qzk_inflate_spec.h) */
+/* lanes per segment of phase A (QATZIP_AMD_INFLATE_K = 1, 2, 4, 8, 16, 32 overrides; 1 = the serial phase A).  The lanes
+ * of a segment share its tables in LDS, start at evenly spaced bits and fall into step with each other.  How many: the chip
+ * seats 2048 waves of this kernel, and a launch that does not fill it ends with its longest lane - so up to 8192 segments
+ * sixteen lanes each (1 GiB of 128 KB segments: 17.1 -> 14.6 ms; 256 MiB of 64 KB: 11.2 -> 8.6; 16 MiB: 5.7 -> 4.1), eight up
+ * to 16384, four beyond (a full chip is better served by fewer lanes falling into step).  Exceptions, both measured:
+ * segments above 256 KB hold so many blocks that sixteen pieces per block outgrow the chain (QZK_CHAIN_MAXEL) and come back
+ * through the serial kernel (1 GiB of 512 KB: 89 ms with eight lanes, 221 with sixteen); segments of 16 KB and less give
+ * sixteen lanes under a hundred bytes each. */
 #define QZD_SPEC_LANES 4u
-/* up to half a launch of four-lane waves (1024 of them, one per SIMD) the phase ends with its longest chain, and eight lanes
- * per segment make that a tenth shorter (profiles/r4_inflate_crossover.txt); a full chip is better served by four */
 #define QZD_SPEC_LANES_FEW 8u
 #define QZD_SPEC_FEW_SEGS 16384u
+#define QZD_SPEC_LANES_FEWER 16u
+#define QZD_SPEC_FEWER_SEGS 8192u
 static uint32_t spec_lanes(const qzk_infseg *hs, uint32_t nsegs)
 {
-    uint32_t K = nsegs <= QZD_SPEC_FEW_SEGS ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
+    uint32_t K = nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 16384u + 64u && hs[0].out_cap <= 262144u + 64u ? QZD_SPEC_LANES_FEWER
+               : nsegs <= QZD_SPEC_FEW_SEGS ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
     const char *ke = getenv("QATZIP_AMD_INFLATE_K");
-    if (ke) { int v = atoi(ke); if (v == 1 || v == 2 || v == 4 || v == 8) K = (uint32_t)v; }
+    if (ke) { int v = atoi(ke); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) K = (uint32_t)v; }
     /* it needs a compressed-length hint (qzk_infseg.pad) and segments that write output and begin with no history */
     for (uint32_t i = 0; i < nsegs && K > 1; i++)
         if ((hs[i].flags & (QZK_INF_COUNT_ONLY | QZK_INF_THROUGH_FLUSH)) || hs[i].pad == 0) K = 1;
     return K;
+}
+/* two phases or a wave per segment? (QATZIP_AMD_INFLATE = lane / wave overrides) */
+static bool use_lanes(uint32_t K, uint32_t nsegs, uint32_t seg_bytes)
+{
+    const char *force = getenv("QATZIP_AMD_INFLATE");
+    if (force) return force[0] == 'l';
+    return K > 1 || nsegs >= QZD_LANE_MIN(seg_bytes);
 }
 #define QZD_SO_PARTS 8u             /* output ranges a streamed decode is resolved and sent in */
 
@@ -185,7 +199,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         if (ov && atoi(ov) > 0) over = (uint32_t)atoi(ov);
 #define QZD_SPEC_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_spec_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
                                              ts_d, lit_d, seq_d, ch_d, rec_d, epoch, over)
-        if (K == 2) QZD_SPEC_LAUNCH(2); else if (K == 4) QZD_SPEC_LAUNCH(4); else QZD_SPEC_LAUNCH(8);
+        if (K == 2) QZD_SPEC_LAUNCH(2); else if (K == 4) QZD_SPEC_LAUNCH(4); else if (K == 16) QZD_SPEC_LAUNCH(16); else if (K == 32) QZD_SPEC_LAUNCH(32); else QZD_SPEC_LAUNCH(8);
 #undef QZD_SPEC_LAUNCH
         /* what that kernel hands back (QZK_INF_ESPEC: a sub-stream outgrew its scratch, too many pieces) goes through the
          * serial phase A, into the segment's first sub-stream - which is sized for a whole segment */
@@ -317,11 +331,11 @@ extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *
     const qzk_infseg *hs = (const qzk_infseg *)h_segs;
     /* few segments: one wave each; thousands: the two-phase path (the wave-per-segment kernel is bound by the CU's
      * scalar unit, the lane kernels spread the serial work over the vector lanes) */
-    const char *force = getenv("QATZIP_AMD_INFLATE");
-    const bool lanes = force ? force[0] == 'l' : nsegs >= QZD_LANE_MIN(hs[0].out_cap);
+    const uint32_t K = spec_lanes(hs, nsegs);
+    const bool lanes = use_lanes(K, nsegs, hs[0].out_cap);
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
     if (lanes) {
-        int rc = two_phase(c, d_comp, d_out, hs, nsegs, (qzk_infres *)h_res, spec_lanes(hs, nsegs), st);
+        int rc = two_phase(c, d_comp, d_out, hs, nsegs, (qzk_infres *)h_res, K, st);
         if (rc) return rc;
     } else {
         const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
@@ -545,7 +559,7 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
      * boundary (00 00 FF FF inside compressed data or a stored block) simply drops out - gives each real segment its
      * output offset, and phase B writes only those.  One pass whatever the candidates look like. --- */
     const char *force_path = getenv("QATZIP_AMD_INFLATE");
-    const bool lanes = force_path ? force_path[0] == 'l' : ns >= QZD_LANE_MIN(seg_hint ? seg_hint : 65536u);
+    const bool lanes = force_path ? force_path[0] == 'l' : true;   /* every candidate carries a length hint: K lanes per segment at any count */
     {
         if (scan_ok && seg_hint && ns > 1 && lanes) {
             auto clen = [&](uint32_t k) { return (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k]; };

@@ -171,7 +171,7 @@ typedef struct { uint64_t lit_off; uint64_t seq_off; } qzk_tokseg;             /
 #define QZK_INF_ESPEC (-6)         /* speculative phase A could not finish this segment: decode it serially */
 #define QZK_PIECE_RAW 0xffffffffu  /* qzk_chain_el.sub: not a sub-stream but seq_count stored bytes at input offset seq_first */
 typedef struct { uint32_t sub, seq_first, seq_count, lit_first, lrun_skip; } qzk_chain_el;
-#define QZK_CHAIN_MAXEL 64        /* pieces per segment (K per Huffman block of the segment, and per round that continues one) */
+#define QZK_CHAIN_MAXEL 160       /* pieces per segment (K per Huffman block of the segment, and per round that continues one) */
 typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chain;
 /* scratch a segment needs: literals <= out_cap (+ staging slack), sequences <= out_cap / 3 (+ tail) */
 #define QZK_TOK_LITCAP(out_cap) ((((uint64_t)(out_cap) + 31) & ~(uint64_t)31) + 32)
@@ -261,10 +261,135 @@ typedef struct {
     bool through;
 } qzk_lane_st;
 
+/* ---- the block header and its tables, without memory on the way (round 4) ----
+ * Round 3 kept a block's code lengths, counts and first codes in the segment's record in device memory and built the tables
+ * from there: a store and a load per symbol, each a round trip, 1 M clocks per header with one lane of a group at work -
+ * 13-21 % of a wave's time once the decode itself had become faster (profiles/r4_phaseA_timeline.txt).  Now everything a
+ * header needs lives in the lane's own LDS and registers:
+ *   - the code-length code (19 symbols, <= 7 bits) is decoded from registers: its limits by length, its symbols in
+ *     canonical order five bits each - no table;
+ *   - the code lengths go, four bits each, into the SIDE region (the literals 0..255: 128 bytes, where the distance root
+ *     will stand afterwards) and, for the symbols from 256 on (30 literal/length symbols, every distance symbol), into
+ *     four registers;
+ *   - counts, first codes, list offsets and running ranks are sixteen 16-bit fields in four registers each (qzk_f16);
+ *   - the literal/length root and the long-literal pool are filled straight from there (the pool stands in the side
+ *     region's second half, which holds no lengths), then the distance root over the literals' lengths, which are done with.
+ * Device memory is only WRITTEN (the sorted symbol lists and ranges the long-code paths of other lanes and kernels read). */
+typedef struct { uint64_t a, b, c, d; } qzk_f16;                  /* sixteen 16-bit fields */
+QZ_DEV uint32_t qzk_f16_get(const qzk_f16 *f, uint32_t l)
+{
+    const uint64_t w = l < 4 ? f->a : l < 8 ? f->b : l < 12 ? f->c : f->d;
+    return (uint32_t)(w >> (16u * (l & 3u))) & 0xffffu;
+}
+QZ_DEV void qzk_f16_add(qzk_f16 *f, uint32_t l, uint32_t v)
+{
+    const uint64_t x = (uint64_t)v << (16u * (l & 3u));
+    f->a += l < 4 ? x : 0; f->b += (l >= 4 && l < 8) ? x : 0; f->c += (l >= 8 && l < 12) ? x : 0; f->d += l >= 12 ? x : 0;
+}
+typedef struct { uint64_t w0, w1, w2, w3; } qzk_tail64;           /* the code lengths of symbols 256..319, four bits each */
+QZ_DEV uint32_t qzk_tail_get(const qzk_tail64 *t, uint32_t i)      /* i = symbol - 256 */
+{
+    const uint64_t w = i < 16 ? t->w0 : i < 32 ? t->w1 : i < 48 ? t->w2 : t->w3;
+    return (uint32_t)(w >> (4u * (i & 15u))) & 15u;
+}
+QZ_DEV void qzk_tail_put(qzk_tail64 *t, uint32_t i, uint32_t v)
+{
+    const uint64_t x = (uint64_t)v << (4u * (i & 15u));
+    t->w0 |= i < 16 ? x : 0; t->w1 |= (i >= 16 && i < 32) ? x : 0; t->w2 |= (i >= 32 && i < 48) ? x : 0; t->w3 |= i >= 48 ? x : 0;
+}
+/* code length of literal/length-or-distance symbol i of the block being read (0..319) */
+QZ_DEV uint32_t qzk_hlen(const uint8_t *side, const qzk_tail64 *t, uint32_t i)
+{
+    return i < 256 ? ((uint32_t)side[i >> 1] >> (4u * (i & 1u))) & 15u : qzk_tail_get(t, i - 256);
+}
+
+/* counts -> first codes and list offsets (canonical order); returns 0 ok, 1 incomplete, -1 over-subscribed */
+QZ_DEV int qzk_canon(const qzk_f16 *cnt, qzk_f16 *first, qzk_f16 *index, int *maxlen_out, uint32_t *nsyms)
+{
+    int left = 1, maxlen = 0; uint32_t code = 0, off = 0;
+    first->a = first->b = first->c = first->d = 0; index->a = index->b = index->c = index->d = 0;
+    for (uint32_t l = 1; l <= 15; l++) {
+        const uint32_t c = qzk_f16_get(cnt, l);
+        left <<= 1; left -= (int)c;
+        if (left < 0) return -1;
+        if (c) maxlen = (int)l;
+        qzk_f16_add(first, l, code & 0xffffu); qzk_f16_add(index, l, off);
+        code = (code + c) << 1; off += c;
+    }
+    *maxlen_out = maxlen; *nsyms = off;
+    return left > 0 ? 1 : 0;
+}
+/* the ranges other lanes (and the careful paths) read from the segment's record: stores only */
+QZ_DEV void qzk_ranges_out(const qzk_f16 *cnt, const qzk_f16 *first, const qzk_f16 *index, uint16_t *count_, uint16_t *first_, uint16_t *index_)
+{
+    for (uint32_t l = 0; l <= 15; l++) { count_[l] = (uint16_t)(l ? qzk_f16_get(cnt, l) : 0); first_[l] = (uint16_t)qzk_f16_get(first, l); index_[l] = (uint16_t)qzk_f16_get(index, l); }
+}
+
+/* literal/length tables of a block from its code lengths (side region + tail registers, or the fixed code's when side == NULL) */
+QZ_DEV int qzk_build_litlen(const uint8_t *side, const qzk_tail64 *tl, uint32_t n, uint16_t *lroot, uint8_t *pool, qzk_inf_tab *T,
+                            int *lmax, uint32_t *lbase)
+{
+#define QZK_LL_LEN(i) (side ? qzk_hlen(side, tl, (i)) : ((i) < 144 ? 8u : (i) < 256 ? 9u : (i) < 280 ? 7u : 8u))
+    qzk_f16 cnt, first, index, next;
+    cnt.a = cnt.b = cnt.c = cnt.d = 0; next.a = next.b = next.c = next.d = 0;
+    for (uint32_t i = 0; i < n; i++) { const uint32_t l = QZK_LL_LEN(i); if (l) qzk_f16_add(&cnt, l, 1); }
+    uint32_t nsyms;
+    const int r = qzk_canon(&cnt, &first, &index, lmax, &nsyms);
+    if (r < 0) return r;
+    for (int i = 0; i < (1 << QZK_LLROOT); i += 2) *(uint32_t *)(lroot + i) = 0;
+    for (int i = 0; i < QZK_LPOOL_N; i += 4) *(uint32_t *)(pool + i) = 0xffffffffu;
+    const uint32_t long_base = QZK_LLROOT < 15 ? qzk_f16_get(&index, QZK_LLROOT + 1) : nsyms;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t l = QZK_LL_LEN(i);
+        if (!l) continue;
+        const uint32_t rank = qzk_f16_get(&next, l), at = qzk_f16_get(&index, l) + rank;
+        qzk_f16_add(&next, l, 1);
+        T->lsorted[at] = (uint16_t)i;
+        if (l <= (uint32_t)QZK_LLROOT) {
+            const uint32_t rv = qzk_rev(qzk_f16_get(&first, l) + rank, (int)l);
+            for (uint32_t f = rv; f < (1u << QZK_LLROOT); f += 1u << l) lroot[f] = (uint16_t)((i << 4) | l);
+        } else {
+            const uint32_t pr = at - long_base;
+            if (pr < (uint32_t)QZK_LPOOL_N && i < 255) pool[pr] = (uint8_t)i;
+        }
+    }
+    qzk_ranges_out(&cnt, &first, &index, T->lcount, T->lfirst, T->lindex);
+    *lbase = long_base;
+    return r;
+#undef QZK_LL_LEN
+}
+/* distance tables (root: u8 entries sym << 3 | len); the lengths of the ndist symbols from symbol `from` on, or all 5 (fixed) */
+QZ_DEV int qzk_build_dist(const qzk_tail64 *tl, uint32_t from, uint32_t n, uint8_t *d8, qzk_inf_tab *T, int *dmax)
+{
+#define QZK_D_LEN(k) (tl ? qzk_tail_get(tl, (from) + (k) - 256u) : 5u)
+    qzk_f16 cnt, first, index, next;
+    cnt.a = cnt.b = cnt.c = cnt.d = 0; next.a = next.b = next.c = next.d = 0;
+    for (uint32_t k = 0; k < n; k++) { const uint32_t l = QZK_D_LEN(k); if (l) qzk_f16_add(&cnt, l, 1); }
+    uint32_t nsyms;
+    const int r = qzk_canon(&cnt, &first, &index, dmax, &nsyms);
+    if (r < 0) return r;
+    for (int i = 0; i < (1 << QZK_LDROOT); i += 4) *(uint32_t *)(d8 + i) = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t l = QZK_D_LEN(k);
+        if (!l) continue;
+        const uint32_t rank = qzk_f16_get(&next, l);
+        qzk_f16_add(&next, l, 1);
+        T->dsorted[qzk_f16_get(&index, l) + rank] = (uint16_t)k;
+        if (l <= (uint32_t)QZK_LDROOT) {
+            const uint32_t rv = qzk_rev(qzk_f16_get(&first, l) + rank, (int)l);
+            for (uint32_t f = rv; f < (1u << QZK_LDROOT); f += 1u << l) d8[f] = (uint8_t)((k << 3) | l);
+        }
+    }
+    qzk_ranges_out(&cnt, &first, &index, T->dcount, T->dfirst, T->dindex);
+    return r;
+#undef QZK_D_LEN
+}
+
 /* one block header: stored -> RAW (or the end of the segment), fixed / dynamic -> tables built, SYM */
 QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uint16_t *droot)
 {
     qzk_lbits *b = &S->b;
+    uint8_t *const side = (uint8_t *)droot;
     S->state = QZK_LS_DONE; S->status = QZK_INF_EDATA;       /* every early return below is a failure */
     qzk_lrefill(b);
     if (b->bc < 3) { S->status = QZK_INF_EIN; return; }
@@ -293,11 +418,8 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
     }
     if (type == 3) return;
     if (type == 1) {
-        for (int i = 0; i < 288; i++) T->lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-        qzk_lane_build(T->lens, 288, lroot, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &S->lmax, QZK_LPOOL(droot));
-        for (int i = 0; i < 30; i++) T->lens[i] = 5;
-        qzk_lane_build<true>(T->lens, 30, droot, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &S->dmax);
-        S->lbase = T->lindex[QZK_LLROOT + 1];
+        qzk_build_litlen((const uint8_t *)0, (const qzk_tail64 *)0, 288, lroot, QZK_LPOOL(droot), T, &S->lmax, &S->lbase);
+        qzk_build_dist((const qzk_tail64 *)0, 256, 30, QZK_DROOT8(droot), T, &S->dmax);
         S->state = QZK_LS_SYM;
         return;
     }
@@ -307,7 +429,8 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
     const uint32_t ndist = QZK_GETBITS(b, 5) + 1; QZK_DROP(b, 5);
     const uint32_t ncode = QZK_GETBITS(b, 4) + 4; QZK_DROP(b, 4);
     if (nlen > 286 || ndist > 30) return;
-    for (int i = 0; i < 19; i++) T->lens[i] = 0;
+    /* the code-length code: lengths of its 19 symbols (three bits each, in the format's order), canonical code in registers */
+    uint64_t cl = 0;                                           /* symbol s: bits 3 s .. 3 s + 2 */
     for (uint32_t i = 0; i < ncode; i++) {
         qzk_lrefill(b);
         if (b->bc < 3) { S->status = QZK_INF_EIN; return; }
@@ -315,33 +438,69 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
         const uint32_t ord = i < 6 ? ((16u | 17u << 5 | 18u << 10 | 0u << 15 | 8u << 20 | 7u << 25) >> (5 * i)) & 31
                            : i < 12 ? ((9u | 6u << 5 | 10u << 10 | 5u << 15 | 11u << 20 | 4u << 25) >> (5 * (i - 6))) & 31
                            : i < 18 ? ((12u | 3u << 5 | 13u << 10 | 2u << 15 | 14u << 20 | 1u << 25) >> (5 * (i - 12))) & 31 : 15u;
-        T->lens[ord] = (uint8_t)v;
+        cl |= (uint64_t)v << (3u * ord);
     }
-    int clmax = 0;
-    /* the 7-bit code-length code borrows the distance-table arrays */
-    if (qzk_lane_build(T->lens, 19, droot, QZK_CLROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &clmax) != 0) return;
-    uint32_t i = 0, prev = 0;
-    uint8_t *L = T->lens;               /* final place: [0, nlen) lit/len, [nlen, nlen+ndist) distance */
-    while (i < nlen + ndist) {
-        qzk_lrefill(b);
-        const int sym = qzk_ldecode(b, droot, QZK_CLROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, clmax);
-        if (sym < 0) return;
-        if (sym < 16) { L[i++] = (uint8_t)sym; prev = (uint32_t)sym; continue; }
-        uint32_t rep, val;
-        if (sym == 16) { if (i == 0 || b->bc < 2) return; val = prev; rep = 3 + QZK_GETBITS(b, 2); QZK_DROP(b, 2); }
-        else if (sym == 17) { if (b->bc < 3) return; val = 0; rep = 3 + QZK_GETBITS(b, 3); QZK_DROP(b, 3); }
-        else { if (b->bc < 7) return; val = 0; rep = 11 + QZK_GETBITS(b, 7); QZK_DROP(b, 7); }
-        if (i + rep > nlen + ndist) return;
-        for (uint32_t k = 0; k < rep; k++) L[i + k] = (uint8_t)val;
-        prev = val; i += rep;
+    uint64_t climit = 0, cld = 0;                               /* per length l = 1..7: limit of its codes left-justified to 7 bits (8-bit
+                                                                 * fields: 128 fits), list offset - first code (mod 256) */
+    uint64_t cls0 = 0, cls1 = 0;                                /* the symbols in canonical order, five bits each, twelve a word */
+    {
+        uint32_t code = 0, off = 0; int left = 1;
+        for (uint32_t l = 1; l <= 7; l++) {
+            uint32_t c = 0;
+            for (uint32_t sidx = 0; sidx < 19; sidx++) {
+                if (((uint32_t)(cl >> (3u * sidx)) & 7u) == l) {
+                    const uint32_t at = off + c;
+                    if (at < 12) cls0 |= (uint64_t)sidx << (5u * at); else cls1 |= (uint64_t)sidx << (5u * (at - 12));
+                    c++;
+                }
+            }
+            left <<= 1; left -= (int)c;
+            if (left < 0) return;
+            climit |= (uint64_t)((code + c) << (7u - l)) << (8u * (l - 1));
+            cld |= (uint64_t)((off - code) & 0xffu) << (8u * (l - 1));
+            code = (code + c) << 1; off += c;
+        }
+        if (left != 0) return;                                  /* the code-length code must be complete */
     }
-    if (L[256] == 0) return;
-    /* (the code-length code's root stood in the side region: both builds below clear their part of it) */
-    int r = qzk_lane_build(L, (int)nlen, lroot, QZK_LLROOT, T->lsorted, T->lcount, T->lfirst, T->lindex, &S->lmax, QZK_LPOOL(droot));
+    qzk_tail64 tl; tl.w0 = tl.w1 = tl.w2 = tl.w3 = 0;
+    {
+        uint32_t i = 0, prev = 0, acc = 0;                      /* acc: the nibbles of the current group of eight literal symbols */
+        while (i < nlen + ndist) {
+            qzk_lrefill(b);
+            if (b->bc < 7 && !(b->pos >= b->end)) return;
+            /* one code-length symbol: the code's length is 1 + the number of limits at or below the next 7 bits read MSB first */
+            const uint32_t V = qzk_rev((uint32_t)b->bb & 0x7fu, 7);
+            uint32_t n7 = 0;
+            for (uint32_t l = 1; l <= 6; l++) n7 += V >= ((uint32_t)(climit >> (8u * (l - 1))) & 0xffu) ? 1u : 0u;
+            const uint32_t l7 = 1 + n7;
+            if (V >= ((uint32_t)(climit >> 48) & 0xffu) || (int)l7 > b->bc) return;
+            const uint32_t ci = ((V >> (7u - l7)) + ((uint32_t)(cld >> (8u * (l7 - 1))) & 0xffu)) & 0xffu;
+            if (ci >= 19) return;
+            const uint32_t sym = (uint32_t)((ci < 12 ? cls0 >> (5u * ci) : cls1 >> (5u * (ci - 12))) & 31u);
+            QZK_DROP(b, l7);
+            uint32_t rep = 1, val = sym;
+            if (sym >= 16) {
+                if (sym == 16) { if (i == 0 || b->bc < 2) return; val = prev; rep = 3 + QZK_GETBITS(b, 2); QZK_DROP(b, 2); }
+                else if (sym == 17) { if (b->bc < 3) return; val = 0; rep = 3 + QZK_GETBITS(b, 3); QZK_DROP(b, 3); }
+                else { if (b->bc < 7) return; val = 0; rep = 11 + QZK_GETBITS(b, 7); QZK_DROP(b, 7); }
+                if (i + rep > nlen + ndist) return;
+            }
+            for (uint32_t k = 0; k < rep; k++, i++) {
+                if (i < 256) {
+                    acc |= val << (4u * (i & 7u));
+                    if ((i & 7u) == 7u) { *(uint32_t *)(side + (i >> 3) * 4) = acc; acc = 0; }
+                } else qzk_tail_put(&tl, i - 256, val);
+            }
+            prev = val;
+        }
+        /* (nlen >= 257: the literals' last group of eight was stored when symbol 255 came) */
+    }
+    if (qzk_tail_get(&tl, 0) == 0) return;                      /* END_BLOCK must have a code */
+    int r = qzk_build_litlen(side, &tl, nlen, lroot, QZK_LPOOL(droot), T, &S->lmax, &S->lbase);
     if (r < 0 || (r > 0 && S->lmax != 1)) return;
-    r = qzk_lane_build<true>(L + nlen, (int)ndist, droot, QZK_LDROOT, T->dsorted, T->dcount, T->dfirst, T->dindex, &S->dmax);
+    /* the distance root goes where the literals' lengths stood: they are done with */
+    r = qzk_build_dist(&tl, nlen, ndist, QZK_DROOT8(droot), T, &S->dmax);
     if (r < 0 || (r > 0 && S->dmax > 1)) return;
-    S->lbase = T->lindex[QZK_LLROOT + 1];
     S->state = QZK_LS_SYM;
 }
 

@@ -385,6 +385,8 @@ int sim_inflate_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, 
 {
     if (K == 2) return two_phase_spec<2>(comp, out, segs, res, nsegs);
     if (K == 4) return two_phase_spec<4>(comp, out, segs, res, nsegs);
+    if (K == 16) return two_phase_spec<16>(comp, out, segs, res, nsegs);
+    if (K == 32) return two_phase_spec<32>(comp, out, segs, res, nsegs);
     return two_phase_spec<8>(comp, out, segs, res, nsegs);
 }
 

@@ -285,7 +285,7 @@ def test_speculative_inflate_matches_serial(sim):
         ref_out = np.zeros(n + 64, np.uint8); ref_res = np.zeros(len(segs), res_dt)
         sim.sim_inflate_lane(cbuf.ctypes.data, ref_out.ctypes.data, sa.ctypes.data, ref_res.ctypes.data, len(segs))
         assert bytes(ref_out[:n]) == src
-        for K in (2, 4, 8):
+        for K in (2, 4, 8, 16, 32):
             out = np.zeros(n + 64, np.uint8); res = np.zeros(len(segs), res_dt)
             redone = sim.sim_inflate_spec(cbuf.ctypes.data, out.ctypes.data, sa.ctypes.data, res.ctypes.data, len(segs), K)
             assert bytes(out[:n]) == src, (kind, n, chunk, K)

@@ -76,7 +76,7 @@ while time.time() - t0 < budget:
         segs, io, oo = [], 0, 0
         for pc, k in zip(pieces, cuts):
             segs.append((io, oo, len(comp) - io, k, 0, len(pc))); io += len(pc); oo += k
-        for fn in (S.sim_inflate, S.sim_inflate_lane, spec(rng.choice([2, 4, 8]))):
+        for fn in (S.sim_inflate, S.sim_inflate_lane, spec(rng.choice([2, 4, 8, 16, 32]))):
             got, res, tail = run(fn, comp, segs, n)
             ok &= got == src and bool((res["status"] >= 0).all()) and tail == b"\xaa" * 64
             ok &= [int(r["in_used"]) for r in res] == [len(pc) for pc in pieces]
