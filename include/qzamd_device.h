@@ -152,6 +152,15 @@ int qzd_inflate_stream_to_host(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, u
                                uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc,
                                uint8_t *h_dst, int *h_sent);
 
+/* The same for a member that is still in HOST memory (qzDecompress, src/qatzip.c:2103-2404 keeps its engine fed while
+ * earlier requests retire): the n bytes at h_src go to d_src piece by piece, each piece is decoded as soon as it has
+ * landed and its output leaves for h_dst while the later pieces are still arriving and decoding.  When it returns all n
+ * bytes stand at d_src, whatever the result.  A stream the pieces cannot take goes through qzd_inflate_stream_to_host
+ * from there (same results, same error codes).  QATZIP_AMD_PIPE=<pieces> overrides the piece count (0: never). */
+int qzd_inflate_stream_from_host(qzd_ctx *ctx, const uint8_t *h_src, uint64_t n, uint8_t *d_src, uint8_t *d_dst, uint64_t dst_cap,
+                                 uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc,
+                                 uint8_t *h_dst, int *h_sent);
+
 /* Adler-32 (zlib adler32(), what the DEFLATE_ZLIB trailer carries: deflateInit2 with windowBits 15,
  * src/qatzip_sw.c:147) of every chunk_sz chunk of HBM-resident data; fold with qzd_adler32_combine */
 int qzd_adler32_chunks(qzd_ctx *ctx, const uint8_t *d_data, uint64_t n, uint32_t chunk_sz, uint32_t *h_adler);

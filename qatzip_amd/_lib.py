@@ -91,7 +91,7 @@ def exported_symbols():
             "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing",
             "qzd_lz4_compress_frames", "qzd_lz4_compress_frames_hw", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats",
             "qzd_adler32_chunks", "qzd_adler32_combine", "qzd_stream_copy_peak", "qzd_deflate_raw_from_host",
-            "qzd_deflate_slots", "qzd_inflate_stream_to_host", "qzamd_async_stats", "qzd_shard_root_create",
+            "qzd_deflate_slots", "qzd_inflate_stream_to_host", "qzd_inflate_stream_from_host", "qzamd_async_stats", "qzd_shard_root_create",
             "qzd_shard_attach", "qzd_lz4_compress_linked", "qzd_shard_put", "qzd_shard_finish", "qzd_shard_close", "qzd_crc32_combine",
             "qzd_crc32_fold", "qzd_pcie_peak", "qzd_rccl_unique_id", "qzd_rccl_create", "qzd_rccl_gather", "qzd_rccl_close"]
 

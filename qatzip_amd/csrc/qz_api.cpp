@@ -769,7 +769,7 @@ static int parse_header(int fmt, const unsigned char *p, uint32_t n, uint32_t *e
  * check all trailers with one CRC launch - the batch the QAT engine keeps in flight, made as wide as the call.
  * Returns the number of members done (0 = not this kind of stream, the member loop takes over), < 0 on error. */
 static int decompress_sized_members(Sess *s, const unsigned char *src, uint32_t n, uint32_t cap, uint32_t *ti_out,
-                                    uint32_t *to_out, unsigned long *crc)
+                                    uint32_t *to_out, unsigned long *crc, bool *resident)
 {
     struct Mem { uint32_t pay, csz, usz; };
     std::vector<Mem> mem;
@@ -800,6 +800,7 @@ static int decompress_sized_members(Sess *s, const unsigned char *src, uint32_t 
         rg[i].off = oo; rg[i].len = mem[i].usz; rg[i].pad = 0;
         oo += mem[i].usz;
     }
+    if (!*resident) { *resident = true; if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL; }
     if (qzd_inflate_segments(s->ctx, s->d_in, s->d_out, segs.data(), nm, res.data()) != QZD_OK) return QZ_FAIL;
     if (qzd_crc32_ranges(s->ctx, s->d_out, rg.data(), nm, c32.data()) != QZD_OK) return QZ_FAIL;
     uint32_t good = 0; uint64_t to = 0;
@@ -819,6 +820,8 @@ static int decompress_sized_members(Sess *s, const unsigned char *src, uint32_t 
     return (int)good;
 }
 
+/* a member this large (compressed) is decoded piece by piece while it arrives: two pieces of qzd_inflate.hip's minimum */
+#define QZ_PIPE_MIN_BYTES (24u << 20)
 static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *src, unsigned int *src_len,
                               unsigned char *dest, unsigned int *dest_len, unsigned long *crc)
 {
@@ -844,12 +847,14 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
     }
     int rc = reserve(s, n, cap);
     if (rc) return rc;
-    if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
+    /* the source goes to the device when something needs it there: a large member is decoded WHILE it arrives
+     * (qzd_inflate_stream_from_host), everything else after one copy of the whole call */
+    bool resident = false;
     uint32_t ti = 0, to = 0; int ret = QZ_OK;
     bool all_sent = true; uint64_t sent_bytes = 0;                  /* output the device layer has already put into dest */
     s->end_of_stream = 0;
     if (fmt == F_GZIP_EXT && !s->p.stop_at_stream_end) {
-        const int done = decompress_sized_members(s, src, n, cap, &ti, &to, crc);
+        const int done = decompress_sized_members(s, src, n, cap, &ti, &to, crc, &resident);
         if (done < 0) { *src_len = 0; *dest_len = 0; return done; }
         if (done > 0) s->end_of_stream = 1;
     }
@@ -860,8 +865,16 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
         uint64_t iu = 0, ol = 0; uint32_t c32 = 0;
         uint8_t *obuf = s->d_out + to;
         int sent = 0;                                               /* large members reach dest while they are still being decoded */
-        int r = qzd_inflate_stream_to_host(s->ctx, s->d_in + ti + hl, n - ti - hl, obuf, cap - to, s->p.hw_buff_sz, &iu, &ol,
+        int r;
+        if (!resident && n - ti - hl >= QZ_PIPE_MIN_BYTES) {
+            resident = true;                                        /* (the bytes before this member's payload are never read on the device) */
+            r = qzd_inflate_stream_from_host(s->ctx, src + ti + hl, n - ti - hl, s->d_in + ti + hl, obuf, cap - to, s->p.hw_buff_sz, &iu, &ol,
+                                             (fmt == F_GZIP || fmt == F_GZIP_EXT || crc) ? &c32 : NULL, dest + to, &sent);
+        } else {
+            if (!resident) { resident = true; if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) { ret = QZ_FAIL; break; } }
+            r = qzd_inflate_stream_to_host(s->ctx, s->d_in + ti + hl, n - ti - hl, obuf, cap - to, s->p.hw_buff_sz, &iu, &ol,
                                            (fmt == F_GZIP || fmt == F_GZIP_EXT || crc) ? &c32 : NULL, dest + to, &sent);
+        }
         if (sent) sent_bytes += ol; else all_sent = false;
         bool held = false;
         if (r == QZD_ERR_DSTCAP && to == 0) {

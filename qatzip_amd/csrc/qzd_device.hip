@@ -232,6 +232,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     if (c->d_big) hipFree(c->d_big);
     if (c->d_lane) hipFree(c->d_lane);
     if (c->d_cdesc) hipFree(c->d_cdesc);
+    for (int i = 0; i < 8; i++) { if (c->pipe_ctx[i]) qzd_destroy(c->pipe_ctx[i]); if (c->pipe_ev[i]) hipEventDestroy(c->pipe_ev[i]); }
     delete c;
 }
 

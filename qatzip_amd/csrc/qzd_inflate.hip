@@ -20,7 +20,11 @@
  *      or have no markers are decoded by one wave straight through.
  */
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <string.h>
 #include <vector>
 
@@ -41,7 +45,7 @@
 #define QZD_LANE_MIN_SEGS_BIG 2048u
 #define QZD_LANE_MIN(seg_bytes) ((seg_bytes) <= 65536u + 64u ? QZD_LANE_MIN_SEGS : QZD_LANE_MIN_SEGS_BIG)
 #define QZD_LANE_SEGS_PER_WAVE 16u
-/* lanes per segment of phase A (QATZIP_AMD_INFLATE_K = 1, 2, 4, 8, 16, 32 overrides; 1 = the serial phase A).  The lanes
+/* lanes per segment of phase A (QATZIP_AMD_INFLATE_K = 1, 4, 8, 16, 32 overrides; 1 = the serial phase A).  The lanes
  * of a segment share its tables in LDS, start at evenly spaced bits and fall into step with each other.  How many: the chip
  * seats 2048 waves of this kernel, and a launch that does not fill it ends with its longest lane - so up to 8192 segments
  * sixteen lanes each (1 GiB of 128 KB segments: 17.1 -> 14.6 ms; 256 MiB of 64 KB: 11.2 -> 8.6; 16 MiB: 5.7 -> 4.1), eight up
@@ -59,7 +63,7 @@ static uint32_t spec_lanes(const qzk_infseg *hs, uint32_t nsegs)
     uint32_t K = nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 16384u + 64u && hs[0].out_cap <= 262144u + 64u ? QZD_SPEC_LANES_FEWER
                : nsegs <= QZD_SPEC_FEW_SEGS ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
     const char *ke = getenv("QATZIP_AMD_INFLATE_K");
-    if (ke) { int v = atoi(ke); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) K = (uint32_t)v; }
+    if (ke) { int v = atoi(ke); if (v == 1 || v == 4 || v == 8 || v == 16 || v == 32) K = (uint32_t)v; }
     /* it needs a compressed-length hint (qzk_infseg.pad) and segments that write output and begin with no history */
     for (uint32_t i = 0; i < nsegs && K > 1; i++)
         if ((hs[i].flags & (QZK_INF_COUNT_ONLY | QZK_INF_THROUGH_FLUSH)) || hs[i].pad == 0) K = 1;
@@ -104,6 +108,24 @@ __global__ void qzk_marker_kernel(const uint8_t *src, uint64_t n, uint32_t *list
             }
         }
     }
+}
+
+/* Control data between the host's pinned staging and the device (segment records in, results and candidate lists out):
+ * moved by a small KERNEL, not by the copy engines.  A copy engine takes its copies in order, so a 16-byte result queued
+ * behind a quarter of a gigabyte of output on its way to the host arrived when that had arrived - the piece-wise decode
+ * (qzd_inflate_stream_from_host) stood still behind its own output for 30 ms.  Both ends are multiples of four bytes;
+ * the host side is hipHostMalloc memory, which the device reads and writes in place. */
+__global__ void qzk_ctl_copy_kernel(uint32_t *dst, const uint32_t *src, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+static hipError_t ctl_copy(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return hipSuccess;
+    const size_t n4 = (bytes + 3) / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, 256);
+    hipLaunchKernelGGL(qzk_ctl_copy_kernel, dim3(blocks), dim3(256), 0, st, (uint32_t *)dst, (const uint32_t *)src, n4);
+    return hipGetLastError();
 }
 
 /* Two-phase inflate of nsegs segments (qzk_inflate_lane.h / qzk_inflate_spec.h).  K == 1: one lane decodes a whole
@@ -161,8 +183,8 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     uint8_t *lit_d = pb; pb += litb;
     qzk_seq *seq_d = (qzk_seq *)pb; pb += (seqb + 255) & ~(size_t)255;
     uint32_t *ord_d = (uint32_t *)pb;
-    HIPCHK(c, hipMemcpyAsync(d_segs, st_segs, sb, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(ts_d, tsv, (size_t)nsegs * K * sizeof(qzk_tokseg), hipMemcpyHostToDevice, st));
+    HIPCHK(c, ctl_copy(d_segs, st_segs, sb, st));
+    HIPCHK(c, ctl_copy(ts_d, tsv, (size_t)nsegs * K * sizeof(qzk_tokseg), st));
     HIPCHK(c, hipEventRecord(c->ev[1][1], st));
     /* segments per single-wave workgroup of the serial phase A: each lane keeps 1.25 KiB of root tables in LDS, and partly
      * filled waves give the serial decode loops more waves to hide behind (measured in DESIGN.md K3b) */
@@ -188,7 +210,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     else {
         const uint32_t spw = 64 / K;
         const dim3 grid((nsegs + spw - 1) / spw), blk(64);
-        static uint32_t spec_epoch = 0;                             /* tags the marks of a launch: scratch left by an earlier one is not mistaken for them */
+        static std::atomic<uint32_t> spec_epoch{0};                 /* tags the marks of a launch: scratch left by an earlier one is not mistaken for them */
         const uint32_t epoch = ++spec_epoch;
         /* how far a block's last lane may run beyond its share before the rest is shared out again (a round more): segments
          * above 64 KB hold several blocks of very different length and pay for every lane left alone; small launches end
@@ -199,11 +221,11 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         if (ov && atoi(ov) > 0) over = (uint32_t)atoi(ov);
 #define QZD_SPEC_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_spec_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
                                              ts_d, lit_d, seq_d, ch_d, rec_d, epoch, over)
-        if (K == 2) QZD_SPEC_LAUNCH(2); else if (K == 4) QZD_SPEC_LAUNCH(4); else if (K == 16) QZD_SPEC_LAUNCH(16); else if (K == 32) QZD_SPEC_LAUNCH(32); else QZD_SPEC_LAUNCH(8);
+        if (K == 4) QZD_SPEC_LAUNCH(4); else if (K == 16) QZD_SPEC_LAUNCH(16); else if (K == 32) QZD_SPEC_LAUNCH(32); else QZD_SPEC_LAUNCH(8);
 #undef QZD_SPEC_LAUNCH
         /* what that kernel hands back (QZK_INF_ESPEC: a sub-stream outgrew its scratch, too many pieces) goes through the
          * serial phase A, into the segment's first sub-stream - which is sized for a whole segment */
-        HIPCHK(c, hipMemcpyAsync(st_res, d_res, rb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, ctl_copy(st_res, d_res, rb, st));
         HIPCHK(c, hipStreamSynchronize(st));
         uint32_t nredo = 0;
         for (uint32_t i = 0; i < nsegs; i++) if (st_res[i].status == QZK_INF_ESPEC) st_ord[nredo++] = i;
@@ -215,7 +237,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
             fprintf(stderr, "\n");
         }
         if (nredo) {
-            HIPCHK(c, hipMemcpyAsync(ord_d, st_ord, (size_t)nredo * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(c, ctl_copy(ord_d, st_ord, (size_t)nredo * 4, st));
             tok_launch(ord_d, nredo);
         }
     }
@@ -225,7 +247,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     if (!run_b) {
         /* phase A only: its results say which candidates are real segments and where their output belongs;
          * two_phase_resolve() runs phase B once the host has decided */
-        HIPCHK(c, hipMemcpyAsync(st_res, d_res, rb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, ctl_copy(st_res, d_res, rb, st));
         HIPCHK(c, hipStreamSynchronize(st));
         HIPCHK(c, hipGetLastError());
         memcpy(h_res, st_res, rb);
@@ -233,7 +255,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         if (hipEventElapsedTime(&ta, c->ev[1][1], c->ev[1][0]) == hipSuccess) c->inf_ms[3] += ta;   /* phase A's kernel(s) */
         return QZD_OK;
     }
-    if (stream_out) { memcpy(st_ord, c->so_nat, (size_t)nsegs * 4); HIPCHK(c, hipMemcpyAsync(ord_d, st_ord, (size_t)nsegs * 4, hipMemcpyHostToDevice, st)); }
+    if (stream_out) { memcpy(st_ord, c->so_nat, (size_t)nsegs * 4); HIPCHK(c, ctl_copy(ord_d, st_ord, (size_t)nsegs * 4, st)); }
     if (!stream_out) {
         hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
                            d_comp, d_out, d_segs, d_res, nsegs, ts_d, K, lit_d, seq_d, ch_d, (const uint32_t *)NULL, 0u);
@@ -261,7 +283,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         HIPCHK(c, hipStreamSynchronize(c->st[1]));
         c->so_sent = off[QZD_SO_PARTS];
     }
-    HIPCHK(c, hipMemcpyAsync(st_res, d_res, rb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, ctl_copy(st_res, d_res, rb, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     memcpy(h_res, st_res, rb);
@@ -276,8 +298,9 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
  * h_order = the real ones in output order.  With h_dst the output leaves for the host range by range behind the launches
  * (off_of / end_of give a range's bytes).  Results (phase B can still find a bad distance) come back in h_res. */
 static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qzk_infseg *hs, uint32_t nsegs,
-                             const uint32_t *h_order, uint32_t count, qzk_infres *h_res, uint8_t *h_dst, hipStream_t st)
+                             const uint32_t *h_order, uint32_t count, qzk_infres *h_res, uint8_t *h_dst, hipStream_t st, hipStream_t out_st = NULL)
 {
+    if (!out_st) out_st = c->st[1];
     if (nsegs != c->tp.nsegs || count == 0) return QZD_ERR_PARAM;
     const uint32_t K = c->tp.K;                                      /* sub-streams per segment of the phase A that ran */
     qzk_infseg *d_segs = (qzk_infseg *)c->tp.segs; qzk_infres *d_res = (qzk_infres *)c->tp.res;
@@ -289,8 +312,8 @@ static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, 
     qzk_infres *st_res = (qzk_infres *)(c->h_aux + o_res);
     memcpy(c->h_aux, hs, sb);
     memcpy(c->h_aux + o_ord, h_order, (size_t)count * 4);
-    HIPCHK(c, hipMemcpyAsync(d_segs, c->h_aux, sb, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->tp.ord, c->h_aux + o_ord, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, ctl_copy(d_segs, c->h_aux, sb, st));
+    HIPCHK(c, ctl_copy(c->tp.ord, c->h_aux + o_ord, (size_t)count * 4, st));
     HIPCHK(c, hipEventRecord(c->ev[1][0], st));
     const uint32_t parts = h_dst && count >= QZD_LANE_MIN_SEGS ? QZD_SO_PARTS : 1u;
     uint64_t off[QZD_SO_PARTS + 1];
@@ -306,13 +329,13 @@ static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, 
     HIPCHK(c, hipEventRecord(c->ev[1][2], st));
     if (h_dst) {
         for (uint32_t p = 0; p < parts; p++) {
-            HIPCHK(c, hipStreamWaitEvent(c->st[1], c->so_ev[p], 0));
-            HIPCHK(c, hipMemcpyAsync(h_dst + off[p], d_out + off[p], off[p + 1] - off[p], hipMemcpyDeviceToHost, c->st[1]));
+            HIPCHK(c, hipStreamWaitEvent(out_st, c->so_ev[p], 0));
+            HIPCHK(c, hipMemcpyAsync(h_dst + off[p], d_out + off[p], off[p + 1] - off[p], hipMemcpyDeviceToHost, out_st));
         }
-        HIPCHK(c, hipStreamSynchronize(c->st[1]));
+        HIPCHK(c, hipStreamSynchronize(out_st));
         c->so_sent = off[parts];
     }
-    HIPCHK(c, hipMemcpyAsync(st_res, d_res, rb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, ctl_copy(st_res, d_res, rb, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     memcpy(h_res, st_res, rb);
@@ -427,7 +450,7 @@ extern "C" int qzd_crc32(qzd_ctx *c, const uint8_t *d_data, uint64_t n, uint32_t
     return QZD_OK;
 }
 
-static int find_markers(qzd_ctx *c, const uint8_t *d_src, uint64_t n, std::vector<uint32_t> &pos)
+static int find_markers(qzd_ctx *c, const uint8_t *d_src, uint64_t n, std::vector<uint32_t> &pos, hipStream_t on = NULL)
 {
     pos.clear();
     if (n < 4) return QZD_OK;
@@ -435,15 +458,16 @@ static int find_markers(qzd_ctx *c, const uint8_t *d_src, uint64_t n, std::vecto
     int rc = qzd_aux_reserve(c, (size_t)cap * 4 + 64);
     if (rc) return rc;
     uint32_t *d_cnt = (uint32_t *)c->d_aux, *d_list = d_cnt + 4;
-    hipStream_t st = c->st[0];
+    hipStream_t st = on ? on : c->st[0];
     HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, st));
     hipLaunchKernelGGL(qzk_marker_kernel, dim3(2048), dim3(256), 0, st, d_src, n, d_list, cap - 8, d_cnt);
-    HIPCHK(c, hipMemcpyAsync(c->h_aux, d_cnt, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, ctl_copy(c->h_aux, d_cnt, 16, st));
     HIPCHK(c, hipStreamSynchronize(st));
     uint32_t cnt = *(uint32_t *)c->h_aux;
     if (cnt > cap - 8) return 1;       /* too many candidates: caller falls back to the serial walk */
     if (cnt) {
-        HIPCHK(c, hipMemcpy(c->h_aux, d_list, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, ctl_copy(c->h_aux, d_list, (size_t)cnt * 4, st));
+        HIPCHK(c, hipStreamSynchronize(st));
         /* the kernel's atomics hand the positions out in no order: three 11-bit counting passes (a 2 GiB call has 32768
          * of them; std::sort took over a millisecond between two kernels) */
         const uint32_t *in = (const uint32_t *)c->h_aux;
@@ -699,6 +723,213 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
     *h_in_used = total_in; *h_out_len = total_out;
     lap("chain check / rest");
     if (h_crc) { rc = qzd_crc32(c, d_dst, total_out, h_crc); lap("crc32"); return rc; }
+    return QZD_OK;
+}
+
+/* ---- a member that is still in HOST memory: decoded piece by piece while it arrives (round 4) ----
+ * qzDecompress used to copy the whole source in, decode, and only then send the output out: for 2 GiB 13 ms of H2D, 12 ms
+ * of phase A, and 37 ms of D2H that began when both were over.  Here the compressed bytes are cut into P pieces that go to
+ * the device one behind the other; as soon as piece p has landed a helper context (its own streams, scratch and host thread)
+ * scans it for flush markers, runs phase A over the candidates that END in the piece, takes the chain's state (next
+ * expected segment start, output offset) from piece p - 1, walks its part of the chain, hands the state on, and runs phase
+ * B with the output leaving for the host behind it.  So the first output is on its way when an eighth of the input has been
+ * decoded, and the link out stays busy while the later pieces' phase A runs.  (The reference keeps its engine fed the same
+ * way: requests are submitted while earlier ones are retired, src/qatzip.c:2103-2404.)
+ * Anything unusual - too many candidates, a chain that does not close at a piece's end (00 00 FF FF inside compressed data
+ * as a piece's last candidate), an error status, a destination too small - abandons the pieces: the input is all on the
+ * device by then, and the call goes through inflate_stream() as before, which reports what is wrong. */
+#define QZD_PIPE_MAX 8u
+#define QZD_PIPE_PIECES 2u                /* see profiles/r4_api_decompress.txt: more pieces lose to each other on the chip */
+#define QZD_PIPE_MIN_BYTES (12u << 20)     /* compressed bytes a piece holds at least (~32 MiB of output, 512 segments) */
+struct qzd_pipe {
+    std::mutex m; std::condition_variable cv;
+    uint32_t P;
+    bool issued[QZD_PIPE_MAX];              /* main thread: the piece has landed (the host waits for each copy: a stream made to wait
+                                             * for a copy's event was let go only when the copies behind it were over too) */
+    bool cand_ok[QZD_PIPE_MAX]; uint32_t lastc[QZD_PIPE_MAX];       /* the last candidate at or before the piece's end */
+    bool chain_ok[QZD_PIPE_MAX]; uint32_t nxt[QZD_PIPE_MAX]; uint64_t oo[QZD_PIPE_MAX];   /* the chain after the piece */
+    bool final_seen; uint64_t total_in, total_out;
+    bool failed;
+    std::chrono::steady_clock::time_point t0;
+};
+
+static void pipe_fail(qzd_pipe *S, uint32_t p)
+{
+    std::lock_guard<std::mutex> g(S->m);
+    S->failed = true;
+    S->cand_ok[p] = true; S->chain_ok[p] = true;
+    S->cv.notify_all();
+}
+
+static void pipe_piece(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                       uint32_t seg_hint, const uint64_t *cut, uint8_t *h_dst)
+{
+    hipSetDevice(H->device);
+    static const bool trace = getenv("QATZIP_AMD_TRACE") != NULL;   /* developer aid: when each step of each piece was over */
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[pipe] piece %u %-18s at %8.3f ms\n", p, what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S->t0).count());
+    };
+    hipStream_t st = H->st[0];
+    const bool last = p + 1 == S->P;
+    {
+        std::unique_lock<std::mutex> g(S->m);
+        S->cv.wait(g, [&] { return S->issued[p] || S->failed; });
+        if (S->failed) { g.unlock(); pipe_fail(S, p); return; }
+    }
+    /* candidates that end in (cut[p], cut[p + 1]]: the marker's four bytes may begin three bytes before the piece */
+    const uint64_t lo = cut[p] >= 3 ? cut[p] - 3 : 0, hi = cut[p + 1];
+    std::vector<uint32_t> mk;
+    if (find_markers(H, d_src + lo, hi - lo, mk, st) != QZD_OK) { pipe_fail(S, p); return; }
+    lap("landed, scanned");
+    std::vector<uint32_t> start;
+    uint32_t prev = 0;
+    {
+        std::unique_lock<std::mutex> g(S->m);
+        if (p) { S->cv.wait(g, [&] { return S->cand_ok[p - 1]; }); prev = S->lastc[p - 1]; }
+        start.push_back(prev);
+        for (uint32_t q : mk) if (lo + q < n && lo + q > prev) start.push_back((uint32_t)(lo + q));
+        S->lastc[p] = start.back(); S->cand_ok[p] = true;
+        S->cv.notify_all();
+        if (S->failed) { g.unlock(); pipe_fail(S, p); return; }
+    }
+    /* my segments: from every start to the next one; the last start is the next piece's first (the last piece's own, to n) */
+    const uint32_t ns = last ? (uint32_t)start.size() : (uint32_t)start.size() - 1;
+    const uint32_t arrived = (uint32_t)(last ? n : hi);
+    auto clen = [&](uint32_t k) { return (k + 1 < start.size() ? start[k + 1] : (uint32_t)n) - start[k]; };
+    std::vector<qzk_infseg> ps(ns);
+    std::vector<qzk_infres> pr(ns);
+    std::vector<uint32_t> where(ns), chain;
+    if (ns) {
+        std::vector<uint32_t> order(ns);
+        {   /* largest compressed size first (32-byte classes), as inflate_stream() seats them */
+            const uint32_t NB = 8192;
+            std::vector<uint32_t> cnt(NB + 1, 0);
+            auto rcls = [&](uint32_t k) { uint32_t v = clen(k) >> 5; return NB - 1 - (v < NB ? v : NB - 1); };
+            for (uint32_t i = 0; i < ns; i++) cnt[rcls(i) + 1]++;
+            for (uint32_t i = 0; i < NB; i++) cnt[i + 1] += cnt[i];
+            for (uint32_t i = 0; i < ns; i++) order[cnt[rcls(i)]++] = i;
+        }
+        for (uint32_t i = 0; i < ns; i++) {
+            const uint32_t k = order[i];
+            where[k] = i;
+            ps[i].in_off = start[k]; ps[i].in_len = arrived - start[k];     /* what has landed - not a byte more */
+            ps[i].out_off = 0; ps[i].out_cap = seg_hint; ps[i].flags = 0; ps[i].pad = clen(k);
+        }
+        lap("phase A begins");
+        if (two_phase(H, d_src, d_dst, ps.data(), ns, pr.data(), spec_lanes(ps.data(), ns), st, false) != QZD_OK) { pipe_fail(S, p); return; }
+        lap("phase A");
+    }
+    /* the chain through my segments, from where the piece before left it */
+    uint32_t want = 0; uint64_t oo = 0; bool fin = false;
+    {
+        std::unique_lock<std::mutex> g(S->m);
+        if (p) { S->cv.wait(g, [&] { return S->chain_ok[p - 1]; }); want = S->nxt[p - 1]; oo = S->oo[p - 1]; }
+        fin = S->final_seen;
+        if (S->failed) { g.unlock(); pipe_fail(S, p); return; }
+    }
+    bool ok = true; uint64_t t_in = 0;
+    if (!fin) {
+        uint32_t k = 0;
+        while (k < start.size() && start[k] < want) k++;
+        if (k >= start.size() || start[k] != want) ok = false;
+        while (ok && k < ns) {
+            const qzk_infres &r = pr[where[k]];
+            if (r.status != QZK_INF_FINAL && r.status != QZK_INF_FLUSH) { ok = false; break; }
+            ps[where[k]].out_off = oo; ps[where[k]].out_cap = r.out_len; ps[where[k]].flags = 0x80000000u;
+            chain.push_back(where[k]);
+            oo += r.out_len;
+            if (oo > dst_cap) { ok = false; break; }
+            if (r.status == QZK_INF_FINAL) { fin = true; t_in = (uint64_t)start[k] + r.in_used; break; }
+            const uint32_t nx = start[k] + r.in_used;
+            uint32_t j = k + 1;
+            while (j < start.size() && start[j] < nx) j++;
+            if (j >= start.size() || start[j] != nx) { ok = false; break; }
+            k = j;
+        }
+        if (ok && !fin && last) ok = false;                         /* the stream ends without its final block */
+    }
+    {
+        std::lock_guard<std::mutex> g(S->m);
+        if (!ok) S->failed = true;
+        S->nxt[p] = start.back(); S->oo[p] = oo; S->chain_ok[p] = true;
+        if (ok && fin && !S->final_seen) { S->final_seen = true; S->total_in = t_in; S->total_out = oo; }
+        S->cv.notify_all();
+        if (S->failed) return;
+    }
+    lap("chain");
+    if (chain.empty()) return;
+    H->inf_ms[2] = 0;
+    for (uint32_t i = 0; i < ns; i++) ps[i].flags = ps[i].flags == 0x80000000u ? 0 : QZK_INF_COUNT_ONLY;
+    if (two_phase_resolve(H, d_src, d_dst, ps.data(), ns, chain.data(), (uint32_t)chain.size(), pr.data(), h_dst, st, c->st[1]) != QZD_OK) { pipe_fail(S, p); return; }
+    for (uint32_t i : chain) if (pr[i].status < 0) { pipe_fail(S, p); return; }
+    if (trace) fprintf(stderr, "[pipe] piece %u phase B kernels %.3f ms, %u segments\n", p, H->inf_ms[2], (uint32_t)chain.size());
+    lap("phase B, sent");
+}
+
+/* d_src: where the n bytes at h_src are to stand on the device (they are all there when this returns, whatever it
+ * returns); the rest as qzd_inflate_stream_to_host */
+extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, uint64_t n, uint8_t *d_src, uint8_t *d_dst, uint64_t dst_cap,
+                                            uint32_t seg_hint, uint64_t *h_in_used, uint64_t *h_out_len, uint32_t *h_crc,
+                                            uint8_t *h_dst, int *h_sent)
+{
+    if (!c || !h_src || !d_src || !h_dst || !h_sent || !h_in_used || !h_out_len) return QZD_ERR_PARAM;
+    if (n == 0 || n > 0xffffffffull) return QZD_ERR_PARAM;
+    hipSetDevice(c->device);
+    *h_sent = 0;
+    uint32_t P = (uint32_t)std::min<uint64_t>(QZD_PIPE_PIECES, n / QZD_PIPE_MIN_BYTES);
+    const char *pe = getenv("QATZIP_AMD_PIPE");                     /* pieces (0 / 1: the whole member at once) */
+    if (pe) P = (uint32_t)std::min<int>(QZD_PIPE_MAX, std::max(0, atoi(pe)));
+    if (!seg_hint) P = 0;
+    for (uint32_t p = 0; p < P; p++) {
+        if (!c->pipe_ctx[p] && qzd_create(c->device, &c->pipe_ctx[p]) != QZD_OK) { P = p; break; }
+        if (!c->pipe_ev[p] && hipEventCreateWithFlags(&c->pipe_ev[p], hipEventDisableTiming) != hipSuccess) { P = p; break; }
+    }
+    if (P < 2) {
+        HIPCHK(c, hipMemcpy(d_src, h_src, n, hipMemcpyHostToDevice));
+        return inflate_stream(c, d_src, n, d_dst, dst_cap, seg_hint, h_in_used, h_out_len, h_crc, h_dst, h_sent);
+    }
+    qzd_pipe S;
+    S.t0 = std::chrono::steady_clock::now();
+    S.P = P; S.final_seen = false; S.failed = false; S.total_in = S.total_out = 0;
+    for (uint32_t p = 0; p < QZD_PIPE_MAX; p++) { S.issued[p] = S.cand_ok[p] = S.chain_ok[p] = false; S.lastc[p] = S.nxt[p] = 0; S.oo[p] = 0; }
+    uint64_t cut[QZD_PIPE_MAX + 1];
+    /* the first two pieces half as large as the others: the output cannot leave before the first piece's phases are over */
+    /* two pieces: a third of the member, then the rest (more: the first two half as large as the others) - the output
+     * cannot leave before the first piece's phases are over, and the second piece's phase A hides behind the first one's way out */
+    for (uint32_t p = 0; p <= P; p++)
+        cut[p] = p == P ? n : p == 0 ? 0 : P == 2 ? (n / 3) & ~(uint64_t)4095 : (n * (2 * p - (p >= 2 ? 2 : 1)) / (2 * P - 2)) & ~(uint64_t)4095;
+    std::vector<std::thread> th;
+    for (uint32_t p = 0; p < P; p++)
+        th.emplace_back(pipe_piece, c->pipe_ctx[p], c, &S, p, (const uint8_t *)d_src, n, d_dst, dst_cap, seg_hint, (const uint64_t *)cut, h_dst);
+    /* the copy, two pieces in flight; a piece is the helpers' when the host has seen its copy end.  (A pageable source makes
+     * every copy block until it is over: the same, one at a time.) */
+    bool copy_ok = true;
+    auto landed = [&](uint32_t p) {
+        if (copy_ok && hipEventSynchronize(c->pipe_ev[p]) != hipSuccess) copy_ok = false;
+        std::lock_guard<std::mutex> g(S.m);
+        if (!copy_ok) S.failed = true;
+        S.issued[p] = true;
+        S.cv.notify_all();
+    };
+    for (uint32_t p = 0; p < P; p++) {
+        if (copy_ok && (hipMemcpyAsync(d_src + cut[p], h_src + cut[p], cut[p + 1] - cut[p], hipMemcpyHostToDevice, c->st_copy) != hipSuccess ||
+                        hipEventRecord(c->pipe_ev[p], c->st_copy) != hipSuccess)) copy_ok = false;
+        if (p) landed(p - 1);
+    }
+    landed(P - 1);
+    for (auto &t : th) t.join();
+    HIPCHK(c, hipStreamSynchronize(c->st_copy));
+    if (!copy_ok) {
+        snprintf(c->err, sizeof(c->err), "host-to-device copy of a piece failed");
+        return QZD_ERR_HIP;
+    }
+    if (S.failed || !S.final_seen) {
+        if (getenv("QATZIP_AMD_TRACE")) fprintf(stderr, "[qzd_inflate_stream_from_host] pieces abandoned, the member goes through as a whole\n");
+        return inflate_stream(c, d_src, n, d_dst, dst_cap, seg_hint, h_in_used, h_out_len, h_crc, h_dst, h_sent);
+    }
+    *h_in_used = S.total_in; *h_out_len = S.total_out; *h_sent = 1;
+    if (h_crc) return qzd_crc32(c, d_dst, S.total_out, h_crc);
     return QZD_OK;
 }
 

@@ -56,6 +56,9 @@ struct qzd_ctx {
     bool no_stream_in;              /* this call is the batched retry of a launch that gave up waiting for its input */
     /* device arrays of the last two-phase inflate (phase A done, phase B still to run): two_phase() / two_phase_resolve() */
     struct { void *segs, *res, *ts, *lits, *seqs, *chains; uint32_t *ord; uint32_t nsegs, K; } tp;
+    /* helpers of a piece-wise host-to-host decode (qzd_inflate_stream_from_host): contexts of their own - streams, scratch,
+     * pinned staging - so that the pieces' phases run side by side; made at the first such call, freed with this context */
+    struct qzd_ctx *pipe_ctx[8]; hipEvent_t pipe_ev[8];
     char err[256];
 };
 

@@ -894,6 +894,70 @@ def test_large_host_input_feeds_a_launch_that_is_already_running(hw, pinned):
     s.close()
 
 
+@pytest.mark.parametrize("hw,pinned,pieces", [(65536, True, None), (65536, False, None), (16384, True, "3"), (131072, True, "8")])
+def test_large_member_is_decoded_while_it_arrives(hw, pinned, pieces):
+    """qzDecompress of a member of 24 MiB (compressed) and more from host memory: the source goes to the device in pieces, a
+    piece's segments are decoded as soon as it has landed and the output leaves while the later pieces arrive and decode
+    (qzd_inflate_stream_from_host; the reference keeps requests in flight the same way, src/qatzip.c:2103-2404).  One
+    pinned source and one destination are used for three kinds of data in a row, so a segment decoded before its bytes had
+    landed - or bytes of the earlier round - would show; the fourth round appends a second member and a cut-off third one
+    (the pieces end with the first member: the rest must be found where it is), the last one damages the stream (the
+    pieces give up, the call must still report it)."""
+    L = A.lib()
+    s = A.Session(data_fmt=A.QZ_DEFLATE_GZIP_EXT, hw_buff_sz=hw)
+    n = (120 << 20) + 4321
+    cap_c = n + (n >> 3) + 65536
+    if pinned:
+        psrc = L.qzMalloc(cap_c, -1, A.PINNED_MEM); pdst = L.qzMalloc(n + 4096 + 64, -1, A.PINNED_MEM)
+        assert psrc and pdst
+    else:
+        hold = (C.create_string_buffer(cap_c), C.create_string_buffer(n + 4096 + 64))
+        psrc, pdst = C.addressof(hold[0]), C.addressof(hold[1])
+    if pieces is not None:
+        os.environ["QATZIP_AMD_PIPE"] = pieces
+
+    def once(clen, dcap):
+        C.memset(pdst + dcap, 0xa5, 64)
+        sl, dl = C.c_uint(clen), C.c_uint(dcap)
+        rc = L.qzDecompress(C.byref(s.s), C.cast(psrc, C.c_char_p), C.byref(sl), C.c_void_p(pdst), C.byref(dl))
+        assert C.string_at(pdst + dcap, 64) == b"\xa5" * 64       # nothing behind the destination
+        return rc, sl.value, dl.value
+
+    try:
+        for rnd, kind in enumerate(("silesia", "rand", "lzmix")):
+            src = datagen.gen_bytes(kind, n, 400 + rnd)
+            comp = s.compress(src, 1)[2]
+            assert len(comp) >= (24 << 20) or kind == "lzmix", len(comp)
+            C.memmove(psrc, comp, len(comp))
+            rc, used, got = once(len(comp), n + 4096)
+            assert rc == A.QZ_OK and used == len(comp) and got == n, (kind, rc, used, got)
+            assert C.string_at(pdst, n) == src, kind
+        # two members and the beginning of a third
+        src = datagen.gen_bytes("silesia", n, 444)
+        tail = datagen.gen_bytes("text", 300000, 445)
+        c1, c2 = s.compress(src, 1)[2], s.compress(tail, 1)[2]
+        both = c1 + c2 + c1[:1000]
+        assert len(both) <= cap_c
+        C.memmove(psrc, both, len(both))
+        rc, used, got = once(len(both), n + 4096)                   # the destination ends inside the second member: whole members only
+        assert rc == A.QZ_BUF_ERROR and used == len(c1) and got == n and C.string_at(pdst, n) == src, (rc, used, got)
+        # a flipped bit in the middle of the first member
+        bad = bytearray(c1); bad[len(bad) // 2] ^= 0x10
+        C.memmove(psrc, bytes(bad), len(bad))
+        rc, used, got = once(len(bad), n + 4096)
+        assert rc == A.QZ_DATA_ERROR and used == 0 and got == 0, (rc, used, got)
+        # and a destination that is too small for the member
+        C.memmove(psrc, c1, len(c1))
+        back = s.decompress(c1, n + 64)
+        assert back[0] == A.QZ_OK and back[2] == src                # (pageable, through the wrapper)
+    finally:
+        if pieces is not None:
+            del os.environ["QATZIP_AMD_PIPE"]
+    if pinned:
+        L.qzFree(psrc); L.qzFree(pdst)
+    s.close()
+
+
 def test_async_requests_of_a_hardware_framing_session_keep_their_framing():
     """advisor (round 2): qzCompress2 requests of a qzamd_set_hw_framing session that wait in the queue together must come
     out framed exactly like one running alone - one complete member per chunk, XFL 0, OS 255 - not in the software path's

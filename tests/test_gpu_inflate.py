@@ -121,7 +121,7 @@ def test_both_inflate_kernels_agree(ctx, monkeypatch, mode):
     assert out == src
 
 
-@pytest.mark.parametrize("k", ["2", "4", "8", "16", "32"])
+@pytest.mark.parametrize("k", ["4", "8", "16", "32"])
 def test_speculative_phase_a_is_bit_exact(ctx, monkeypatch, k):
     # opt-in sub-segment speculation (qzk_inflate_spec.h): K lanes per segment; whatever it cannot take goes through
     # the serial kernel, so every kind of stream must still come out right
