@@ -182,7 +182,9 @@ typedef struct { int32_t status; uint32_t in_used, out_len, pad; } qzd_lz4res;
 int qzd_lz4_compress_frames(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t frame_sz, uint8_t *d_dst,
                             uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len);
 /* the same frames with the header the reference's HARDWARE path writes per chunk (qzLZ4HeaderGen,
- * src/qatzip_lz4.c:104-132: FLG 0x4C, content size = the chunk's bytes); footer as qzLZ4FooterGen (:134-143) */
+ * src/qatzip_lz4.c:104-132: FLG 0x4C, content size = the chunk's bytes); footer as qzLZ4FooterGen (:134-143).
+ * frame_sz above 64 KB (a hw_buff_sz of 128 KB .. 512 KB): every chunk's frame holds linked 64 KB blocks - one wave per
+ * chunk, all chunks of the call in one launch */
 int qzd_lz4_compress_frames_hw(qzd_ctx *ctx, const uint8_t *d_src, uint64_t n, uint32_t frame_sz, uint8_t *d_dst,
                                uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len);
 /* ONE call above 64 KB as the one frame LZ4F_compressFrame writes for it (src/qatzip_sw.c:451-456): FLG 0x4C, the 64 KB

@@ -574,17 +574,8 @@ static int compress_lz4_hw(QzSession_T *sess, Sess *s, const unsigned char *src,
     if (qzd_h2d(s->ctx, s->d_in, src, n) != QZD_OK) return QZ_FAIL;
     std::vector<uint32_t> lens(nchunks);
     uint64_t produced = 0;
-    if (hw <= 65536) {
-        if (qzd_lz4_compress_frames_hw(s->ctx, s->d_in, n, hw, s->d_out, s->out_cap, &produced, lens.data()) != QZD_OK) return QZ_FAIL;
-    } else {
-        for (uint32_t k = 0; k < nchunks; k++) {
-            const uint32_t cl = std::min<uint32_t>(hw, n - k * hw);
-            uint64_t one = 0;
-            if (cl > 65536) { if (qzd_lz4_compress_linked(s->ctx, s->d_in + (size_t)k * hw, cl, s->d_out + produced, s->out_cap - produced, &one) != QZD_OK) return QZ_FAIL; }
-            else if (qzd_lz4_compress_frames_hw(s->ctx, s->d_in + (size_t)k * hw, cl, 65536, s->d_out + produced, s->out_cap - produced, &one, NULL) != QZD_OK) return QZ_FAIL;
-            lens[k] = (uint32_t)one; produced += one;
-        }
-    }
+    /* one launch for all chunks, whatever hw_buff_sz: one-block frames up to 64 KB, linked blocks above (a wave per chunk) */
+    if (qzd_lz4_compress_frames_hw(s->ctx, s->d_in, n, hw, s->d_out, s->out_cap, &produced, lens.data()) != QZD_OK) return QZ_FAIL;
     uint32_t take = 0; uint64_t bytes = 0;
     while (take < nchunks && bytes + lens[take] <= cap) bytes += lens[take++];
     if (take == 0) return QZ_BUF_ERROR;

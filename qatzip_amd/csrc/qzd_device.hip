@@ -1038,10 +1038,13 @@ static int lz4_compress_frames_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n
                                     uint8_t *d_dst, uint64_t dst_cap, uint64_t *h_out_len, uint32_t *h_frame_len, uint32_t hw_hdr)
 {
     if (!c || !d_dst || (n && !d_src) || !h_out_len) return QZD_ERR_PARAM;
-    if (frame_sz == 0 || frame_sz > QZK_LZ4_MAXBLK) { snprintf(c->err, sizeof(c->err), "LZ4 frames above 64 KB (linked blocks) are not produced"); return QZD_ERR_UNSUPPORTED; }
+    /* above 64 KB a frame has several linked blocks: only the hardware path's per-chunk frames are made that way here (one
+     * call = one frame of the software path goes through qzd_lz4_compress_linked) */
+    const bool linked = frame_sz > QZK_LZ4_MAXBLK;
+    if (frame_sz == 0 || (linked && (!hw_hdr || frame_sz > (1u << 30)))) { snprintf(c->err, sizeof(c->err), "LZ4 frames above 64 KB (linked blocks) are not produced"); return QZD_ERR_UNSUPPORTED; }
     hipSetDevice(c->device);
     const uint32_t nfr = n ? (uint32_t)((n + frame_sz - 1) / frame_sz) : 1;
-    const uint32_t stride = (frame_sz + 15 + 4 + 8 + 64 + 15) & ~15u;
+    const uint32_t stride = (frame_sz + 15 + 4 * ((frame_sz + 65535) >> 16) + 8 + 64 + 15) & ~15u;
     if (nfr > c->call_cap) {
         hipDeviceSynchronize();
         hipFree(c->d_len); hipFree(c->d_crc); hipFree(c->d_offs);
@@ -1051,7 +1054,8 @@ static int lz4_compress_frames_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n
         HIPCHK(c, hipMalloc(&c->d_offs, (size_t)nfr * 8));
         c->call_cap = nfr;
     }
-    const uint32_t batch = nfr < 16384u ? nfr : 16384u;
+    uint32_t batch = nfr < 16384u ? nfr : 16384u;
+    if (linked && (uint64_t)batch * stride > (1ull << 30)) batch = std::max<uint32_t>(1u, (uint32_t)((1ull << 30) / stride));   /* slots of a gigabyte at most */
     if ((size_t)batch * stride > c->slot_cap) {
         hipDeviceSynchronize();
         for (int i = 0; i < QZD_NBUF; i++) { hipFree(c->slots[i]); c->slots[i] = NULL; }
@@ -1072,7 +1076,16 @@ static int lz4_compress_frames_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n
         if (const char *e = getenv("QATZIP_AMD_LZ4_WPC")) wpc = (uint32_t)atoi(e);
         if (wpc > 32) wpc = 32;
         const uint32_t cus = c->cus ? c->cus : 256u;
-        if (wpc && bn > 8 * cus) {
+        if (linked) {
+            /* one wave per chunk; the call's last chunk is a one-block frame when it is 64 KB or less */
+            const bool tail_small = b + bn == nfr && n - (uint64_t)(nfr - 1) * frame_sz <= QZK_LZ4_MAXBLK;
+            const uint32_t nl = tail_small ? bn - 1 : bn;
+            if (nl) hipLaunchKernelGGL(qzk_lz4c_linked_many_kernel, dim3(nl), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, nl, c->slots[0], stride, c->d_len + b);
+            if (tail_small) {
+                const uint64_t toff = (uint64_t)(nfr - 1) * frame_sz;
+                hipLaunchKernelGGL(qzk_lz4c_kernel, dim3(1), dim3(64), 0, st, d_src + toff, n - toff, (uint32_t)QZK_LZ4_MAXBLK, 1u, c->slots[0] + (size_t)(bn - 1) * stride, stride, c->d_len + nfr - 1, hw_hdr);
+            }
+        } else if (wpc && bn > 8 * cus) {
             const uint32_t waves = std::min<uint32_t>(bn, wpc * cus);
             if (waves > c->lz4tab_waves) {
                 hipDeviceSynchronize();

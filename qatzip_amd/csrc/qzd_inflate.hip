@@ -11,13 +11,20 @@
  * inside compressed data) are discarded by that chain walk.
  *
  * Strategy per stream (qzd_inflate_stream):
- *   1. marker scan (GPU) -> sorted candidate starts
- *   2. optimistic single pass: candidate k is assumed real and to produce exactly
- *      seg_hint bytes (the session's hw_buff_sz) at k*seg_hint; validated afterwards
- *   3. otherwise two passes: count-only decode of all candidates -> chain walk +
- *      prefix sums on the host -> decode of the true segments at exact offsets
- *   4. streams whose segments reference earlier history (Z_SYNC_FLUSH producers)
- *      or have no markers are decoded by one wave straight through.
+ *   1. marker scan (GPU) -> sorted candidate starts; every candidate knows where the next one begins, i.e. how long
+ *      it is at most compressed
+ *   2a. phase A (Huffman decoding into token streams, K lanes per candidate: qzk_inflate_spec.h) over EVERY candidate,
+ *      the chain walk on the host (a candidate that is no boundary drops out, every real segment gets its output
+ *      offset), phase B (qzk_lz_resolve_kernel) for the real ones, range by range with the output leaving for the host
+ *      behind it when the caller wants it there
+ *   2b. (QATZIP_AMD_INFLATE=wave) optimistic single pass, a wave per candidate: candidate k is assumed real and to
+ *      produce exactly seg_hint bytes (the session's hw_buff_sz) at k*seg_hint; validated afterwards
+ *   3. otherwise two passes: count-only decode of all candidates -> chain walk + prefix sums on the host -> decode of
+ *      the true segments at exact offsets
+ *   4. streams whose segments reference earlier history (Z_SYNC_FLUSH producers) or have no markers are decoded by
+ *      one wave straight through.
+ * A member that is still in host memory (qzd_inflate_stream_from_host) goes through 1 and 2a piece by piece while it
+ * arrives; whatever the pieces cannot take falls back to the list above.
  */
 #include <algorithm>
 #include <atomic>

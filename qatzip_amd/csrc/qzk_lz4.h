@@ -376,11 +376,8 @@ QZ_KERNEL_OCC(64, 8) qzk_lz4c_pull_kernel(const uint8_t *src, uint64_t src_len, 
  * does not shrink), end mark, XXH32 of the content.  The blocks share one parse state, so this is one wave's serial work
  * from the first byte to the last; it is what keeps a QZ_LZ4 session's bytes equal to the software path's for every call
  * size, not a fast path (calls of at most 64 KB, and the 64 KB-frame bench configuration, go through qzk_lz4c_kernel). */
-QZ_KERNEL_MAX(64) qzk_lz4c_linked_kernel(const uint8_t *src, uint32_t n, uint8_t *out, uint32_t *out_len)
+QZ_DEV uint32_t qzk_lz4c_linked_frame(const uint8_t *src, uint32_t n, uint8_t *out, uint32_t *table, uint32_t *slot, int lane)
 {
-    QZ_LDS uint32_t table[4096];
-    QZ_LDS uint32_t slot[1024];
-    const int lane = qz_lane();
     for (int i = lane; i < 4096; i += 64) table[i] = 0;
     if (lane == 0) {
         out[0] = 0x04; out[1] = 0x22; out[2] = 0x4d; out[3] = 0x18;
@@ -409,8 +406,33 @@ QZ_KERNEL_MAX(64) qzk_lz4c_linked_kernel(const uint8_t *src, uint32_t n, uint8_t
     if (lane == 0) {
         out[pos] = out[pos + 1] = out[pos + 2] = out[pos + 3] = 0;
         out[pos + 4] = (uint8_t)xx; out[pos + 5] = (uint8_t)(xx >> 8); out[pos + 6] = (uint8_t)(xx >> 16); out[pos + 7] = (uint8_t)(xx >> 24);
-        *out_len = pos + 8;
     }
+    return pos + 8;
+}
+QZ_KERNEL_MAX(64) qzk_lz4c_linked_kernel(const uint8_t *src, uint32_t n, uint8_t *out, uint32_t *out_len)
+{
+    QZ_LDS uint32_t table[4096];
+    QZ_LDS uint32_t slot[1024];
+    const int lane = qz_lane();
+    const uint32_t len = qzk_lz4c_linked_frame(src, n, out, table, slot, lane);
+    if (lane == 0) *out_len = len;
+}
+/* the hardware path's framing with a hw_buff_sz above 64 KB (src/qatzip_lz4.c:104-143): every chunk of `chunk` bytes is
+ * such a frame of its own - one wave per chunk, all chunks of the call in one launch, frame k into slot k (the scan and the
+ * gather of the one-block frames put them back to back).  The call's last chunk may be 64 KB or less: that one is a
+ * one-block frame and not this kernel's (nfr counts the chunks above 64 KB only). */
+QZ_KERNEL_MAX(64) qzk_lz4c_linked_many_kernel(const uint8_t *src, uint64_t total, uint32_t chunk, uint32_t nfr, uint8_t *slots,
+                                              uint32_t stride, uint32_t *lens)
+{
+    QZ_LDS uint32_t table[4096];
+    QZ_LDS uint32_t slot[1024];
+    const int lane = qz_lane();
+    const uint32_t k = blockIdx.x;
+    if (k >= nfr) return;
+    const uint64_t off = (uint64_t)k * chunk;
+    const uint32_t n = total - off < chunk ? (uint32_t)(total - off) : chunk;
+    const uint32_t len = qzk_lz4c_linked_frame(src + off, n, slots + (uint64_t)k * stride, table, slot, lane);
+    if (lane == 0) lens[k] = len;
 }
 
 /* ------------------------------------------------------------------ K5: frame decode */

@@ -279,6 +279,13 @@ int sim_lz4c_hw(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slot
     return (int)nframes;
 }
 
+/* K4, the hardware framing's chunks above 64 KB: a linked frame per chunk, one launch */
+int sim_lz4c_linked_many(const uint8_t *src, uint64_t total, uint32_t chunk, uint32_t nfr, uint8_t *slots, uint32_t stride, uint32_t *lens)
+{
+    sim::launch(nfr, 64, 0, [&] { qzk_lz4c_linked_many_kernel(src, total, chunk, nfr, slots, stride, lens); });
+    return 0;
+}
+
 /* K4, linked mode: ONE frame for a call above 64 KB */
 int sim_lz4c_linked(const uint8_t *src, uint32_t n, uint8_t *out, uint32_t *out_len)
 {

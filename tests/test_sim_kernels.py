@@ -315,6 +315,19 @@ def test_lz4_linked_frames_match_liblz4_goldens(sim):
         out = C.create_string_buffer(n + n // 255 + 4096); ol = C.c_uint32(0)
         sim.sim_lz4c_linked(src, n, out, C.byref(ol))
         assert out.raw[:ol.value] == exp, (kind, n, seed, ol.value, len(exp))
+    # the hardware framing's chunks above 64 KB: a frame per chunk, all in one launch (compress_lz4_hw) - each slot must hold
+    # what the one-frame kernel writes for that chunk alone
+    sim.sim_lz4c_linked_many.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    src = datagen.gen_bytes("silesia", 3 * 131072 + 70000, 11)
+    chunk, nfr = 131072, 4
+    stride = (chunk + 15 + 4 * 2 + 8 + 64 + 15) & ~15
+    slots = C.create_string_buffer(nfr * stride); lens = (C.c_uint32 * nfr)()
+    sim.sim_lz4c_linked_many(src, len(src), chunk, nfr, slots, stride, lens)
+    for k in range(nfr):
+        part = src[k * chunk:(k + 1) * chunk]
+        out = C.create_string_buffer(len(part) + 4096); ol = C.c_uint32(0)
+        sim.sim_lz4c_linked(part, len(part), out, C.byref(ol))
+        assert slots.raw[k * stride:k * stride + lens[k]] == out.raw[:ol.value], k
 
 
 def test_lz4_frames_match_oracle(sim):
