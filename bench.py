@@ -10,20 +10,28 @@ compress every call, then decompress every call (the reference harness' "-D both
 counts uncompressed bytes for either direction and doubles them for "both", test/main.c:2336-2346).
 Multi-GPU: independent chunks shard across ranks with no data-path collective in the timed region (weak scaling:
 every rank owns its own buffer); gloo carries the barrier and the max/sum reductions of the timings.  After the timed
-region the ranks also build ONE gzip-ext member out of one shard each (config 5's shape): the compressed shards travel
-to rank 0's HBM - as peer-to-peer copies into an IPC window and as an RCCL send/recv group, both timed - and
-`config.one_stream` reports them.  `python bench.py --gpus N` launches its own N ranks when no launcher set WORLD_SIZE.
+region the ranks also build gzip-ext members the way BASELINE config 5 asks for - a striped volume: member m holds one
+slice of every rank (--members, default 16 from 8 ranks on, else 4), the members are PIPELINED (while member m travels to
+rank 0's HBM the ranks compress member m + 1) - over peer-to-peer copies into an IPC window and over an RCCL send/recv
+group, both timed and both verified by decoding on rank 0: `config.one_stream`.  `python bench.py --gpus N` launches its own
+N ranks when no launcher set WORLD_SIZE.
 
 Beside the headline the line carries (rank 0, N = 1 only, all outside the timed region):
   config.api_*          the same work through qatzip.h itself: ONE qzCompress / qzDecompress call of --api-mb (2047) MiB on
                         qzMalloc(PINNED_MEM) buffers, PCIe both ways included, and its ratio to min(link, kernel rate)
+                        (the decode takes the member in two pieces while it arrives: profiles/r4_api_decompress.txt)
   config.pcie_*         plain pinned hipMemcpyAsync, 1 GiB each way, on this box
   config.concurrent_sessions   the buffer as 2 GiB calls of two sessions started together (the harness' -t)
-  config.raw_sweep      BASELINE config 3: QZ_DEFLATE_RAW, hw_buff_sz 16 / 64 / 128 KB
-  config.lz4            BASELINE config 4: LZ4 frames of 64 KB with XXH32
-  roofline              the dominant kernel against the HBM peak (datasheet) and the copy rate measured on this box
-  roofline_decode       the two inflate kernels of a call, the same way
+  config.raw_sweep      BASELINE config 3: QZ_DEFLATE_RAW, hw_buff_sz 16 / 64 / 128 KB - call rates, the kernels' own
+                        milliseconds (HIP events inside the library), their fraction of the HBM peak and their measured HBM
+                        traffic per launch (profiles/r4_raw<K>_pmc.json)
+  config.lz4            BASELINE config 4: LZ4 frames of 64 KB with XXH32, the same way (profiles/r4_lz4_pmc.json)
+  roofline              the dominant kernel (K1, qzk_lz77_pull_kernel) against the HBM peak (datasheet) and the copy rate
+                        measured on this box; traffic = HBM bytes per launch from profiles/r4_pmc.json
+  roofline_decode       the two inflate kernels of a call (phase A + phase B), the same way
   cpu_baseline          the software path's port on every physical core of this host, and this host's own libz
+`traffic` fields are read from the committed rocprofv3 --pmc summaries and only when those were taken from THESE sources
+(every summary carries the SHA-256 of qatzip_amd/csrc; src_sha256() below) with this command's --mb - null otherwise.
 
 Prints ONE JSON line on rank 0.
 """
