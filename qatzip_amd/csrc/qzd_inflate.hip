@@ -268,13 +268,14 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
                            d_comp, d_out, d_segs, d_res, nsegs, ts_d, K, lit_d, seq_d, ch_d, (const uint32_t *)NULL, 0u);
         HIPCHK(c, hipEventRecord(c->ev[1][2], st));
     } else {
-        /* phase B over QZD_SO_PARTS ranges of the output, in output order; each range leaves for the host on the copy
+        /* phase B over up to QZD_SO_PARTS ranges of the output, in output order; each range leaves for the host on the copy
          * stream as soon as its launch is done, while the next range is being resolved.  (Whether the ranges are what
          * the caller wanted is decided afterwards, from the results; a decode that turns out wrong is simply copied
          * again as a whole.) */
+        const uint32_t parts = std::min<uint32_t>(QZD_SO_PARTS, std::max<uint32_t>(1u, nsegs / 4096u));      /* (as two_phase_resolve) */
         uint64_t off[QZD_SO_PARTS + 1];
-        for (uint32_t p = 0; p < QZD_SO_PARTS; p++) {
-            const uint32_t first = (uint32_t)((uint64_t)nsegs * p / QZD_SO_PARTS), end = (uint32_t)((uint64_t)nsegs * (p + 1) / QZD_SO_PARTS);
+        for (uint32_t p = 0; p < parts; p++) {
+            const uint32_t first = (uint32_t)((uint64_t)nsegs * p / parts), end = (uint32_t)((uint64_t)nsegs * (p + 1) / parts);
             off[p] = hs[c->so_nat[first]].out_off;
             const qzk_infseg &lastseg = hs[c->so_nat[end - 1]];
             off[p + 1] = lastseg.out_off + lastseg.out_cap;
@@ -283,12 +284,12 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
             HIPCHK(c, hipEventRecord(c->so_ev[p], st));
         }
         HIPCHK(c, hipEventRecord(c->ev[1][2], st));
-        for (uint32_t p = 0; p < QZD_SO_PARTS; p++) {       /* a pageable destination makes these block the host: all launches are out already */
+        for (uint32_t p = 0; p < parts; p++) {       /* a pageable destination makes these block the host: all launches are out already */
             HIPCHK(c, hipStreamWaitEvent(c->st[1], c->so_ev[p], 0));
             HIPCHK(c, hipMemcpyAsync(c->so_host + off[p], d_out + off[p], off[p + 1] - off[p], hipMemcpyDeviceToHost, c->st[1]));
         }
         HIPCHK(c, hipStreamSynchronize(c->st[1]));
-        c->so_sent = off[QZD_SO_PARTS];
+        c->so_sent = off[parts];
     }
     HIPCHK(c, ctl_copy(st_res, d_res, rb, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -322,7 +323,9 @@ static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, 
     HIPCHK(c, ctl_copy(d_segs, c->h_aux, sb, st));
     HIPCHK(c, ctl_copy(c->tp.ord, c->h_aux + o_ord, (size_t)count * 4, st));
     HIPCHK(c, hipEventRecord(c->ev[1][0], st));
-    const uint32_t parts = h_dst && count >= QZD_LANE_MIN_SEGS ? QZD_SO_PARTS : 1u;
+    /* ranges of the output that leave one behind the other: a launch lasts as long as its slowest segment (~1 ms for 64 KB),
+     * so a range is worth a launch of its own from ~4096 segments on (eight launches over 3000 segments took 8.8 ms, one 1.3) */
+    const uint32_t parts = !h_dst ? 1u : std::min<uint32_t>(QZD_SO_PARTS, std::max<uint32_t>(1u, count / 4096u));
     uint64_t off[QZD_SO_PARTS + 1];
     for (uint32_t p = 0; p < parts; p++) {
         const uint32_t first = (uint32_t)((uint64_t)count * p / parts), end = (uint32_t)((uint64_t)count * (p + 1) / parts);
@@ -906,6 +909,10 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
      * cannot leave before the first piece's phases are over, and the second piece's phase A hides behind the first one's way out */
     for (uint32_t p = 0; p <= P; p++)
         cut[p] = p == P ? n : p == 0 ? 0 : P == 2 ? (n / 3) & ~(uint64_t)4095 : (n * (2 * p - (p >= 2 ? 2 : 1)) / (2 * P - 2)) & ~(uint64_t)4095;
+    if (const char *ce = getenv("QATZIP_AMD_PIPE_CUTS")) {          /* developer aid: the pieces' boundaries in percent, "10,40" */
+        uint32_t k = 1;
+        for (const char *q = ce; *q && k < P; k++) { cut[k] = (n * (uint64_t)atoi(q) / 100) & ~(uint64_t)4095; while (*q && *q != ',') q++; if (*q) q++; }
+    }
     std::vector<std::thread> th;
     for (uint32_t p = 0; p < P; p++)
         th.emplace_back(pipe_piece, c->pipe_ctx[p], c, &S, p, (const uint8_t *)d_src, n, d_dst, dst_cap, seg_hint, (const uint64_t *)cut, h_dst);
