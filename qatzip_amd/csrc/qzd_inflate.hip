@@ -914,8 +914,13 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
         for (const char *q = ce; *q && k < P; k++) { cut[k] = (n * (uint64_t)atoi(q) / 100) & ~(uint64_t)4095; while (*q && *q != ',') q++; if (*q) q++; }
     }
     std::vector<std::thread> th;
-    for (uint32_t p = 0; p < P; p++)
-        th.emplace_back(pipe_piece, c->pipe_ctx[p], c, &S, p, (const uint8_t *)d_src, n, d_dst, dst_cap, seg_hint, (const uint64_t *)cut, h_dst);
+    th.reserve(P);
+    for (uint32_t p = 0; p < P; p++) {
+        /* a piece whose thread cannot be started counts as failed (the others must not wait for it), and the call goes
+         * through as a whole below - nothing may leave this C entry point as an exception */
+        try { th.emplace_back(pipe_piece, c->pipe_ctx[p], c, &S, p, (const uint8_t *)d_src, n, d_dst, dst_cap, seg_hint, (const uint64_t *)cut, h_dst); }
+        catch (...) { pipe_fail(&S, p); }
+    }
     /* the copy, two pieces in flight; a piece is the helpers' when the host has seen its copy end.  (A pageable source makes
      * every copy block until it is over: the same, one at a time.) */
     bool copy_ok = true;
