@@ -295,6 +295,56 @@ def test_speculative_inflate_matches_serial(sim):
     assert taken > 50            # the speculative kernel really decoded most of the ordinary segments itself
 
 
+def test_damaged_streams_end_in_an_error_or_in_zlibs_own_bytes(sim):
+    """a decoder must never crash, hang or write outside its output: a segment with flipped bits (most of them in the block
+    header, which is decoded in LDS and registers since round 4) or cut short is reported as an error - or, when zlib decodes
+    the damaged stream too and it fills the segment exactly, comes out as the bytes zlib produces (tools/sim_fuzz_corrupt.py
+    is the campaign; the reference's flipped-byte cases: SURVEY 8b, src/qatzip_sw.c:357-361)"""
+    import random
+    seg_dt = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
+    res_dt = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
+    for f in (sim.sim_inflate, sim.sim_inflate_lane):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    sim.sim_inflate_spec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    decoders = (("wave", sim.sim_inflate), ("lane", sim.sim_inflate_lane),
+                ("k4", lambda a, b, c, d, e: sim.sim_inflate_spec(a, b, c, d, e, 4)),
+                ("k16", lambda a, b, c, d, e: sim.sim_inflate_spec(a, b, c, d, e, 16)))
+    errors = same = 0
+    for seed in range(1, 241):
+        rng = random.Random(seed)
+        kind = rng.choice(datagen.KINDS)
+        n = rng.choice([rng.randrange(1, 300), rng.randrange(300, 20000)])
+        src = datagen.gen_bytes(kind, n, 9000 + seed)
+        co = zlib.compressobj(rng.choice([1, 6, 9]), zlib.DEFLATED, -15, 9, rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY]))
+        comp = bytearray(co.compress(src) + co.flush())
+        if rng.random() < 0.15 and len(comp) > 4:
+            comp = comp[:rng.randrange(1, len(comp))]
+        else:
+            for _ in range(rng.choice([1, 1, 2, 5])):
+                at = rng.randrange(0, min(len(comp), 120)) if rng.random() < 0.7 else rng.randrange(0, len(comp))
+                comp[at] ^= 1 << rng.randrange(8)
+        comp = bytes(comp)
+        want = None
+        try:
+            d = zlib.decompressobj(-15)
+            out = d.decompress(comp, n + 1)
+            if d.eof and len(out) == n:
+                want = out
+        except zlib.error:
+            pass
+        for name, fn in decoders:
+            cbuf = np.frombuffer(comp + b"\0" * 64, np.uint8).copy(); obuf = np.full(n + 64, 0xAA, np.uint8)
+            sa = np.array([(0, 0, len(comp), n, 0, len(comp))], dtype=seg_dt); res = np.zeros(1, res_dt)
+            fn(cbuf.ctypes.data, obuf.ctypes.data, sa.ctypes.data, res.ctypes.data, 1)
+            assert bytes(obuf[n:]) == b"\xaa" * 64, (seed, name)
+            if res[0]["status"] >= 0 and res[0]["out_len"] == n:
+                assert want is not None and bytes(obuf[:n]) == want, (seed, name, kind, n)
+                same += 1
+            else:
+                errors += 1
+    assert errors > 200 and same > 50, (errors, same)
+
+
 def test_lz4_linked_frames_match_liblz4_goldens(sim):
     """a QZ_LZ4 call above 64 KB: ONE frame with linked blocks (LZ4F_compressFrame, src/qatzip_sw.c:451-456) - the kernel
     against liblz4 1.9.3's own frames (tests/golden/lz4_linked) and the oracle on a few more shapes"""
