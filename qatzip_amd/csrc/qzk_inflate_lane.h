@@ -27,6 +27,7 @@
 #ifndef QZK_INFLATE_LANE_H
 #define QZK_INFLATE_LANE_H
 #include "qzk_inflate.h"
+#include "qzk_lz_batch.h"
 
 #ifdef QZ_SIM
 #define QZK_PIN(x) ((void)0)
@@ -990,80 +991,24 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_tok_kernel(const uint8_t *comp, const qzk_inf
 /* ------------------------------------------------------------------ phase B */
 QZ_DEV uint32_t qzk_wave_scan_incl(uint32_t v, int lane) { (void)lane; return qz_wave_incl_scan(v); }
 
-/* Phase B reads back bytes its own wave stored a moment ago (a match's source is earlier output): the stores are made
- * visible by a workgroup-scope fence (s_waitcnt vmcnt(0): the wave waits for its stores to reach the L2 at every
- * dependency step).  Serving those loads from the L2 instead (non-temporal loads, wave-local fence, nothing waits) was
- * measured slower: every one of them then misses the L1. */
-#define QZK_RLD64(p) qzk_ld64u(p)
-#define QZK_RLD32(p) qz_ld32(p)
-#define QZK_RLD16(p) qz_ld16(p)
-#define QZK_RLD8(p) (*(const uint8_t *)(p))
+/* phase B orders its direct writes (stored blocks, runs too long for a batch) before whatever reads them back */
 #define QZK_RSYNC() qz_wave_sync()
-
-/* copy one match inside the output: len bytes from d - dist to d (the classic overlapping LZ77 copy) */
-QZ_DEV void qzk_copy_match(uint8_t *d, uint32_t dist, uint32_t len)
-{
-    const uint8_t *s = d - dist;
-    if (dist >= 8) {
-        if (len >= 8) {
-            uint32_t i = 0;
-            for (; i + 8 <= len; i += 8) qzk_st64u(d + i, QZK_RLD64(s + i));
-            if (i < len) qzk_st64u(d + len - 8, QZK_RLD64(s + len - 8));     /* overlapping tail, same bytes again */
-        } else {
-            if (len & 4) { ((qz_u32u *)d)->v = QZK_RLD32(s); d += 4; s += 4; }
-            if (len & 2) { ((qz_u16u *)d)->v = (uint16_t)QZK_RLD16(s); d += 2; s += 2; }
-            if (len & 1) *d = QZK_RLD8(s);
-        }
-        return;
-    }
-    /* period < 8: build 16 bytes of the periodic pattern in registers, then every 8-byte step is a funnel shift */
-    uint64_t P = 0;
-    for (uint32_t i = 0; i < dist; i++) P |= (uint64_t)QZK_RLD8(s + i) << (8 * i);
-    uint64_t q0 = 0, q1 = 0;
-    for (uint32_t t = 0, ph = 0; t < 16; t++) {
-        const uint64_t byte = (P >> (8 * ph)) & 0xff;
-        if (t < 8) q0 |= byte << (8 * t); else q1 |= byte << (8 * (t - 8));
-        if (++ph == dist) ph = 0;
-    }
-    uint32_t ph = 0, i = 0;
-    for (; i + 8 <= len; i += 8) {
-        qzk_st64u(d + i, ph ? (q0 >> (8 * ph)) | (q1 << (64 - 8 * ph)) : q0);
-        ph += 8; while (ph >= dist) ph -= dist;
-    }
-    if (i < len) {
-        const uint64_t v = ph ? (q0 >> (8 * ph)) | (q1 << (64 - 8 * ph)) : q0;
-        for (uint32_t k = 0; i + k < len; k++) d[i + k] = (uint8_t)(v >> (8 * k));
-    }
-}
 
 #ifdef QZK_SPEC_PROF
 __device__ unsigned long long qzk_stamp_b[2];
 #endif
 /* one wave per segment; QZK_RES_WAVES segments per workgroup (one: single-wave workgroups).  ts_stride sub-streams per segment (1 after the serial
  * phase A, K after the speculative one); the chain says which pieces of which sub-streams make up the segment.  The
- * output-dependent checks (capacity, history) live here because a speculative sub-decoder does not know its offset. */
+ * output-dependent checks (capacity, history) live here because a speculative sub-decoder does not know its offset.
+ * The copying itself is qzk_lz_batch.h (round 5): batches of up to 64 sequences put together in an LDS window, whole 16-byte
+ * rows out, one exposed memory round trip per batch. */
 #ifndef QZK_RES_WAVES
-#define QZK_RES_WAVES 1            /* segments (waves) per workgroup: 1 / 2 / 4 / 8 -> 11.6 / 11.9 / 13.1 / 15.0 ms per 2 GiB call - a
+#define QZK_RES_WAVES 1            /* segments (waves) per workgroup: 1 / 2 / 4 / 8 -> 11.6 / 11.9 / 13.1 / 15.0 ms per 2 GiB call (round 4) - a
                                     * workgroup leaves with its slowest segment, and segments differ */
 #endif
 #ifndef QZK_RES_OCC
-#define QZK_RES_OCC 6              /* waves per SIMD the register budget is cut for (measured: 8 -> 15.6 ms and 7 -> 19.1 ms with their spills, 6 -> 13.2 ms) */
+#define QZK_RES_OCC 6              /* waves per SIMD the register budget is cut for: 75 VGPRs, nothing in scratch (7 -> 4 spilled, 8 -> 12) */
 #endif
-#ifndef QZK_COOP_LEN
-#define QZK_COOP_LEN 32            /* matches at least this long are copied by the whole wave */
-#endif
-/* A batch of 64 sequences is ~350 bytes of output on the bench data, and copying it as it stands is address-bound: every
- * match is a per-lane load and a per-lane store at an address of its own (64 lanes, 64 lines, per dependency level), every
- * 64 literals a store scattered over the batch.  Batches whose output fits QZK_RES_LIM bytes are therefore put together in
- * LDS and leave as whole 16-byte rows: literals land in the wave's buffer, matches whose source lies before the batch read
- * it from memory once (8 bytes a trip, no dependency between them: everything before the batch is final), matches inside
- * the batch are byte copies within LDS in dependency order, and the finished batch goes out row by row.  The buffer is laid
- * out with the destination's own 16-byte phase, so a row of LDS is a row of memory. */
-#ifndef QZK_RES_LIM
-#define QZK_RES_LIM 3072
-#endif
-#define QZK_RES_BUF (QZK_RES_LIM + 32)
-typedef qzk_u32x4 qzk_res_u32x4;
 
 QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                 const qzk_tokseg *ts, uint32_t ts_stride, const uint8_t *lits, const qzk_seq *seqs,
@@ -1071,11 +1016,11 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8
 {
     /* `order`: the launch covers `count` segments picked by index (a range of the OUTPUT, so that it can leave for the
      * host while the next range is resolved); NULL: all nsegs in array order */
-    QZ_LDS __attribute__((aligned(16))) uint8_t obuf_all[QZK_RES_WAVES][QZK_RES_BUF];
+    QZ_LDS __attribute__((aligned(16))) uint8_t obuf_all[QZK_RES_WAVES][QZK_RB_OB];
+    QZ_LDS __attribute__((aligned(16))) uint8_t lbuf_all[QZK_RES_WAVES][QZK_RB_LT];
 #ifdef QZK_SPEC_PROF
     if ((threadIdx.x & 63) == 0) atomicMin(&qzk_stamp_b[0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
-    uint8_t *const ob = obuf_all[threadIdx.x >> 6];
     const int lane = qz_lane();
     const uint32_t widx = blockIdx.x * QZK_RES_WAVES + (threadIdx.x >> 6);
     if (widx >= (order ? count : nsegs)) return;
@@ -1083,19 +1028,19 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8
     if (sidx >= nsegs) return;
     const qzk_infseg sg = segs[sidx];
     if (res[sidx].status < 0 || (sg.flags & QZK_INF_COUNT_ONLY)) return;
-    uint8_t *o = out + sg.out_off;
-    const uint64_t hist = (sg.flags & QZK_INF_THROUGH_FLUSH) ? sg.out_off : 0;     /* bytes a match may reach back before o */
+    qzk_rb S;
+    qzk_rb_init(&S, obuf_all[threadIdx.x >> 6], lbuf_all[threadIdx.x >> 6], out + sg.out_off,
+                (sg.flags & QZK_INF_THROUGH_FLUSH) ? sg.out_off : 0 /* bytes a match may reach back before the segment */, sg.out_cap);
     const uint32_t nel = chains[sidx].nel;
-    uint32_t obase = 0;                                 /* output bytes of earlier batches */
     int err = 0;
     for (uint32_t e = 0; e < nel && !err; e++) {
         const qzk_chain_el ce = chains[sidx].el[e];
         if (ce.sub == QZK_PIECE_RAW) {                  /* a stored block: copy it from the compressed input */
-            if ((uint64_t)obase + ce.seq_count > sg.out_cap) { err = QZK_INF_EOUT; break; }
-            const uint8_t *s = comp + sg.in_off + ce.seq_first;
-            for (uint32_t i = (uint32_t)lane; i < ce.seq_count; i += 64) o[obase + i] = s[i];
+            if ((uint64_t)S.obase + ce.seq_count > sg.out_cap) { err = QZK_INF_EOUT; break; }
+            qzk_rb_flush(&S, lane);
+            qzk_rb_direct(&S, comp + sg.in_off + ce.seq_first, ce.seq_count, lane);
             QZK_RSYNC();
-            obase += ce.seq_count;
+            qzk_rb_skip(&S, ce.seq_count);
             continue;
         }
         const qzk_tokseg tk = ts[(uint64_t)sidx * ts_stride + ce.sub];
@@ -1103,164 +1048,39 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8
         const qzk_seq *sq = seqs + tk.seq_off + ce.seq_first;
         const uint32_t ns = ce.seq_count;
         uint32_t lbase = 0;                             /* literal bytes of this piece consumed by earlier batches */
-        for (uint32_t b0 = 0; b0 < ns && !err; b0 += 64) {
-            const uint32_t i = b0 + (uint32_t)lane;
-            uint32_t litrun = 0, mlen = 0, dist = 1;
-            if (i < ns) { const qzk_seq q = sq[i]; litrun = q.litrun; mlen = q.mlen; dist = (uint32_t)q.dm1 + 1; }
-            if (i == 0) litrun -= ce.lrun_skip;         /* literals the sub-decoder produced before it was in step */
-            const uint32_t s_tot = qzk_wave_scan_incl(litrun + mlen, lane), s_lit = qzk_wave_scan_incl(litrun, lane);
-            const uint32_t Tb = qz_readlane(s_tot, 63), Lb = qz_readlane(s_lit, 63);
-            const uint32_t my_o = obase + s_tot - (litrun + mlen);       /* where my literals land */
-            const uint32_t my_l0 = s_lit - litrun;                       /* my first literal, batch-relative */
-            const uint32_t my_m = my_o + litrun;                         /* where my match lands */
-            if ((uint64_t)obase + Tb > sg.out_cap) err = QZK_INF_EOUT;
-            else if (qz_ballot(mlen != 0 && (uint64_t)dist > (uint64_t)my_m + hist) != 0) err = QZK_INF_EHIST;
-            if (err) break;
-            if (Tb <= QZK_RES_LIM) {                                        /* wave-uniform */
-                /* ---- the batch in LDS: position p of the segment's output sits at ob[p - obase + sh] ---- */
-                const uint32_t sh = (uint32_t)((uintptr_t)(o + obase) & 15);
-#define QZK_OBI(p) ((uint32_t)(p) - obase + sh)                             /* index in ob of output position p >= obase (plain LDS indices: a
-                                                                             * biased LDS pointer does not survive a cast to a flat one) */
-                for (uint32_t k0 = 0; k0 < Lb; k0 += 64) {
-                    const uint32_t k = k0 + (uint32_t)lane;
-                    int j = 0;
-                    for (int step = 32; step; step >>= 1) if (qz_shfl(s_lit, j + step - 1) <= k) j += step;
-                    const uint32_t oj = qz_shfl(my_o, j), lj = qz_shfl(my_l0, j);
-                    if (k < Lb) ob[QZK_OBI(oj + (k - lj))] = lp[lbase + k];
-                }
-                /* no wait for the rows of earlier batches: a source before the batch is read by loads issued behind the
-                 * stores that wrote it, and a wave's memory operations reach the L2 in issue order */
-                qz_lds_sync();
-                /* matches whose (first period of) source ends before the batch: read from memory, nothing to wait for */
-                const int64_t sp0 = (int64_t)my_m - (int64_t)dist;
-                const uint32_t per = mlen < dist ? mlen : dist;
-                const bool outside = mlen != 0 && sp0 + (int64_t)per <= (int64_t)obase;
-                if (outside && mlen < QZK_COOP_LEN) {
-                    const uint8_t *sp = o + sp0;
-                    uint8_t *d = ob + QZK_OBI(my_m);
-                    if (dist >= mlen) {
-                        if (mlen >= 8) {
-                            uint32_t i = 0;
-                            for (; i + 8 <= mlen; i += 8) qzk_st64u(d + i, qzk_ld64u(sp + i));
-                            if (i < mlen) qzk_st64u(d + mlen - 8, qzk_ld64u(sp + mlen - 8));
-                        } else {
-                            uint32_t i = 0;
-                            if (mlen & 4) { ((qz_u32u *)d)->v = qz_ld32(sp); i = 4; }
-                            if (mlen & 2) { ((qz_u16u *)(d + i))->v = (uint16_t)qz_ld16(sp + i); i += 2; }
-                            if (mlen & 1) d[i] = sp[i];
-                        }
-                    } else {                                                /* a short period from before the batch, repeated */
-                        for (uint32_t i = 0, ph = 0; i < mlen; i++) { d[i] = sp[ph]; if (++ph == dist) ph = 0; }
-                    }
-                }
-                {
-                    uint64_t wide = qz_ballot(outside && mlen >= QZK_COOP_LEN);
-                    while (wide) {
-                        const int g = qz_ctz64(wide);
-                        wide &= wide - 1;
-                        const uint32_t M = qz_readlane(my_m, g), D = qz_readlane(dist, g), L = qz_readlane(mlen, g);
-                        const uint32_t stp = 64u % D;
-                        uint32_t r = (uint32_t)lane % D;
-                        const uint8_t *sp = o + ((int64_t)M - (int64_t)D);
-                        for (uint32_t i = (uint32_t)lane; i < L; i += 64) {
-                            ob[QZK_OBI(M + i)] = sp[r];
-                            r += stp; if (r >= D) r -= D;
-                        }
-                    }
-                }
-                qz_lds_sync();
-                /* matches that read from the batch itself: dependency order, bytes from LDS (from memory where a source
-                 * starts before the batch) */
-                const uint32_t src_end = my_m - dist + per;
-                uint64_t pending = qz_ballot(mlen != 0 && !outside);
-                while (pending) {
-                    const int f = qz_ctz64(pending);
-                    const uint32_t m_f = qz_readlane(my_m, f);
-                    const bool ready = ((pending >> lane) & 1) && (lane == f || src_end <= m_f);
-                    uint64_t wide = qz_ballot(ready && mlen >= QZK_COOP_LEN);
-                    if (ready && mlen < QZK_COOP_LEN) {
-                        if (sp0 >= (int64_t)obase) qzk_copy_match(ob + QZK_OBI(my_m), dist, mlen);    /* source and match in the buffer: 8 bytes a step */
-                        else for (uint32_t i = 0; i < mlen; i++) {                                   /* the source starts before the batch (rare) */
-                            const int64_t q = sp0 + (int64_t)i;
-                            uint8_t v;
-                            if (q >= (int64_t)obase) v = ob[QZK_OBI((uint32_t)q)]; else v = o[q];
-                            ob[QZK_OBI(my_m + i)] = v;
-                        }
-                    }
-                    while (wide) {
-                        const int g = qz_ctz64(wide);
-                        wide &= wide - 1;
-                        const uint32_t M = qz_readlane(my_m, g), D = qz_readlane(dist, g), L = qz_readlane(mlen, g);
-                        /* the source period [M - D, M) is final (below the first unfinished match, or this is it): byte i of
-                         * the match is byte i mod D of the period */
-                        const uint32_t stp = 64u % D;
-                        uint32_t r = (uint32_t)lane % D;
-                        const int64_t s0 = (int64_t)M - (int64_t)D;
-                        for (uint32_t i = (uint32_t)lane; i < L; i += 64) {
-                            const int64_t q = s0 + (int64_t)r;
-                            uint8_t v;
-                            if (q >= (int64_t)obase) v = ob[QZK_OBI((uint32_t)q)]; else v = o[q];
-                            ob[QZK_OBI(M + i)] = v;
-                            r += stp; if (r >= D) r -= D;
-                        }
-                    }
-                    pending &= ~qz_ballot(ready);
-                    qz_lds_sync();
-                }
-                /* out: whole 16-byte rows where the batch fills them, bytes at its two ends */
-                {
-                    uint8_t *const g0 = o + obase - sh;                     /* 16-byte aligned */
-                    const uint32_t rows = (sh + Tb + 15) >> 4;
-                    for (uint32_t rw = (uint32_t)lane; rw < rows; rw += 64) {
-                        const uint32_t lo = rw << 4;
-                        if (lo >= sh && lo + 16 <= sh + Tb) *(qzk_res_u32x4 *)(g0 + lo) = *(const qzk_res_u32x4 *)(ob + lo);
-                        else for (uint32_t t = 0; t < 16; t++) if (lo + t >= sh && lo + t < sh + Tb) g0[lo + t] = ob[lo + t];
-                    }
-                }
-                qz_lds_sync();                                              /* the next batch writes the buffer again */
-                obase += Tb; lbase += Lb;
-                continue;
-#undef QZK_OBI
-            }
-            /* literal k of the batch belongs to the first sequence whose inclusive literal count exceeds k */
-            for (uint32_t k0 = 0; k0 < Lb; k0 += 64) {
-                const uint32_t k = k0 + (uint32_t)lane;
-                int j = 0;
-                for (int step = 32; step; step >>= 1) if (qz_shfl(s_lit, j + step - 1) <= k) j += step;
-                const uint32_t oj = qz_shfl(my_o, j), lj = qz_shfl(my_l0, j);
-                if (k < Lb) o[oj + (k - lj)] = lp[lbase + k];
-            }
-            QZK_RSYNC();                                                /* matches may read these literals */
-            const uint32_t src_end = my_m - dist + (mlen < dist ? mlen : dist);
-            uint64_t pending = qz_ballot(mlen != 0);
-            while (pending) {
-                /* everything below the first unfinished match is final: it and every match reading only from there go now */
-                const int f = qz_ctz64(pending);
-                const uint32_t m_f = qz_readlane(my_m, f);
-                const bool ready = ((pending >> lane) & 1) && (lane == f || src_end <= m_f);
-                /* short matches: their lane copies them.  Long ones (runs, repeated records) would be dozens of
-                 * one-lane load/store pairs on a texture path that is already the bottleneck: the whole wave copies
-                 * them, a byte per lane and step, reading the source period-wise when the match overlaps itself */
-                uint64_t wide = qz_ballot(ready && mlen >= QZK_COOP_LEN);
-                if (ready && mlen < QZK_COOP_LEN) qzk_copy_match(o + (int64_t)my_m, dist, mlen);
-                while (wide) {
-                    const int g = qz_ctz64(wide);
-                    wide &= wide - 1;
-                    const uint32_t M = qz_readlane(my_m, g), D = qz_readlane(dist, g), L = qz_readlane(mlen, g);
-                    const uint32_t stp = 64u % D;
-                    uint32_t r = (uint32_t)lane % D;
-                    const uint8_t *sp = o + ((int64_t)M - (int64_t)D);
-                    for (uint32_t i = (uint32_t)lane; i < L; i += 64) {
-                        o[M + i] = QZK_RLD8(sp + r);
-                        r += stp; if (r >= D) r -= D;
-                    }
-                }
-                pending &= ~qz_ballot(ready);
+        uint32_t b0 = 0;
+        uint64_t cur = (uint32_t)lane < ns ? qzk_rb_ld64((const uint8_t *)(sq + lane)) : 0;
+        while (b0 < ns) {
+            /* a record: {u32 literal run, u16 match length, u16 distance - 1} */
+            uint32_t litrun = (uint32_t)cur, mlen = (uint32_t)(cur >> 32) & 0xffffu, dist = (uint32_t)(cur >> 48) + 1;
+            if (b0 + (uint32_t)lane == 0) litrun -= ce.lrun_skip;      /* literals the sub-decoder produced before it was in step */
+            uint32_t s_tot = qzk_wave_scan_incl(litrun + mlen, lane), s_lit = qzk_wave_scan_incl(litrun, lane);
+            uint32_t n = qzk_rb_fit(s_tot, s_lit);
+            if (n > ns - b0) n = ns - b0;
+            if (n == 0) {
+                /* the first sequence alone is more than a batch holds (a long literal run): straight to the output */
+                const uint32_t L = qz_readlane(litrun, 0), M = qz_readlane(mlen, 0), D = qz_readlane(dist, 0);
+                if ((uint64_t)S.obase + L + M > sg.out_cap) { err = QZK_INF_EOUT; break; }
+                if (M != 0 && (uint64_t)D > (uint64_t)S.obase + L + S.hist) { err = QZK_INF_EHIST; break; }
+                qzk_rb_flush(&S, lane);
+                qzk_rb_direct(&S, lp + lbase, L, lane);
                 QZK_RSYNC();
+                qzk_rb_skip(&S, L);
+                if (M) { qzk_rb_direct_match(&S, D, M, lane); QZK_RSYNC(); qzk_rb_skip(&S, M); }
+                lbase += L; b0 += 1;
+                cur = b0 + (uint32_t)lane < ns ? qzk_rb_ld64((const uint8_t *)(sq + b0 + lane)) : 0;
+                continue;
             }
-            obase += Tb; lbase += Lb;
+            /* the records of the batch after this one: asked for now, used when this batch is out */
+            const uint64_t nxt = b0 + n + (uint32_t)lane < ns ? qzk_rb_ld64((const uint8_t *)(sq + b0 + n + lane)) : 0;
+            if ((uint32_t)lane >= n) { s_tot -= litrun + mlen; s_lit -= litrun; litrun = 0; mlen = 0; }    /* (sums of idle lanes: never read) */
+            const uint32_t Tb = qz_readlane(s_tot, (int)n - 1), Lb = qz_readlane(s_lit, (int)n - 1);
+            err = qzk_rb_batch(&S, lp + lbase, Lb, s_lit - litrun, litrun, mlen, dist, s_tot, Tb, lane);
+            lbase += Lb; b0 += n;
+            cur = nxt;
         }
     }
+    if (!err) qzk_rb_flush(&S, lane);
     if (err) res[sidx].status = err;                    /* wave-uniform value, every lane stores the same word */
 }
 

@@ -311,7 +311,7 @@ static void two_phase_serial(const uint8_t *comp, uint8_t *out, const qzk_infseg
         ts[i].lit_off = lt; ts[i].seq_off = sqt;
         if (!(segs[i].flags & QZK_INF_COUNT_ONLY)) { lt += QZK_TOK_LITCAP(segs[i].out_cap); sqt += QZK_TOK_SEQCAP(segs[i].out_cap); }
     }
-    std::vector<uint8_t> lits(lt + 64, 0xee);
+    std::vector<uint8_t> lits(lt + 1088, 0xee);          /* phase B reads whole 16-byte rows (qzk_lz_batch.h) */
     std::vector<qzk_seq> seqs(sqt + 8);
     /* 16 segments per workgroup; the emulator wants whole waves, the kernel bounds-checks */
     sim::launch((nsegs + 15) / 16, 64, 0, [&] {
@@ -354,7 +354,7 @@ static int two_phase_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *s
             ts[(size_t)i * K + j].lit_off = lt; ts[(size_t)i * K + j].seq_off = sqt;
             lt += QZK_SPEC_LITCAP(segs[i].out_cap, K, j); sqt += QZK_SPEC_SEQCAP(segs[i].out_cap, K, j);
         }
-    std::vector<uint8_t> lits(lt + 64, 0xee);
+    std::vector<uint8_t> lits(lt + 1088, 0xee);          /* phase B reads whole 16-byte rows (qzk_lz_batch.h) */
     std::vector<qzk_seq> seqs(sqt + 8);
     const uint32_t spw = 64 / K;
     sim::launch((nsegs + spw - 1) / spw, 64, 0, [&] {
