@@ -35,6 +35,9 @@ QZ_DEV uint64_t qz_ballot(bool p) { return __ballot(p); }
 QZ_DEV uint32_t qz_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 QZ_DEV uint32_t qz_readlane(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 QZ_DEV uint32_t qz_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+/* a wave-uniform value into ONE lane of a vector register (this clang has no writelane builtin: a compare the fields of one
+ * record share, and a v_cndmask per field) */
+QZ_DEV uint32_t qz_writelane(uint32_t old, uint32_t val, int sel) { return (int)(threadIdx.x & 63) == sel ? val : old; }
 /* orders LDS traffic between the lanes of ONE wave (single-wave workgroups) */
 QZ_DEV void qz_wave_sync()
 {
@@ -58,6 +61,7 @@ QZ_DEV uint8_t qz_ld8_l2(const uint8_t *p) { return __hip_atomic_load(p, __ATOMI
 #endif
 #ifdef QZ_SIM
 static inline void qz_lds_sync() { qz_wave_sync(); }
+static inline uint32_t qz_writelane(uint32_t old, uint32_t val, int sel) { return qz_lane() == sel ? val : old; }
 static inline uint8_t qz_ld8_l2(const uint8_t *p) { return *p; }
 #endif
 

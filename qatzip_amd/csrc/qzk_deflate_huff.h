@@ -801,7 +801,10 @@ QZ_DEV void qzk_lz77_pull_body(const uint8_t *src, uint64_t src_len, uint32_t ch
              * memory operations of one wave reach the L2 in issue order */
             qz_lds_sync();
             const bool is_final = cdesc ? (cdesc[chunk] & QZK_CDESC_FINAL) != 0 : chunk == final_chunk;
-#if defined(QZK_PROF) && !defined(QZ_SIM)
+#if defined(QZK_K1_NOK2)                    /* measurement only (profiles/r5_k1_without_k2.txt): the parse and the CRC, the symbols are dropped */
+            (void)is_final;
+            out_len[chunk] = 0;                     /* wave-uniform: every lane stores the same word */
+#elif defined(QZK_PROF) && !defined(QZ_SIM)
             const uint64_t tk_ = __builtin_readcyclecounter();
             uint64_t plan_ = 0;
             qzk_huff_chunk<true>((qzk_huff_lds *)lds, qz_lane(), src + (uint64_t)chunk * chunk_sz, wlc, wdist, meta + chunk,

@@ -21,6 +21,7 @@
 #ifndef QZK_LZ4_H
 #define QZK_LZ4_H
 #include "qzk_common.h"
+#include "qzk_lz_batch.h"
 
 #define QZK_LZ4_MINMATCH 4
 #define QZK_LZ4_MFLIMIT 12
@@ -61,6 +62,50 @@ QZ_DEV uint32_t qzk_wave_xxh32(const uint8_t *p, uint32_t n, int lane)
         h = qzk_rotl(v0, 1) + qzk_rotl(v1, 7) + qzk_rotl(v2, 12) + qzk_rotl(v3, 18);
         pos = stripes << 4;
     } else h = QZK_XP5;
+    h += n;
+    while (pos + 4 <= n) { h = qzk_rotl(h + qz_ld32(p + pos) * QZK_XP3, 17) * QZK_XP4; pos += 4; }
+    while (pos < n) { h = qzk_rotl(h + p[pos] * QZK_XP5, 11) * QZK_XP1; pos++; }
+    h ^= h >> 15; h *= QZK_XP2; h ^= h >> 13; h *= QZK_XP3; h ^= h >> 16;
+    return h;
+}
+
+/* The same hash for a frame's content (tens of KB): the four accumulator chains stay serial, but their words arrive as
+ * whole 16-byte stripes - every lane fetches two of the next 128 while lanes 0-3 work through the 128 before them out of
+ * `stage` (2 KiB of LDS, 16-byte aligned), instead of four lanes fetching dwords 16 bytes apart.  Round 5: the decoder got
+ * ~10x faster (qzk_lz4d_kernel below) and four lanes' loads had become a fifth of a frame. */
+QZ_DEV uint32_t qzk_wave_xxh32_staged(const uint8_t *p, uint32_t n, uint8_t *stage, int lane)
+{
+    if (n < 16 * 128) return qzk_wave_xxh32(p, n, lane);
+    const uint32_t stripes = n >> 4;
+    uint32_t v = lane == 0 ? QZK_XP1 + QZK_XP2 : lane == 1 ? QZK_XP2 : lane == 2 ? 0u : 0u - QZK_XP1;
+    /* a stripe = two 8-byte pieces (the content may sit at any byte address) */
+    uint64_t a0 = qzk_rb_ld64(p + 16 * (uint32_t)lane), a1 = qzk_rb_ld64(p + 16 * (uint32_t)lane + 8);
+    uint64_t b0 = qzk_rb_ld64(p + 16 * (64 + (uint32_t)lane)), b1 = qzk_rb_ld64(p + 16 * (64 + (uint32_t)lane) + 8);
+    for (uint32_t s0 = 0; s0 < stripes; s0 += 128) {
+        const uint32_t cnt = stripes - s0 < 128 ? stripes - s0 : 128;
+        qz_lds_sync();                                              /* the stripes before have been worked through */
+        ((uint64_t *)stage)[2 * (uint32_t)lane] = a0; ((uint64_t *)stage)[2 * (uint32_t)lane + 1] = a1;
+        ((uint64_t *)stage)[2 * (64 + (uint32_t)lane)] = b0; ((uint64_t *)stage)[2 * (64 + (uint32_t)lane) + 1] = b1;
+        const uint32_t s1 = s0 + 128;                               /* the next 128: asked for now */
+        if (s1 + (uint32_t)lane < stripes) { a0 = qzk_rb_ld64(p + 16 * (s1 + (uint32_t)lane)); a1 = qzk_rb_ld64(p + 16 * (s1 + (uint32_t)lane) + 8); }
+        if (s1 + 64 + (uint32_t)lane < stripes) { b0 = qzk_rb_ld64(p + 16 * (s1 + 64 + (uint32_t)lane)); b1 = qzk_rb_ld64(p + 16 * (s1 + 64 + (uint32_t)lane) + 8); }
+        qz_lds_sync();
+        if (lane < 4) {
+            const uint32_t *w = (const uint32_t *)stage + lane;
+            uint32_t k = 0;
+            for (; k + 8 <= cnt; k += 8) {                          /* eight words asked for before the first is used */
+                const uint32_t x0 = w[4 * k], x1 = w[4 * k + 4], x2 = w[4 * k + 8], x3 = w[4 * k + 12], x4 = w[4 * k + 16],
+                               x5 = w[4 * k + 20], x6 = w[4 * k + 24], x7 = w[4 * k + 28];
+#define QZK_XR(x_) v = qzk_rotl(v + (x_) * QZK_XP2, 13) * QZK_XP1
+                QZK_XR(x0); QZK_XR(x1); QZK_XR(x2); QZK_XR(x3); QZK_XR(x4); QZK_XR(x5); QZK_XR(x6); QZK_XR(x7);
+#undef QZK_XR
+            }
+            for (; k < cnt; k++) v = qzk_rotl(v + w[4 * k] * QZK_XP2, 13) * QZK_XP1;
+        }
+    }
+    const uint32_t v0 = qz_readlane(v, 0), v1 = qz_readlane(v, 1), v2 = qz_readlane(v, 2), v3 = qz_readlane(v, 3);
+    uint32_t h = qzk_rotl(v0, 1) + qzk_rotl(v1, 7) + qzk_rotl(v2, 12) + qzk_rotl(v3, 18);
+    uint32_t pos = stripes << 4;
     h += n;
     while (pos + 4 <= n) { h = qzk_rotl(h + qz_ld32(p + pos) * QZK_XP3, 17) * QZK_XP4; pos += 4; }
     while (pos < n) { h = qzk_rotl(h + p[pos] * QZK_XP5, 11) * QZK_XP1; pos++; }
@@ -127,6 +172,11 @@ QZ_DEV uint32_t qzk_lz4_tld(const TAB *table, uint32_t h)
 }
 
 template <bool LINKED, typename TAB, bool GTAB = false>
+/* Syncs: every exchange between the lanes here goes through LDS (slot table, LDS hash tables: a wave's DS operations
+ * execute in order) or through the device-memory table, whose stores and `sc1` loads reach the L2 in issue order - so the
+ * lanes only need the compiler kept from reordering (qz_lds_sync), not qz_wave_sync()'s workgroup fence: that one waits
+ * (s_waitcnt vmcnt(0)) for every store still on its way, table inserts and output bytes included, a full round trip at
+ * each of the ten syncs of a sequence (round 5). */
 QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint8_t *out, uint32_t cap, TAB *table,
                                 uint32_t *slot, int lane)
 {
@@ -136,7 +186,7 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
         if (GTAB) { for (int i = lane; i < (int)(QZK_LZ4_HASHSZ * sizeof(TAB) / 16); i += 64) { qzk_lz4_u32x4 z = {0, 0, 0, 0}; ((qzk_lz4_u32x4 *)table)[i] = z; } }
         else { for (int i = lane; i < QZK_LZ4_HASHSZ; i += 64) table[i] = 0; }
     }
-    qz_wave_sync();
+    qz_lds_sync();
     const uint32_t be = bs + n;
     uint32_t op = 0, anchor = bs, ip;
     const int32_t mfl1 = (int32_t)be - QZK_LZ4_MFLIMIT + 1;     /* mflimitPlusOne */
@@ -145,7 +195,7 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
     if (n >= QZK_LZ4_MFLIMIT + 1) {
         /* first byte: the block's first position goes into the table unsearched (an independent block's is 0 - already
          * there), the search starts behind it */
-        if (LINKED) { if (lane == 0) table[qzk_lz4_hash5(in + bs)] = (TAB)bs; qz_wave_sync(); }
+        if (LINKED) { if (lane == 0) table[qzk_lz4_hash5(in + bs)] = (TAB)bs; qz_lds_sync(); }
         ip = bs + 1;
         for (;;) {
             /* ---------------- search streak from ip ---------------- */
@@ -166,9 +216,9 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                 if (live) { v = qz_ld32(in + f); h = QZK_LZ4H(f, v); cand = qzk_lz4_tld<GTAB>(table, h); }
                 const uint32_t key = h & 1023;
                 if (live) slot[key] = 64;
-                qz_wave_sync();
+                qz_lds_sync();
                 if (live) atomicMin(&slot[key], (uint32_t)lane);
-                qz_wave_sync();
+                qz_lds_sync();
                 const bool suspect = live && slot[key] != (uint32_t)lane;
                 bool hit = false;
                 if (live && !suspect) hit = QZK_LZ4NEAR(cand, f) && qz_ld32(in + cand) == v;
@@ -197,7 +247,7 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                 const int last_ins = got ? fl : (first_dead < (int)W ? first_dead - 1 : (int)W - 1);
                 if (sizeof(TAB) == 4) {
                     if (live && lane <= last_ins) atomicMax((uint32_t *)&table[h], f);
-                    qz_wave_sync();
+                    qz_lds_sync();
                 } else {
                     /* 16-bit entries have no LDS atomic: the last probe of a hash is elected through the slot table - per
                      * key the highest (rest of the hash, lane) wins, its hash is served, the other hashes on that key go
@@ -206,13 +256,13 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                     const uint32_t val = (((h >> 10) << 6) | (uint32_t)lane) + 1;
                     while (qz_ballot(pend)) {
                         if (pend) slot[key] = 0;
-                        qz_wave_sync();
+                        qz_lds_sync();
                         if (pend) atomicMax(&slot[key], val);
-                        qz_wave_sync();
+                        qz_lds_sync();
                         const uint32_t w = pend ? slot[key] : 0;
                         if (pend && w == val) table[h] = (TAB)f;
                         if (pend && ((w - 1) >> 6) == (h >> 10)) pend = false;      /* my hash was the one served */
-                        qz_wave_sync();
+                        qz_lds_sync();
                     }
                 }
                 if (got) { found = true; mpos = qz_readlane(f, fl); mcand = fcand; break; }
@@ -264,11 +314,11 @@ QZ_DEV uint32_t qzk_lz4_block_t(const uint8_t *in, uint32_t bs, uint32_t n, uint
                 uint32_t v2 = qz_ld32(in + mip - 2), v0 = qz_ld32(in + mip);
                 uint32_t h2 = QZK_LZ4H(mip - 2, v2), h0 = QZK_LZ4H(mip, v0);
                 if (lane == 0) table[h2] = (TAB)(mip - 2);
-                qz_wave_sync();
+                qz_lds_sync();
                 uint32_t mi = qzk_lz4_tld<GTAB>(table, h0);
-                qz_wave_sync();
+                qz_lds_sync();
                 if (lane == 0) table[h0] = (TAB)mip;
-                qz_wave_sync();
+                qz_lds_sync();
                 if (QZK_LZ4NEAR(mi, mip) && qz_ld32(in + mi) == v0) { token_at = op++; tok = 0; match = mi; continue; }
                 break;
             }
@@ -443,45 +493,181 @@ typedef struct { int32_t status; uint32_t in_used; uint32_t out_len; uint32_t pa
 #define QZK_LZ4_EOUT (-2)
 #define QZK_LZ4_EIN (-3)
 
-/* decode one block into o[op..); history = o[0..op) (linked frames).  returns new op or ~0u on error */
-QZ_DEV uint32_t qzk_lz4_dblock(const uint8_t *ip, uint32_t n, uint8_t *o, uint32_t op, uint32_t ocap, int lane)
+/* K5, round 5: the frame's blocks through the batch engine of qzk_lz_batch.h.  An LZ4 block is a serial token stream - a
+ * sequence's place depends on the literal runs before it - but what a sequence that BEGINS at a given byte would be depends
+ * on a handful of bytes only.  So the walk is speculated a window at a time: lane i takes the block as if a sequence began
+ * at s + i (token, literal run, offset, match length: two unaligned LDS reads out of a 1 KiB ring of the stream, refilled 512
+ * bytes at a time with the next refill already on its way), and a short chase - v_readlane of the `next` field from s on, a
+ * few scalar instructions a hop - picks the lanes that really are sequence starts.  Their records go into a queue in LDS in
+ * stream order; whenever it holds 64 (or the block is through) the wave takes as many as fit the engine's window and literal
+ * staging, one per lane, and resolves them in parallel: literals of the batch as one span of aligned rows into LDS, matches
+ * from before the window in one round trip, the rest inside LDS, whole rows out.  What the speculation cannot settle from
+ * the bytes at hand (length bytes chained beyond 270, a literal run that reaches past the ring, anything wrong) is re-read
+ * serially from memory for that one sequence.
+ * Round 4's kernel walked the stream with four or five dependent global round trips per sequence and copied a byte per lane
+ * (profiles/r4_lz4_counters.txt: 20.7 ms per GiB).  A first round-5 version walked it on the scalar unit out of a register
+ * window - ~150 scalar instructions a sequence, and a CU has ONE scalar ALU for its 24 waves: 18.3 ms. */
+#define QZK_L4_RING 1024u
+#define QZK_L4_Q 128u
+#define QZK_L4_SLOW 0xffffffffu
+typedef struct __attribute__((aligned(16))) { uint32_t lit_off, lit, ml, off; } qzk_l4rec;
+typedef struct {
+    const uint8_t *blk;         /* the block's bytes */
+    uint32_t n, lim;            /* its size; bytes that may be read from blk (to the end of the frame's input) */
+    uint8_t *ring;              /* LDS, QZK_L4_RING + 16: stream byte x at ring[x % RING], the first 16 once more behind the end */
+    qzk_l4rec *q;               /* LDS, QZK_L4_Q records */
+    uint32_t filled;            /* the ring holds the stream's [filled - RING, filled); a multiple of 512 */
+    uint32_t qh, qt;            /* the queue's head and tail (running record numbers) */
+    uint32_t s;                 /* where the next sequence begins */
+    uint64_t pre;               /* per lane: the 8 bytes at filled + 8 * lane, asked for ahead of time */
+} qzk_l4p;
+QZ_DEV uint64_t qzk_l4_fetch(const qzk_l4p *P, uint32_t at, int lane)
 {
-    uint32_t p = 0;
-    if (n == 0) return ~0u;
-    for (;;) {
-        if (p >= n) return ~0u;
-        uint32_t tok = ip[p++], len = tok >> 4;
-        if (len == 15) { uint32_t b; do { if (p >= n) return ~0u; b = ip[p++]; len += b; } while (b == 255); }
-        if (len > n - p || len > ocap - op) return ~0u;
-        qzk_wave_copy(o + op, ip + p, len, lane); op += len; p += len;
-        if (p == n) break;
-        if (n - p < 2) return ~0u;
-        uint32_t off = ip[p] | (uint32_t)ip[p + 1] << 8; p += 2;
-        if (off == 0 || off > op) return ~0u;
-        len = tok & 15;
-        if (len == 15) { uint32_t b; do { if (p >= n) return ~0u; b = ip[p++]; len += b; } while (b == 255); }
-        len += QZK_LZ4_MINMATCH;
-        if (len > ocap - op) return ~0u;
-        qz_wave_sync();                                     /* this wave's earlier stores -> its loads */
-        for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-            uint32_t si = off >= len ? i : i % off;
-            o[op + i] = o[op - off + si];
-        }
-        op += len;
+    const uint32_t o = at + 8u * (uint32_t)lane;
+    if (o + 8 <= P->lim) return qzk_rb_ld64(P->blk + o);
+    uint64_t v = 0;
+    for (uint32_t t = 0; t < 8; t++) if (o + t < P->lim) v |= (uint64_t)P->blk[o + t] << (8 * t);
+    return v;
+}
+/* the ring reaches at least 513 bytes beyond s, and s itself is in it */
+QZ_DEV void qzk_l4_stage(qzk_l4p *P, int lane)
+{
+    if (P->s >= P->filled + 512u) { P->filled = P->s & ~511u; P->pre = qzk_l4_fetch(P, P->filled, lane); }    /* a literal run longer than the ring */
+    bool put = false;
+    while (P->filled <= P->s + 512u) {
+        if (!put) qz_lds_sync();                                    /* the lanes have read what this overwrites */
+        put = true;
+        const uint32_t r = (P->filled & (QZK_L4_RING - 1)) + 8u * (uint32_t)lane;
+        *(uint64_t *)(P->ring + r) = P->pre;
+        if (r < 16) *(uint64_t *)(P->ring + QZK_L4_RING + r) = P->pre;
+        P->filled += 512u;
+        P->pre = qzk_l4_fetch(P, P->filled, lane);
     }
-    return op;
+    if (put) qz_lds_sync();
+}
+/* one sequence read serially from memory (wave-uniform): what the window could not settle.  0, or -1: not a sequence */
+QZ_DEV int qzk_l4_slow(const uint8_t *blk, uint32_t n, uint32_t *ps, qzk_l4rec *r)
+{
+    uint32_t p = *ps;
+    if (p >= n) return -1;
+    const uint32_t tok = blk[p++];
+    uint32_t lit = tok >> 4;
+    if (lit == 15) { uint32_t b; do { if (p >= n) return -1; b = blk[p++]; lit += b; } while (b == 255); }
+    if (lit > n - p) return -1;
+    r->lit_off = p; r->lit = lit; r->ml = 0; r->off = 1;
+    p += lit;
+    if (p == n) { *ps = n; return 0; }                              /* the block's last sequence: literals only */
+    if (n - p < 2) return -1;
+    const uint32_t off = (uint32_t)blk[p] | (uint32_t)blk[p + 1] << 8; p += 2;
+    if (off == 0) return -1;
+    uint32_t ml = tok & 15;
+    if (ml == 15) { uint32_t b; do { if (p >= n) return -1; b = blk[p++]; ml += b; } while (b == 255); }
+    if (p >= n) return -1;                                          /* a block ends with a literals-only sequence */
+    r->ml = ml + QZK_LZ4_MINMATCH; r->off = off;
+    *ps = p;
+    return 0;
+}
+/* one window: the sequences that begin in [s, s + 64) join the queue.  0, or -1 */
+QZ_DEV int qzk_l4_window(qzk_l4p *P, int lane)
+{
+    qzk_l4_stage(P, lane);
+    const uint32_t base = P->s, n = P->n;
+    const uint32_t p = base + (uint32_t)lane;
+    const uint32_t x = qz_ld32(P->ring + (p & (QZK_L4_RING - 1)));             /* token and the byte behind it */
+    const uint32_t tok = x & 0xff;
+    uint32_t lit = tok >> 4, ml = tok & 15, q = p + 1;
+    bool slow = p >= n;
+    if (lit == 15) { const uint32_t b = (x >> 8) & 0xff; lit += b; q++; slow = slow || b == 255; }
+    const uint32_t lit_off = q;
+    q += lit;
+    const bool last = q == n;
+    slow = slow || q > n || (!last && q + 3 > P->filled);
+    const uint32_t y = qz_ld32(P->ring + (q & (QZK_L4_RING - 1)));             /* offset and the byte behind it (garbage when slow) */
+    const uint32_t off = y & 0xffff;
+    uint32_t q2 = q + 2;
+    if (ml == 15) { const uint32_t b = (y >> 16) & 0xff; ml += b; q2++; slow = slow || (!last && b == 255); }
+    ml += QZK_LZ4_MINMATCH;
+    slow = slow || (!last && (off == 0 || q2 >= n));                            /* (q2 >= n: a block ends with a literals-only sequence) */
+    const uint32_t next = slow ? QZK_L4_SLOW : last ? n : q2;
+    /* the chase: from s on, which lanes are sequence starts */
+    uint64_t V = 0;
+    uint32_t s = base;
+    bool hit_slow = false;
+    while (s < base + 64u && s < n) {
+        const uint32_t i = s - base, nx = qz_readlane(next, (int)i);
+        if (nx == QZK_L4_SLOW) { hit_slow = true; break; }
+        V |= 1ull << i;
+        s = nx;
+    }
+    if ((V >> lane) & 1) {
+        qzk_l4rec r; r.lit_off = lit_off; r.lit = lit; r.ml = last ? 0u : ml; r.off = last ? 1u : off;
+        P->q[(P->qt + (uint32_t)qz_popc64(V & qz_below(lane))) & (QZK_L4_Q - 1)] = r;
+    }
+    P->qt += (uint32_t)qz_popc64(V);
+    if (hit_slow) {
+        qzk_l4rec r;
+        if (qzk_l4_slow(P->blk, n, &s, &r)) return -1;
+        if (lane == 0) P->q[P->qt & (QZK_L4_Q - 1)] = r;
+        P->qt++;
+    }
+    P->s = s;
+    qz_lds_sync();
+    return 0;
 }
 
-QZ_KERNEL qzk_lz4d_kernel(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *segs, qzk_lz4res *res, uint32_t nsegs)
+/* decode one block through S (history = the frame's output so far: linked frames).  0 or an error */
+QZ_DEV int qzk_lz4_dblock(qzk_rb *S, const uint8_t *blk, uint32_t n, uint32_t lim, uint8_t *ring, qzk_l4rec *queue, int lane)
 {
+    if (n == 0) return -1;
+    qzk_l4p P; P.blk = blk; P.n = n; P.lim = lim; P.ring = ring; P.q = queue; P.filled = 0; P.qh = P.qt = 0; P.s = 0;
+    P.pre = qzk_l4_fetch(&P, 0, lane);
+    for (;;) {
+        while (P.s < n && P.qt - P.qh < 64u) if (qzk_l4_window(&P, lane)) return -1;
+        const uint32_t cnt = P.qt - P.qh < 64u ? P.qt - P.qh : 64u;
+        if (cnt == 0) break;                                        /* (the block is through and every sequence resolved) */
+        qzk_l4rec r; r.lit_off = 0; r.lit = 0; r.ml = 0; r.off = 1;
+        if ((uint32_t)lane < cnt) r = P.q[(P.qh + (uint32_t)lane) & (QZK_L4_Q - 1)];
+        const uint32_t span0 = qz_readlane(r.lit_off, 0);
+        uint32_t s_tot = qz_wave_incl_scan(r.lit + r.ml);
+        const uint32_t s_span = r.lit_off + r.lit - span0;         /* grows with the lane: the literals lie in stream order */
+        const uint32_t fit = (uint32_t)qz_popc64(qz_ballot((uint32_t)lane < cnt && s_tot <= QZK_RB_LIM && s_span <= QZK_RB_LITMAX));
+        if (fit == 0) {
+            /* one sequence that is more than a batch holds: straight to the output */
+            const uint32_t gL = qz_readlane(r.lit, 0), gM = qz_readlane(r.ml, 0), gD = qz_readlane(r.off, 0);
+            if ((uint64_t)S->obase + gL + gM > S->out_cap) return -1;
+            if (gM != 0 && (uint64_t)gD > (uint64_t)S->obase + gL) return -1;
+            qzk_rb_flush(S, lane);
+            qzk_rb_direct(S, blk + span0, gL, lane);
+            qz_wave_sync();
+            qzk_rb_skip(S, gL);
+            if (gM) { qzk_rb_direct_match(S, gD, gM, lane); qz_wave_sync(); qzk_rb_skip(S, gM); }
+            P.qh += 1;
+            continue;
+        }
+        if ((uint32_t)lane >= fit) { s_tot -= r.lit + r.ml; r.lit = 0; r.ml = 0; }
+        const uint32_t Tb = qz_readlane(s_tot, (int)fit - 1), span_len = qz_readlane(s_span, (int)fit - 1);
+        if (qzk_rb_batch(S, blk + span0, span_len, r.lit_off - span0, r.lit, r.ml, r.off, s_tot, Tb, lane)) return -1;
+        P.qh += fit;
+    }
+    return 0;
+}
+
+QZ_KERNEL_OCC(64, 6) qzk_lz4d_kernel(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *segs, qzk_lz4res *res, uint32_t nsegs)
+{
+    QZ_LDS __attribute__((aligned(16))) uint8_t obuf[QZK_RB_OB];
+    QZ_LDS __attribute__((aligned(16))) uint8_t lbuf[QZK_RB_LT];
+    QZ_LDS __attribute__((aligned(16))) uint8_t ring[QZK_L4_RING + 16];
+    QZ_LDS qzk_l4rec queue[QZK_L4_Q];
     const int lane = qz_lane();
-    const uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t s = blockIdx.x;
     if (s >= nsegs) return;
     const qzk_lz4seg sg = segs[s];
     const uint8_t *p = comp + sg.in_off;
     uint8_t *o = out + sg.out_off;
     const uint32_t n = sg.in_len;
-    int status = QZK_LZ4_EDATA; uint32_t pos = 0, op = 0;
+    int status = QZK_LZ4_EDATA; uint32_t pos = 0;
+    qzk_rb S;
+    qzk_rb_init(&S, obuf, lbuf, o, 0, sg.out_cap);
     do {
         if (n < 7) { status = QZK_LZ4_EIN; break; }
         if (qz_ld32(p) != 0x184D2204u) break;
@@ -500,25 +686,25 @@ QZ_KERNEL qzk_lz4d_kernel(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *s
             uint32_t bsz = bh & 0x7fffffffu;
             if (bsz > n - pos) { status = QZK_LZ4_EIN; ok = false; break; }
             if (bh & 0x80000000u) {
-                if (bsz > sg.out_cap - op) { status = QZK_LZ4_EOUT; ok = false; break; }
-                qzk_wave_copy(o + op, p + pos, bsz, lane); op += bsz;
-            } else {
-                uint32_t nop = qzk_lz4_dblock(p + pos, bsz, o, op, sg.out_cap, lane);
-                if (nop == ~0u) { ok = false; break; }
-                op = nop;
-            }
+                if (bsz > sg.out_cap - S.obase) { status = QZK_LZ4_EOUT; ok = false; break; }
+                qzk_rb_flush(&S, lane);
+                qzk_rb_direct(&S, p + pos, bsz, lane);
+                qz_wave_sync();
+                qzk_rb_skip(&S, bsz);
+            } else if (qzk_lz4_dblock(&S, p + pos, bsz, n - pos, ring, queue, lane)) { ok = false; break; }
             pos += bsz + (bcheck ? 4 : 0);
         }
+        qzk_rb_flush(&S, lane);
         if (!ok) break;
         if (ccheck) {
             if (pos + 4 > n) { status = QZK_LZ4_EIN; break; }
             qz_wave_sync();
-            if (qz_ld32(p + pos) != qzk_wave_xxh32(o, op, lane)) break;
+            if (qz_ld32(p + pos) != qzk_wave_xxh32_staged(o, S.obase, obuf, lane)) break;
             pos += 4;
         }
         status = QZK_LZ4_OK;
     } while (0);
-    if (lane == 0) { qzk_lz4res r; r.status = status; r.in_used = pos; r.out_len = op; r.pad = 0; res[s] = r; }
+    if (lane == 0) { qzk_lz4res r; r.status = status; r.in_used = pos; r.out_len = S.obase; r.pad = 0; res[s] = r; }
 }
 
 #endif

@@ -296,7 +296,7 @@ int sim_lz4c_linked(const uint8_t *src, uint32_t n, uint8_t *out, uint32_t *out_
 /* K5: decode nsegs frames */
 int sim_lz4d(const uint8_t *comp, uint8_t *out, const qzk_lz4seg *segs, qzk_lz4res *res, uint32_t nsegs)
 {
-    sim::launch((nsegs + 3) / 4, 256, 0, [&] { qzk_lz4d_kernel(comp, out, segs, res, nsegs); });
+    sim::launch(nsegs, 64, 0, [&] { qzk_lz4d_kernel(comp, out, segs, res, nsegs); });
     return 0;
 }
 

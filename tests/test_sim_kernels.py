@@ -504,3 +504,100 @@ def test_lz4_hardware_path_header(sim):
                 sw = O.sw_compress("LZ4", piece, 65536, 1, cap=len(piece) + len(piece) // 255 + 200)[2]
                 got = bytes(slots[i * stride:i * stride + int(lens[i])])
                 assert got == _lz4_hw_frame(piece, sw), (kind, n, fs, i)
+
+
+LZ4SEG_DT = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4")])
+LZ4RES_DT = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("pad", "<u4")])
+
+
+def _sim_lz4d(sim, frames, caps, lead=0, guard=64):
+    """decode `frames` (one segment each) into one buffer, outputs back to back behind `lead` bytes; returns (bytes per
+    segment, results, the guard bytes around the outputs)"""
+    sim.sim_lz4d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    comp = b"".join(frames)
+    cbuf = np.frombuffer(comp + b"\0" * 64, np.uint8).copy()
+    total = lead + sum(caps)
+    obuf = np.full(total + guard, 0xAA, np.uint8)
+    segs, io, oo = [], 0, lead
+    for f, cap in zip(frames, caps):
+        segs.append((io, oo, len(f), cap)); io += len(f); oo += cap
+    sa = np.array(segs, dtype=LZ4SEG_DT); res = np.zeros(len(segs), LZ4RES_DT)
+    sim.sim_lz4d(cbuf.ctypes.data, obuf.ctypes.data, sa.ctypes.data, res.ctypes.data, len(segs))
+    outs, oo = [], lead
+    for cap in caps:
+        outs.append(bytes(obuf[oo:oo + cap])); oo += cap
+    return outs, res, bytes(obuf[:lead]), bytes(obuf[total:])
+
+
+def test_lz4_frame_decoder_matches_the_software_path(sim):
+    """K5 (round 5: a scalar walk of the token stream dealing sequences to the lanes, resolved by the batch engine of
+    qzk_lz_batch.h): what LZ4F_decompress makes of the software path's frames (src/qatzip_sw.c:486-533) - every kind, the
+    sizes around lz4's limits, calls above 64 KB (ONE frame of linked blocks: matches reach back across block borders),
+    incompressible input (stored blocks), outputs at every 16-byte phase, several frames in one launch"""
+    for kind in datagen.KINDS:
+        frames, srcs = [], []
+        for n in (0, 1, 12, 13, 300, 4097, 65535, 65536, 65537, 150001):
+            if kind == "lzmix" and n > 70000:
+                n = 66000
+            src = datagen.gen_bytes(kind, n, 77)
+            rc, _, fr, _ = O.sw_compress("LZ4", src, 65536, 1, cap=n + n // 255 + 4096)
+            assert rc == 0
+            frames.append(fr); srcs.append(src)
+        for lead in (0, 5):
+            outs, res, head, tail = _sim_lz4d(sim, frames, [len(s) for s in srcs], lead=lead)
+            assert head == b"\xaa" * lead and tail == b"\xaa" * 64, (kind, lead)
+            for i, (o, s, f) in enumerate(zip(outs, srcs, frames)):
+                assert res[i]["status"] == 0 and res[i]["out_len"] == len(s) and res[i]["in_used"] == len(f), (kind, lead, i, res[i])
+                assert o == s, (kind, lead, i, len(s))
+    # liblz4's own frames for calls above 64 KB
+    import json
+    d = os.path.join(HERE, "golden", "lz4_linked")
+    with open(os.path.join(d, "index.json")) as f:
+        idx = json.load(f)
+    frames = [open(os.path.join(d, fr["file"]), "rb").read() for fr in idx["frames"]]
+    srcs = [datagen.gen_bytes(fr["kind"], fr["n"], fr["seed"]) for fr in idx["frames"]]
+    outs, res, _, tail = _sim_lz4d(sim, frames, [len(s) for s in srcs])
+    assert tail == b"\xaa" * 64
+    for i, (o, s) in enumerate(zip(outs, srcs)):
+        assert res[i]["status"] == 0 and o == s, (i, res[i])
+    # shapes the batch engine has special paths for: a run (one sequence longer than a batch), short periods, long literal
+    # runs between matches, matches reaching to the frame's first byte
+    rng = np.random.default_rng(5)
+    shapes = [b"\0" * 65536, b"ab" * 30000, b"abc" * 21000, bytes(rng.integers(0, 256, 5000, dtype=np.uint8)) * 9,
+              bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) + b"x" * 5000 + bytes(rng.integers(0, 256, 3000, dtype=np.uint8)),
+              b"".join(bytes([65 + (i % 7)]) * (i % 40 + 1) for i in range(3000))]
+    frames = [O.sw_compress("LZ4", s, 65536, 1, cap=len(s) + 4096)[2] for s in shapes]
+    outs, res, _, tail = _sim_lz4d(sim, frames, [len(s) for s in shapes])
+    assert tail == b"\xaa" * 64
+    for i, (o, s) in enumerate(zip(outs, shapes)):
+        assert res[i]["status"] == 0 and o == s, (i, res[i])
+
+
+def test_lz4_decoder_on_damaged_frames(sim):
+    """flipped bits, truncation, a destination one byte short: an error (the content checksum catches what the token walk
+    does not), never a byte outside the segment's output (src/qatzip_sw.c:498-500,524-532: LZ4F errors end in QZ_FAIL)"""
+    import random
+    errors = same = 0
+    for seed in range(1, 161):
+        rng = random.Random(seed)
+        kind = rng.choice(datagen.KINDS)
+        n = rng.choice([rng.randrange(1, 300), rng.randrange(300, 20000), rng.randrange(60000, 70000)])
+        src = datagen.gen_bytes(kind, n, 1200 + seed)
+        fr = bytearray(O.sw_compress("LZ4", src, 65536, 1, cap=n + n // 255 + 4096)[2])
+        cap = n
+        mode = rng.random()
+        if mode < 0.15:
+            fr = fr[:rng.randrange(1, len(fr))]
+        elif mode < 0.25:
+            cap = max(0, n - rng.randrange(1, 20))
+        else:
+            for _ in range(rng.choice([1, 1, 2, 5])):
+                fr[rng.randrange(0, len(fr))] ^= 1 << rng.randrange(8)
+        outs, res, head, tail = _sim_lz4d(sim, [bytes(fr)], [cap], lead=rng.choice([0, 3, 16]))
+        assert tail == b"\xaa" * 64 and set(head) <= {0xAA}, seed
+        if res[0]["status"] == 0:
+            assert outs[0] == src[:cap] and cap == n, seed
+            same += 1
+        else:
+            errors += 1
+    assert errors > 120, (errors, same)
