@@ -99,109 +99,219 @@ def allreduce(pg, v, op):
 
 # ------------------------------------------------------------------ CPU baseline (reported, not the target)
 def host_cpu():
-    """(physical cores this process may use, model name)"""
-    model, cores = "unknown", set()
+    """(one logical CPU per physical core this process may use, model name)"""
+    model, cores = "unknown", {}
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
     try:
-        phys = core = None
-        for line in open("/proc/cpuinfo"):
+        proc = phys = core = None
+        for line in list(open("/proc/cpuinfo")) + [""]:
             k, _, v = line.partition(":")
             k = k.strip(); v = v.strip()
             if k == "model name":
                 model = v
+            elif k == "processor":
+                proc = int(v)
             elif k == "physical id":
                 phys = v
             elif k == "core id":
                 core = v
-            elif k == "" and phys is not None and core is not None:
-                cores.add((phys, core)); phys = core = None
-    except OSError:
+            elif k == "" and proc is not None:
+                if proc in allowed:
+                    key = (phys, core) if phys is not None and core is not None else ("p", proc)
+                    cores[key] = min(cores.get(key, proc), proc)
+                proc = phys = core = None
+    except (OSError, ValueError):
         pass
-    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n = min(len(cores), allowed) if cores else allowed
-    return max(1, n), model
+    cpus = sorted(cores.values()) or sorted(allowed)
+    return cpus, model
 
 
-def cpu_worker(idx: int, shard_mb: int, base_mb: int):
-    """one worker process of the CPU baseline: its own contiguous shard of the bench data (regenerated from the same
-    seed), the software path's port, then this host's libz; prints one JSON line"""
-    import zlib
-    import datagen
+class _ZStream(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("next_in", _C.c_void_p), ("avail_in", _C.c_uint), ("total_in", _C.c_ulong), ("next_out", _C.c_void_p),
+                ("avail_out", _C.c_uint), ("total_out", _C.c_ulong), ("msg", _C.c_char_p), ("state", _C.c_void_p),
+                ("zalloc", _C.c_void_p), ("zfree", _C.c_void_p), ("opaque", _C.c_void_p), ("data_type", _C.c_int),
+                ("adler", _C.c_ulong), ("reserved", _C.c_ulong)]
+
+
+def _libz():
+    """this host's libz through its C API (no CPython buffer in between), or None"""
+    import ctypes as C
+    try:
+        lib = C.CDLL("libz.so.1")
+    except OSError:
+        return None
+    lib.zlibVersion.restype = C.c_char_p
+    lib.deflateInit2_.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    lib.inflateInit2_.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    for f in (lib.deflate, lib.inflate):
+        f.argtypes = [C.c_void_p, C.c_int]
+    for f in (lib.deflateEnd, lib.inflateEnd):
+        f.argtypes = [C.c_void_p]
+    return lib
+
+
+def _libz_pass(lib, src_buf, n, dst_buf, dst_cap, back_buf):
+    """the software path's loop (src/qatzip_sw.c:178-231, :323-351) on libz itself: deflateInit2(1, 8, -15, 9, 0), one
+    deflate(Z_FULL_FLUSH) per 64 KB with the whole destination behind it, Z_FINISH on the last; then one inflate stream.
+    Returns (compress s, decompress s, compressed bytes)."""
+    import ctypes as C
+    ver = lib.zlibVersion()
+    st = _ZStream()
+    t0 = time.perf_counter()
+    assert lib.deflateInit2_(C.byref(st), 1, 8, -15, 9, 0, ver, C.sizeof(_ZStream)) == 0
+    base_in, base_out = C.addressof(src_buf), C.addressof(dst_buf)
+    pos = 0
+    while True:
+        send = min(CHUNK, n - pos)
+        st.next_in = base_in + pos; st.avail_in = send
+        st.next_out = base_out + st.total_out; st.avail_out = dst_cap - st.total_out
+        pos += send
+        fin = pos >= n
+        rc = lib.deflate(C.byref(st), 4 if fin else 3)
+        assert rc == (1 if fin else 0) and st.avail_in == 0, rc
+        if fin:
+            break
+    clen = st.total_out
+    lib.deflateEnd(C.byref(st))
+    t1 = time.perf_counter()
+    zi = _ZStream()
+    assert lib.inflateInit2_(C.byref(zi), -15, ver, C.sizeof(_ZStream)) == 0
+    zi.next_in = base_out; zi.avail_in = clen
+    zi.next_out = C.addressof(back_buf); zi.avail_out = n
+    rc = lib.inflate(C.byref(zi), 2)                                 # Z_SYNC_FLUSH, as the reference calls it
+    assert rc == 1 and zi.total_out == n, (rc, zi.total_out)
+    lib.inflateEnd(C.byref(zi))
+    t2 = time.perf_counter()
+    return t1 - t0, t2 - t1, clen
+
+
+def cpu_worker(idx: int, shard_mb: int, data_path: str, cpu: int):
+    """one worker process of the CPU baseline, pinned to one physical core the way the reference's script pins its
+    processes with taskset (test/performance_tests/run_perf_test.sh:104-110): its own contiguous shard of the bench data
+    (a file in shared memory the parent wrote), three passes of this host's libz through its C API and three of the
+    software path's port (oracle/), all workers starting together; prints one JSON line"""
+    import ctypes as C
+    import numpy as np
     import oracle_lib as O
-    base = datagen.gen("silesia", base_mb << 20, 20250523)
+    if cpu >= 0 and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, {cpu})
+        except OSError:
+            pass
+    base = np.memmap(data_path, dtype=np.uint8, mode="r")
     S = min(shard_mb << 20, len(base)) & ~(CHUNK - 1)
     span = max(1, len(base) - S)
-    src = base[(idx * 7919 * CHUNK) % span:][:S].tobytes()
+    off = (idx * 7919 * CHUNK) % span
+    src = bytes(base[off:off + S])
     del base
+    lib = _libz()
+    src_buf = C.create_string_buffer(src, S); cap = S * 9 // 8 + 65536
+    dst_buf = C.create_string_buffer(cap); back_buf = C.create_string_buffer(S)
     O.sw_compress("GZIP_EXT", src[:CHUNK], CHUNK, 1)                 # tables built, pages touched
-    t0 = time.perf_counter()
-    rc, used, out, _ = O.sw_compress("GZIP_EXT", src, CHUNK, 1, cap=len(src) * 9 // 8 + 65536)
-    t1 = time.perf_counter()
-    rc2, _, back = O.sw_decompress("GZIP_EXT", out, len(src) + 64)
-    t2 = time.perf_counter()
-    assert rc == 0 and used == len(src) and rc2 == 0 and back == src
-    res = {"n": S, "tc": t1 - t0, "td": t2 - t1, "clen": len(out)}
-    try:
+    if lib:
+        _libz_pass(lib, src_buf, min(S, 4 * CHUNK), dst_buf, cap, back_buf)
+    print("READY", flush=True)
+    sys.stdin.readline()                                             # the parent lets every worker go at once
+    res = {"n": S, "cpu": cpu, "port": [], "libz": []}
+    for _ in range(3):
+        if lib:
+            tc, td, clen = _libz_pass(lib, src_buf, S, dst_buf, cap, back_buf)
+            res["libz"].append([tc, td]); res["zclen"] = clen
+    if lib:
+        assert back_buf.raw == src
+        res["zver"] = lib.zlibVersion().decode()
+    for _ in range(3):
         t0 = time.perf_counter()
-        co = zlib.compressobj(1, zlib.DEFLATED, -15, 9, 0)
-        parts = []
-        for off in range(0, len(src), CHUNK):
-            last = off + CHUNK >= len(src)
-            parts.append(co.compress(src[off:off + CHUNK]) + co.flush(zlib.Z_FINISH if last else zlib.Z_FULL_FLUSH))
-        comp = b"".join(parts)
+        rc, used, out, _ = O.sw_compress("GZIP_EXT", src, CHUNK, 1, cap=cap)
         t1 = time.perf_counter()
-        back = zlib.decompress(comp, -15)
+        rc2, _, back = O.sw_decompress("GZIP_EXT", out, S + 64)
         t2 = time.perf_counter()
-        assert back == src
-        res.update({"ztc": t1 - t0, "ztd": t2 - t1, "zver": zlib.ZLIB_RUNTIME_VERSION})
-    except Exception as e:   # noqa: BLE001
-        res["zerr"] = str(e)[:100]
-    print(json.dumps(res))
+        assert rc == 0 and used == S and rc2 == 0 and back == src
+        res["port"].append([t1 - t0, t2 - t1]); res["clen"] = len(out)
+    print(json.dumps(res), flush=True)
 
 
 def cpu_baseline(shard_mb: int, base_mb: int, max_workers: int):
-    """The oracle (a port of the reference's software path, src/qatzip_sw.c:77-441) on this box's host cores, the way
-    the reference measures itself (test/performance_tests/run_perf_test.sh:100-123): N independent worker PROCESSES, one
-    per physical core, each on its own contiguous shard of the bench buffer, rates summed; one worker alone beside it.
-    Each worker then runs the same loop over this host's own libz (deflateInit2(1, 8, -15, 9, 0) + Z_FULL_FLUSH per
-    64 KB through Python's zlib)."""
+    """The reference's arithmetic on this box's host cores, the way the reference measures itself
+    (test/performance_tests/run_perf_test.sh:100-123): N independent worker PROCESSES, one per physical core and pinned to
+    it, each on its own contiguous shard (>= 64 MiB) of the bench buffer, all released together, three passes each; the
+    per-worker rates of a pass summed, the MEDIAN pass reported with the spread of the three.  `value` is this host's own
+    libz driven like src/qatzip_sw.c:178-231 / :323-351 when it is the pinned 1.2.11 (its bytes are the reference's:
+    tests/test_oracle.py) - kind "libz"; the port of oracle/ (the checker, a slower restatement) stands beside it."""
     import subprocess
-    ncores, model = host_cpu()
-    nw = max(1, min(ncores, max_workers))
+    import tempfile
+    import datagen
+    cpus, model = host_cpu()
+    nw = max(1, min(len(cpus), max_workers))
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(shm, "qatzip_amd_bench_%d.bin" % os.getpid())
+    datagen.gen("silesia", max(base_mb, shard_mb + 16) << 20, 20250523).tofile(path)
 
     def run(count):
         ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--cpu-mb", str(shard_mb),
-                                "--base-mb", str(base_mb)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-              for i in range(count)]
+                                "--cpu-data", path, "--cpu-pin", str(cpus[i % len(cpus)])],
+                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(count)]
+        ready = [p for p in ps if (p.stdout.readline() or "").startswith("READY")]
+        for p in ready:
+            try:
+                p.stdin.write("GO\n"); p.stdin.flush()
+            except OSError:
+                pass
         out = []
         for p in ps:
-            o, _ = p.communicate(timeout=600)
+            try:
+                o, _ = p.communicate(timeout=900)
+            except subprocess.TimeoutExpired:
+                p.kill(); continue
             line = [x for x in o.splitlines() if x.startswith("{")]
             if p.returncode == 0 and line:
                 out.append(json.loads(line[-1]))
         return out
-    one = run(1)
-    many = run(nw)
+    try:
+        one = run(1)
+        many = run(nw)
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
     if not one or not many:
         return {"error": "CPU baseline workers failed"}
 
-    def rates(rs, kc, kd):
-        c = sum(r["n"] / r[kc] for r in rs) / 1e9; d = sum(r["n"] / r[kd] for r in rs) / 1e9
-        both = sum(2 * r["n"] / (r[kc] + r[kd]) for r in rs) / 1e9
-        return round(both, 4), round(c, 4), round(d, 4)
-    v, c, d = rates(many, "tc", "td"); v1, c1, d1 = rates(one, "tc", "td")
-    libz = None
-    zs = [r for r in many if "ztc" in r]
-    if zs:
-        zv, zc, zd = rates(zs, "ztc", "ztd"); z1 = rates([r for r in one if "ztc" in r] or zs[:1], "ztc", "ztd")
-        libz = {"zlibVersion": zs[0]["zver"], "value": zv, "compress": zc, "decompress": zd, "one_worker": z1[0], "workers": len(zs),
-                "note": "raw deflate level 1, memLevel 9, Z_FULL_FLUSH per 64 KB (the loop of src/qatzip_sw.c:178-231) through Python's zlib"}
-    return {"value": v, "unit": "GB/s", "cores": len(many), "kind": "port", "compress": c, "decompress": d,
-            "one_worker": {"value": v1, "compress": c1, "decompress": d1},
-            "cpu_model": model, "physical_cores": ncores,
-            "sample": "%d worker process(es) x %d MiB contiguous shards of the same buffer, GZIP_EXT L1 64 KB chunks, compress + "
-                      "decompress, oracle/libqzoracle.so, per-worker rates summed (%.1f s of CPU work)"
-                      % (len(many), many[0]["n"] >> 20, sum(r["tc"] + r["td"] for r in many)),
-            "ratio": round(sum(r["clen"] for r in many) / sum(r["n"] for r in many), 4), "host_libz": libz}
+    def rates(rs, key):
+        """per pass: (both directions, compress, decompress) GB/s summed over the workers; then the median pass and the spread"""
+        rs = [r for r in rs if len(r.get(key, [])) == 3]
+        if not rs:
+            return None
+        passes = []
+        for k in range(3):
+            passes.append((sum(2 * r["n"] / (r[key][k][0] + r[key][k][1]) for r in rs) / 1e9,
+                           sum(r["n"] / r[key][k][0] for r in rs) / 1e9, sum(r["n"] / r[key][k][1] for r in rs) / 1e9))
+        order = sorted(passes)
+        med = order[1]
+        return {"value": round(med[0], 4), "compress": round(med[1], 4), "decompress": round(med[2], 4),
+                "spread": round((order[2][0] - order[0][0]) / med[0], 4), "passes": [round(p[0], 4) for p in passes], "workers": len(rs)}
+    port, port1 = rates(many, "port"), rates(one, "port")
+    libz, libz1 = rates(many, "libz"), rates(one, "libz")
+    zver = next((r["zver"] for r in many if "zver" in r), None)
+    pinned = libz is not None and zver == "1.2.11"
+    head = libz if pinned else port
+    cpu_s = sum(sum(a + b for a, b in r.get("port", [])) + sum(a + b for a, b in r.get("libz", [])) for r in many)
+    res = {"value": head["value"], "unit": "GB/s", "cores": head["workers"], "kind": "libz" if pinned else "port",
+           "compress": head["compress"], "decompress": head["decompress"], "spread": head["spread"], "passes": head["passes"],
+           "one_worker": (libz1 if pinned else port1), "cpu_model": model, "physical_cores": len(cpus),
+           "sample": "%d worker process(es), each pinned to one physical core, x %d MiB contiguous shards of the same buffer, "
+                     "GZIP_EXT L1 64 KB chunks, compress + decompress, three passes started together, median pass of the "
+                     "summed per-worker rates (%.0f s of CPU work in all)" % (len(many), many[0]["n"] >> 20, cpu_s),
+           "ratio": round(sum(r.get("clen", 0) for r in many) / max(1, sum(r["n"] for r in many if "clen" in r)), 4),
+           "port": dict(port or {}, one_worker=port1, note="oracle/libqzoracle.so: the CPU restatement the parity tests check against"),
+           }
+    if libz is not None:
+        res["host_libz"] = dict(libz, zlibVersion=zver, one_worker=libz1,
+                                note="deflateInit2(1, 8, -15, 9, 0) + deflate(Z_FULL_FLUSH) per 64 KB, inflate(Z_SYNC_FLUSH): the loops of "
+                                     "src/qatzip_sw.c:178-231 and :323-351 through libz's C API (ctypes)")
+    return res
 
 
 # ------------------------------------------------------------------ extra legs (outside the timed region)
@@ -413,7 +523,7 @@ def view(qz, buf, off, n):
     return v
 
 
-def one_stream_leg(ctx, qz, pg, rank, world, d_src, slice_mb, members, steps):
+def one_stream_leg(ctx, qz, pg, rank, world, d_src, slice_mb, members, steps, ndev=None, progress=None):
     """BASELINE config 5 as written, timed: a logical buffer of `members` x (world x slice_mb MiB) - 16 members of 8 x 511 MiB
     = 64 GB on an 8-GPU node; a gzip-ext header describes less than 4 GiB, so the buffer is a SEQUENCE of members - dealt to
     the ranks like a striped volume (shard.member_plan).  Every member is built by all ranks: each deflates its shard on its
@@ -426,6 +536,7 @@ def one_stream_leg(ctx, qz, pg, rank, world, d_src, slice_mb, members, steps):
     ranks' own CPU CRC-32s of member 0, and a prefix of member 0's payload against the oracle."""
     import zlib
     from qatzip_amd import shard
+    note = progress or (lambda what: None)                           # where the leg stands, for the line of a run that timed out
     # the ranks of this leg share one node by contract: RCCL's bootstrap sockets may use the loopback interface (the
     # container's hostname need not resolve); a launcher that knows better sets the variable itself
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
@@ -452,11 +563,19 @@ def one_stream_leg(ctx, qz, pg, rank, world, d_src, slice_mb, members, steps):
     d_out = ctx.alloc(total // 2 + (1 << 26)) if rank == 0 else None      # the bench data compresses to < 0.4: half is room enough
     best = None
     for transport in ("ipc", "rccl"):
+        if transport == "rccl" and ndev is not None and ndev < world:
+            # a rehearsal of N ranks on fewer devices (a one-GPU box): RCCL admits ONE rank per device (ncclCommInitRank:
+            # "invalid usage" otherwise) - its transport is not started, and the line says so instead of printing RCCL's error
+            out["rccl"] = {"skipped": "%d ranks on %d device(s): RCCL takes one rank per GPU; the IPC window carries this run, the RCCL "
+                                      "transport (ncclAllGather + ncclSend/ncclRecv group, qzd_rccl_*) needs one GPU per rank" % (world, ndev)}
+            continue
         try:
+            note("%s: setting the transport up" % transport)
             one = shard.OneStream(ctx, pg, rank, world, sl, CHUNK, 1, transport)
             if one.error:
                 out[transport] = {"error": one.error[:200]}
                 continue
+            note("%s: first pass over %d members (warm-up, checked)" % (transport, len(plan)))
             r = one.run_members(src, plan, d_out)                    # warm-up + the pass that is checked
             if "error" in r:
                 out[transport] = {"error": r["error"][:200]}
@@ -483,6 +602,7 @@ def one_stream_leg(ctx, qz, pg, rank, world, d_src, slice_mb, members, steps):
                         exp = O.sw_compress("RAW", host[:k].tobytes(), CHUNK, 1, last=0 if (world > 1 or k < n0) else 1, cap=k * 9 // 8 + 65536)[2]
                         verified = verified and d_out.download(len(exp), 24).tobytes() == exp
                     pos += mb_len
+            note("%s: checked, timed passes" % transport)
             barrier(pg)
             t0 = time.perf_counter()
             tg = td = tov = 0.0
@@ -538,7 +658,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mb", type=int, default=4096, help="buffer size per GPU in MiB (default: the 4 GB config)")
     ap.add_argument("--base-mb", type=int, default=128, help="distinct synthetic data generated per GPU (tiled)")
-    ap.add_argument("--cpu-mb", type=int, default=16, help="CPU baseline: shard size per thread, MiB")
+    ap.add_argument("--cpu-mb", type=int, default=64, help="CPU baseline: shard size per worker, MiB")
+    ap.add_argument("--cpu-data", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-pin", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=256, help="CPU baseline: at most this many worker processes")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true")
@@ -551,7 +673,7 @@ def main():
                     "(the rocprofv3 --pmc passes: every K1 launch of the run is then a whole 2 GiB call)")
     args = ap.parse_args()
     if args.cpu_worker is not None:
-        cpu_worker(args.cpu_worker, args.cpu_mb, args.base_mb)
+        cpu_worker(args.cpu_worker, args.cpu_mb, args.cpu_data, args.cpu_pin)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                      # does not return
@@ -644,14 +766,16 @@ def main():
                         d.free()
                     d_back.free()
                     members = args.members or (16 if world >= 8 else 4)
-                    box["one"] = one_stream_leg(ctx, qatzip_amd, pg, rank, world, d_src, min(511, 4095 // world, args.mb), members, max(1, args.steps))
+                    box["one"] = one_stream_leg(ctx, qatzip_amd, pg, rank, world, d_src, min(511, 4095 // world, args.mb), members, max(1, args.steps), ndev,
+                                                lambda what: box.__setitem__("at", what))
                 except Exception as e:   # noqa: BLE001 - the headline must survive a box without peer access
                     box["one"] = {"error": str(e)[:200]}
             th = threading.Thread(target=leg, daemon=True)
             th.start()
             th.join(float(os.environ.get("QATZIP_AMD_BENCH_LEG_TIMEOUT", "240")))
             if th.is_alive():
-                one = {"error": "the one-member leg did not finish in time on rank %d (a transport is waiting for a rank that is not coming)" % rank}
+                one = {"error": "the one-stream leg did not finish in %s s on rank %d; it was at: %s" %
+                                (os.environ.get("QATZIP_AMD_BENCH_LEG_TIMEOUT", "240"), rank, box.get("at", "its preparation (buffers, member 0's CRC)"))}
                 hard_exit = True
             else:
                 one = box.get("one")

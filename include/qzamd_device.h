@@ -28,6 +28,7 @@ extern "C" {
 #define QZD_ERR_DSTCAP (-3)      /* destination too small (maps to QZ_BUF_ERROR / QZ_FAIL) */
 #define QZD_ERR_DATA (-4)        /* corrupt compressed input (maps to QZ_DATA_ERROR) */
 #define QZD_ERR_UNSUPPORTED (-5)
+#define QZD_ERR_NOMEM (-6)       /* device memory for a call's scratch could not be had (maps to QZ_NOSW_LOW_MEM) */
 
 typedef struct qzd_ctx qzd_ctx;
 

@@ -887,6 +887,10 @@ static int decompress_deflate(QzSession_T *sess, Sess *s, const unsigned char *s
             }
         }
         if (r == QZD_ERR_DSTCAP) { ret = QZ_BUF_ERROR; break; }
+        /* only what the DATA is to blame for is a data error: a failed device call is QZ_FAIL, scratch that could not be
+         * had QZ_NOSW_LOW_MEM (there is no software path behind this library to go to) */
+        if (r == QZD_ERR_NOMEM) { ret = QZ_NOSW_LOW_MEM; break; }
+        if (r == QZD_ERR_HIP || r == QZD_ERR_PARAM) { ret = QZ_FAIL; break; }
         if (r != QZD_OK) { ret = QZ_DATA_ERROR; break; }
         uint32_t pos = ti + (uint32_t)hl + (uint32_t)iu;
         if (fmt == F_GZIP || fmt == F_GZIP_EXT) {

@@ -1091,12 +1091,19 @@ static int lz4_compress_frames_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n
                 hipDeviceSynchronize();
                 if (c->d_lz4tab) hipFree(c->d_lz4tab);
                 c->d_lz4tab = NULL; c->lz4tab_waves = 0;
-                HIPCHK(c, hipMalloc(&c->d_lz4tab, 256 + (size_t)waves * QZK_LZ4_HASHSZ * 2));
+                /* frame counter (256 B), the waves' epochs, their tables (8192 entries of 8 bytes each: 64 KiB a wave, 512 MiB for
+                 * a full device) - cleared ONCE here: the epochs take the place of a clearing per frame */
+                const size_t epb = ((size_t)waves * 4 + 255) & ~(size_t)255, tb = (size_t)waves * QZK_L4C_TABW * 8;
+                HIPCHK(c, hipMalloc(&c->d_lz4tab, 256 + epb + tb));
+                HIPCHK(c, hipMemsetAsync(c->d_lz4tab, 0, 256 + epb + tb, st));
                 c->lz4tab_waves = waves;
             }
             HIPCHK(c, hipMemsetAsync(c->d_lz4tab, 0, 4, st));
-            hipLaunchKernelGGL(qzk_lz4c_pull_kernel, dim3(waves), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, bn, c->slots[0], stride,
-                               c->d_len + b, hw_hdr, (uint16_t *)(c->d_lz4tab + 256), (uint32_t *)c->d_lz4tab);
+            {
+                const size_t epb = ((size_t)c->lz4tab_waves * 4 + 255) & ~(size_t)255;
+                hipLaunchKernelGGL(qzk_lz4c_pull_kernel, dim3(waves), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, bn, c->slots[0], stride,
+                                   c->d_len + b, hw_hdr, (uint64_t *)(c->d_lz4tab + 256 + epb), (uint32_t *)(c->d_lz4tab + 256), (uint32_t *)c->d_lz4tab);
+            }
         } else
             hipLaunchKernelGGL(qzk_lz4c_kernel, dim3(bn), dim3(64), 0, st, d_src + boff, n - boff, frame_sz, bn, c->slots[0], stride, c->d_len + b, hw_hdr);
         hipLaunchKernelGGL(qzk_scan_kernel, dim3(1), dim3(1024), 0, st, c->d_len + b, bn, c->d_offs + b, c->d_running);

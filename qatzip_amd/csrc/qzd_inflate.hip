@@ -175,11 +175,24 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     const bool stream_out = run_b && c->so_host && c->so_nat && nsegs >= QZD_LANE_MIN_SEGS;
     const size_t ordb = ((size_t)nsegs * 4 + 255) & ~(size_t)255;
     const size_t need = tabb + tsb + chb + rcb + litb + seqb + ordb + 256;
-    if (need > c->big_cap) {
+    /* the scratch grows with the largest call and shrinks again when a call needs less than a quarter of it (a 4 GiB decode
+     * leaves 44 GB behind; the next 64 KB call gives them back) */
+    if (need > c->big_cap || (c->big_cap > ((size_t)1 << 30) && need * 4 < c->big_cap)) {
         hipDeviceSynchronize();
         if (c->d_big) hipFree(c->d_big);
         c->d_big = NULL; c->big_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_big, need));
+        /* QATZIP_AMD_SCRATCH_MAX=<bytes>: a ceiling for this scratch (tests: the paths a failed allocation takes) */
+        const char *cap_e = getenv("QATZIP_AMD_SCRATCH_MAX");
+        const bool refused = cap_e && need > (size_t)strtoull(cap_e, NULL, 10);
+        if (refused || hipMalloc(&c->d_big, need) != hipSuccess) {
+            (void)hipGetLastError();
+            c->d_big = NULL;
+            /* not enough device memory for K sub-streams per segment: one per segment needs a third of it; after that the
+             * callers take the wave-per-segment kernel, which needs none */
+            if (K > 1) return two_phase(c, d_comp, d_out, hs, nsegs, h_res, 1, st, run_b);
+            snprintf(c->err, sizeof(c->err), "inflate: %zu bytes of decode scratch are not available", need);
+            return QZD_ERR_NOMEM;
+        }
         c->big_cap = need;
     }
     uint8_t *pb = c->d_big;
@@ -262,7 +275,10 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         if (hipEventElapsedTime(&ta, c->ev[1][1], c->ev[1][0]) == hipSuccess) c->inf_ms[3] += ta;   /* phase A's kernel(s) */
         return QZD_OK;
     }
-    if (stream_out) { memcpy(st_ord, c->so_nat, (size_t)nsegs * 4); HIPCHK(c, ctl_copy(ord_d, st_ord, (size_t)nsegs * 4, st)); }
+    if (stream_out) {
+        HIPCHK(c, hipStreamSynchronize(st));                        /* the redo list in st_ord may still be on its way to the device */
+        memcpy(st_ord, c->so_nat, (size_t)nsegs * 4); HIPCHK(c, ctl_copy(ord_d, st_ord, (size_t)nsegs * 4, st));
+    }
     if (!stream_out) {
         hipLaunchKernelGGL(qzk_lz_resolve_kernel, dim3((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES), dim3(64 * QZK_RES_WAVES), 0, st,
                            d_comp, d_out, d_segs, d_res, nsegs, ts_d, K, lit_d, seq_d, ch_d, (const uint32_t *)NULL, 0u);
@@ -367,10 +383,13 @@ extern "C" int qzd_inflate_segments(qzd_ctx *c, const uint8_t *d_comp, uint8_t *
     const uint32_t K = spec_lanes(hs, nsegs);
     const bool lanes = use_lanes(K, nsegs, hs[0].out_cap);
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
+    bool waves = !lanes;
     if (lanes) {
         int rc = two_phase(c, d_comp, d_out, hs, nsegs, (qzk_infres *)h_res, K, st);
-        if (rc) return rc;
-    } else {
+        if (rc == QZD_ERR_NOMEM) waves = true;                      /* no room for the token streams: a wave per segment needs none */
+        else if (rc) return rc;
+    }
+    if (waves) {
         const size_t sb = (size_t)nsegs * sizeof(qzk_infseg), rb = (size_t)nsegs * sizeof(qzk_infres);
         int rc = qzd_aux_reserve(c, sb + rb + 64);
         if (rc) return rc;
@@ -594,6 +613,7 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
      * output offset, and phase B writes only those.  One pass whatever the candidates look like. --- */
     const char *force_path = getenv("QATZIP_AMD_INFLATE");
     const bool lanes = force_path ? force_path[0] == 'l' : true;   /* every candidate carries a length hint: K lanes per segment at any count */
+    bool lanes_nomem = false;                                       /* the token scratch could not be had: the wave-per-segment passes below */
     {
         if (scan_ok && seg_hint && ns > 1 && lanes) {
             auto clen = [&](uint32_t k) { return (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k]; };
@@ -618,6 +638,7 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
             lap("segment records");
             HIPCHK(c, hipEventRecord(c->ev[0][0], c->st[0]));
             rc = two_phase(c, d_src, d_dst, ps.data(), ns, pr.data(), spec_lanes(ps.data(), ns), c->st[0], false);
+            if (rc == QZD_ERR_NOMEM) { lanes_nomem = true; goto after_lanes; }        /* the passes below need no token scratch */
             if (rc) return rc;
             lap("phase A");
             std::vector<uint32_t> chain;                        /* launch indices of the real segments, in output order */
@@ -655,8 +676,9 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
         }
     }
 
+after_lanes:
     /* --- 2b. optimistic single pass (fewer candidates: one wave per segment) --- */
-    if (!done && scan_ok && seg_hint && ns > 1 && !lanes) {
+    if (!done && scan_ok && seg_hint && ns > 1 && (!lanes || lanes_nomem)) {
         for (uint32_t k = 0; k < ns; k++) {
             uint64_t oo = (uint64_t)k * seg_hint;
             segs[k].in_off = start[k]; segs[k].in_len = (uint32_t)(n - start[k]);
@@ -771,8 +793,18 @@ static void pipe_fail(qzd_pipe *S, uint32_t p)
     S->cv.notify_all();
 }
 
+static void pipe_piece_body(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                            uint32_t seg_hint, const uint64_t *cut, uint8_t *h_dst);
+/* a helper thread's entry: nothing may leave it as an exception (std::terminate inside a C API) - a piece that runs out of
+ * host memory counts as failed and the member goes through as a whole */
 static void pipe_piece(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
                        uint32_t seg_hint, const uint64_t *cut, uint8_t *h_dst)
+{
+    try { pipe_piece_body(H, c, S, p, d_src, n, d_dst, dst_cap, seg_hint, cut, h_dst); }
+    catch (...) { pipe_fail(S, p); }
+}
+static void pipe_piece_body(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, const uint8_t *d_src, uint64_t n, uint8_t *d_dst, uint64_t dst_cap,
+                            uint32_t seg_hint, const uint64_t *cut, uint8_t *h_dst)
 {
     hipSetDevice(H->device);
     static const bool trace = getenv("QATZIP_AMD_TRACE") != NULL;   /* developer aid: when each step of each piece was over */
@@ -870,10 +902,17 @@ static void pipe_piece(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, const ui
     lap("chain");
     if (chain.empty()) return;
     H->inf_ms[2] = 0;
+    {   /* what phase A of this piece took, for qzd_last_inflate_timing() of the call (the pieces' kernels overlap: a sum of
+         * kernel times, not a span) */
+        std::lock_guard<std::mutex> g(S->m);
+        c->inf_ms[3] += H->inf_ms[3]; c->inf_ms[0] += H->inf_ms[3];
+        H->inf_ms[3] = 0;
+    }
     for (uint32_t i = 0; i < ns; i++) ps[i].flags = ps[i].flags == 0x80000000u ? 0 : QZK_INF_COUNT_ONLY;
     if (two_phase_resolve(H, d_src, d_dst, ps.data(), ns, chain.data(), (uint32_t)chain.size(), pr.data(), h_dst, st, c->st[1]) != QZD_OK) { pipe_fail(S, p); return; }
     for (uint32_t i : chain) if (pr[i].status < 0) { pipe_fail(S, p); return; }
     if (trace) fprintf(stderr, "[pipe] piece %u phase B kernels %.3f ms, %u segments\n", p, H->inf_ms[2], (uint32_t)chain.size());
+    { std::lock_guard<std::mutex> g(S->m); c->inf_ms[2] += H->inf_ms[2]; c->inf_ms[0] += H->inf_ms[2]; }
     lap("phase B, sent");
 }
 
@@ -899,6 +938,7 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
         HIPCHK(c, hipMemcpy(d_src, h_src, n, hipMemcpyHostToDevice));
         return inflate_stream(c, d_src, n, d_dst, dst_cap, seg_hint, h_in_used, h_out_len, h_crc, h_dst, h_sent);
     }
+    c->inf_ms[0] = c->inf_ms[1] = c->inf_ms[2] = c->inf_ms[3] = 0;
     qzd_pipe S;
     S.t0 = std::chrono::steady_clock::now();
     S.P = P; S.final_seen = false; S.failed = false; S.total_in = S.total_out = 0;
@@ -911,8 +951,9 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
         cut[p] = p == P ? n : p == 0 ? 0 : P == 2 ? (n / 3) & ~(uint64_t)4095 : (n * (2 * p - (p >= 2 ? 2 : 1)) / (2 * P - 2)) & ~(uint64_t)4095;
     if (const char *ce = getenv("QATZIP_AMD_PIPE_CUTS")) {          /* developer aid: the pieces' boundaries in percent, "10,40" */
         uint32_t k = 1;
-        for (const char *q = ce; *q && k < P; k++) { cut[k] = (n * (uint64_t)atoi(q) / 100) & ~(uint64_t)4095; while (*q && *q != ',') q++; if (*q) q++; }
+        for (const char *q = ce; *q && k < P; k++) { cut[k] = (n * (uint64_t)std::min(100, std::max(0, atoi(q))) / 100) & ~(uint64_t)4095; while (*q && *q != ',') q++; if (*q) q++; }
     }
+    for (uint32_t p = 1; p <= P; p++) if (cut[p] < cut[p - 1]) cut[p] = cut[p - 1];      /* boundaries only ever go up */
     std::vector<std::thread> th;
     th.reserve(P);
     for (uint32_t p = 0; p < P; p++) {

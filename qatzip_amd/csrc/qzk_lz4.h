@@ -348,6 +348,316 @@ template <bool GTAB>
 QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap, uint16_t *table, uint32_t *slot, int lane)
 { return qzk_lz4_block_t<false, uint16_t, GTAB>(in, 0, n, out, cap, table, slot, lane); }
 
+/* ------------------------------------------------------------------ K4, round 5: the block compressor of the pull kernel
+ * The same parse (lz4 1.9.3 LZ4_compress_fast, 16-bit positions, 13-bit hash), rebuilt around the number of dependent
+ * memory round trips per sequence - ten in the form above (profiles/r4_lz4_counters.txt: 49.8 ms per GiB, the waves waiting
+ * 80 % of their cycles at 32 waves per CU: nothing but fewer round trips makes a wave faster), three here:
+ *   - a table entry carries what the compare needs: {epoch, position, the four bytes at that position} in 8 bytes.  The
+ *     lookup's answer says hit or miss; the gather of 16-64 candidate words (a line each) is gone.  The epoch - a counter
+ *     the wave keeps, one per frame - replaces the clearing of the table: an entry of another frame reads as lz4's
+ *     zero-initialised slot (position 0, with the block's first four bytes);
+ *   - the input around the parse point lives in a register window F (lane i = the dword at fb + 4i, 256 bytes): the probes'
+ *     own words, the literals, the catch-up and the forward count on the input's side, and the two words the test behind a
+ *     match needs all come out of it through cross-lane reads; it is re-based (one load) every couple of hundred bytes;
+ *   - on a hit ONE load brings the candidate's neighbourhood (C: 16 bytes before it, 240 behind) - catch-up and count are
+ *     compares of F against C in registers, and only a match longer than that goes back to memory;
+ *   - the block is put together in LDS and leaves as whole 16-byte rows (tokens, length bytes and offsets were single-byte
+ *     stores of lane 0).
+ * A streak that goes beyond its first sixteen probes (data that does not compress) reads its probes' words from memory as
+ * before; literal runs above 128 bytes are copied memory to memory. */
+#define QZK_L4C_OST 832u            /* staging: a flush leaves < 256 + 16 bytes, a sequence adds at most 1 + 2 + 128 + 2 + 258 */
+#define QZK_L4C_LITMAX 128u
+typedef struct { uint8_t *st; uint8_t *out; uint32_t oph, op, adj, hd; } qzk_l4o;
+#define QZK_L4O_IDX(O_, p_) ((uint32_t)(p_) + (O_)->adj)
+QZ_DEV void qzk_l4o_init(qzk_l4o *O, uint8_t *st, uint8_t *out)
+{
+    O->st = st; O->out = out; O->oph = (uint32_t)((uintptr_t)out & 15); O->op = 0; O->adj = O->oph; O->hd = O->oph;
+}
+/* whole rows out, the ragged one to the front (as qzk_lz_batch.h) */
+QZ_DEV void qzk_l4o_rows(qzk_l4o *O, int lane)
+{
+    const uint32_t total = QZK_L4O_IDX(O, O->op), R = total >> 4;
+    if (!R) return;
+    qz_lds_sync();
+    uint8_t *const g0 = O->out - (int32_t)O->adj;                          /* 16-byte aligned (adj = phase - 16 * rows gone) */
+    uint32_t first = 0;
+    if (O->hd) { if ((uint32_t)lane >= O->hd && lane < 16) g0[lane] = O->st[lane]; first = 1; O->hd = 0; }
+    for (uint32_t rw = first + (uint32_t)lane; rw < R; rw += 64) *(qzk_rb_u32x4 *)(g0 + 16 * rw) = *(const qzk_rb_u32x4 *)(O->st + 16 * rw);
+    qz_lds_sync();
+    if ((total & 15) && lane < 4) ((uint32_t *)O->st)[lane] = ((const uint32_t *)O->st)[4 * R + (uint32_t)lane];
+    O->adj -= 16 * R;
+    qz_lds_sync();
+}
+/* everything out (before a direct copy, at the end) */
+QZ_DEV void qzk_l4o_all(qzk_l4o *O, int lane)
+{
+    qzk_l4o_rows(O, lane);
+    const uint32_t sh = QZK_L4O_IDX(O, O->op);                     /* < 16 */
+    qz_lds_sync();
+    if ((uint32_t)lane >= O->hd && (uint32_t)lane < sh) (O->out - (int32_t)O->adj)[lane] = O->st[lane];
+    O->hd = sh;
+    qz_lds_sync();                                                  /* the staging is written again from here on */
+}
+QZ_DEV void qzk_l4o_byte(qzk_l4o *O, uint32_t b, int lane) { if (lane == 0) O->st[QZK_L4O_IDX(O, O->op)] = (uint8_t)b; O->op++; }
+/* a length that did not fit its nibble: len - 15 in bytes of 255 */
+QZ_DEV void qzk_l4o_len(qzk_l4o *O, uint32_t len, int lane)
+{
+    const uint32_t nff = len / 255u;
+    uint8_t *d = O->st + QZK_L4O_IDX(O, O->op);
+    for (uint32_t i = (uint32_t)lane; i < nff; i += 64) d[i] = 255;
+    if (lane == 0) d[nff] = (uint8_t)(len - 255u * nff);
+    O->op += nff + 1;
+}
+
+/* the register window: 256 bytes of the block from fb on, a dword per lane; bytes behind the block's end read as zero */
+QZ_DEV uint32_t qzk_f_load(const uint8_t *in, uint32_t n, uint32_t fb, int lane)
+{
+    const uint32_t o = fb + 4u * (uint32_t)lane;
+    if (o + 4 <= n) return qz_ld32(in + o);
+    uint32_t v = 0;
+    for (uint32_t t = 0; t < 4; t++) if (o + t < n) v |= (uint32_t)in[o + t] << (8 * t);
+    return v;
+}
+QZ_DEV uint32_t qzk_alignb(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * sh)); }
+/* the dword at byte r of the window, r of the lane's own (r + 4 <= 256; every lane takes part) */
+QZ_DEV uint32_t qzk_f_x32(uint32_t F, uint32_t r)
+{
+    const uint32_t k = (r >> 2) & 63u;
+    const uint32_t lo = qz_shfl(F, (int)k), hi = qz_shfl(F, (int)(k < 63u ? k + 1 : 63u));
+    return qzk_alignb(hi, lo, r & 3u);
+}
+QZ_DEV uint32_t qzk_f_u32(uint32_t F, uint32_t r)                  /* the same for a wave-uniform r */
+{
+    const uint32_t k = r >> 2;
+    const uint32_t lo = qz_readlane(F, (int)k), hi = qz_readlane(F, (int)(k < 63u ? k + 1 : 63u));
+    return qzk_alignb(hi, lo, r & 3u);
+}
+
+QZ_DEV uint64_t qzk_lz4_tld64(const uint64_t *p)
+{
+#ifndef QZ_SIM
+    uint64_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+#else
+    return *p;
+#endif
+}
+#define QZK_L4E(ep_, pos_, v_) ((uint64_t)(ep_) << 48 | (uint64_t)(pos_) << 32 | (uint64_t)(v_))
+
+/* LZ4 block compress of in[0..n) into out (capacity cap) through `table` (QZK_LZ4_HASHSZ entries of 8 bytes in device
+ * memory, this wave's, never cleared per block: `epoch` != 0 is this block's); returns the size, 0 when it does not fit */
+QZ_DEV uint32_t qzk_lz4_block_f(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap, uint64_t *table, uint32_t epoch,
+                                uint32_t *slot, uint8_t *stage, int lane)
+{
+    qzk_l4o O; qzk_l4o_init(&O, stage, out);
+    const uint32_t be = n;
+    uint32_t anchor = 0, ip;
+    const int32_t mfl1 = (int32_t)be - QZK_LZ4_MFLIMIT + 1;     /* mflimitPlusOne */
+    const uint32_t matchlimit = be - QZK_LZ4_LASTLIT;
+    bool ended = false;
+    if (n >= QZK_LZ4_MFLIMIT + 1) {
+        const uint32_t in0 = qz_ld32(in);                           /* what lz4's zero-initialised table points at */
+        uint32_t fb = 0, F = qzk_f_load(in, n, 0, lane);
+#define QZK_L4DEC(e_, cand_, cv_) do { const bool mine_ = (uint32_t)((e_) >> 48) == epoch; \
+            cand_ = mine_ ? (uint32_t)((e_) >> 32) & 0xffffu : 0u; cv_ = mine_ ? (uint32_t)(e_) : in0; } while (0)
+        ip = 1;
+        for (;;) {
+            /* ---------------- search streak from ip ---------------- */
+            {   /* the window covers the literals so far (when they are few enough to go through it) and the first probes */
+                const uint32_t lo = ip - anchor <= QZK_L4C_LITMAX ? anchor : (ip >= 16 ? ip - 16 : 0);
+                if (fb > lo || ip + 20 > fb + 256) { fb = lo; F = qzk_f_load(in, n, fb, lane); }
+            }
+            uint32_t j0 = 0, mpos = 0, mcand = 0; bool found = false;
+            for (;;) {
+                const uint32_t W = j0 == 0 ? QZK_LZ4_W0 : 64u;
+                const bool inw = (uint32_t)lane < W;
+                const uint32_t j = j0 + (uint32_t)lane, t = j ? j - 1 : 0, b = t >> 6, r = t & 63;
+                const uint32_t f = ip + (j ? 1 + 32 * b * (b + 1) + (b + 1) * r : 0), step = j ? (63 + j) >> 6 : 1;
+                const bool can = (int32_t)(f + step) <= mfl1;        /* else this probe is the `goto _last_literals` */
+                const bool live = inw && can;
+                uint32_t v = 0, h = 0, cand = 0, cv = 0;
+                if (j0 == 0) { const uint32_t x = qzk_f_x32(F, live ? f - fb : 0u); v = live ? x : 0u; }
+                else if (live) v = qz_ld32(in + f);
+                if (live) { h = QZK_LZ4HASH(v); const uint64_t e = qzk_lz4_tld64(table + h); QZK_L4DEC(e, cand, cv); }
+                const uint32_t key = h & 1023;
+                if (live) slot[key] = 64;
+                qz_lds_sync();
+                if (live) atomicMin(&slot[key], (uint32_t)lane);
+                qz_lds_sync();
+                const bool suspect = live && slot[key] != (uint32_t)lane;
+                const bool hit = live && !suspect && cv == v;
+                const uint64_t DEAD = qz_ballot(inw && !can);
+                uint64_t HIT = qz_ballot(hit);
+                const uint64_t SUS = qz_ballot(suspect);
+                const int first_dead = DEAD ? qz_ctz64(DEAD) : (int)W;
+                int bound = HIT ? qz_ctz64(HIT) : (int)W;
+                if (bound > first_dead) bound = first_dead;
+                /* replay colliding lanes that come before the first clean hit */
+                uint64_t todo = SUS & qz_below(bound);
+                int fl = bound; uint32_t fcand = 0;
+                while (todo) {
+                    int s = qz_ctz64(todo);
+                    todo &= todo - 1;
+                    uint32_t hs = qz_readlane(h, s), vs = qz_readlane(v, s);
+                    uint64_t same = qz_ballot(live && h == hs) & qz_below(s);
+                    uint32_t cs, cw;
+                    if (same) { int m = qz_msb64(same); cs = qz_readlane(f, m); cw = qz_readlane(v, m); }
+                    else { cs = qz_readlane(cand, s); cw = qz_readlane(cv, s); }
+                    if (cw == vs) { fl = s; fcand = cs; break; }
+                }
+                if (fl == bound && bound < first_dead && HIT) fcand = qz_readlane(cand, bound);
+                const bool got = fl < first_dead && (fl < bound || (HIT && bound < (int)W && fl == bound));
+                /* insert every probed position up to and including the hit (or the whole window): per key the highest
+                 * (rest of the hash, lane) wins, its hash is served, the other hashes on that key go round again */
+                const int last_ins = got ? fl : (first_dead < (int)W ? first_dead - 1 : (int)W - 1);
+                {
+                    bool pend = live && lane <= last_ins;
+                    const uint32_t val = (((h >> 10) << 6) | (uint32_t)lane) + 1;
+                    while (qz_ballot(pend)) {
+                        if (pend) slot[key] = 0;
+                        qz_lds_sync();
+                        if (pend) atomicMax(&slot[key], val);
+                        qz_lds_sync();
+                        const uint32_t w = pend ? slot[key] : 0;
+                        if (pend && w == val) table[h] = QZK_L4E(epoch, f, v);
+                        if (pend && ((w - 1) >> 6) == (h >> 10)) pend = false;      /* my hash was the one served */
+                        qz_lds_sync();
+                    }
+                }
+                if (got) { found = true; mpos = qz_readlane(f, fl); mcand = fcand; break; }
+                if (first_dead < (int)W) break;                      /* ran into the end: last literals */
+                j0 += W;
+            }
+            if (!found) break;
+            /* ---------------- catch up + sequence(s) ---------------- */
+            uint32_t mip = mpos, match = mcand;
+            uint32_t cb = match >= 16 ? match - 16 : 0;
+            uint32_t C = qzk_f_load(in, n, cb, lane);               /* the candidate's neighbourhood: the sequence's one load */
+            {   /* backward extension: lane i compares the bytes i + 1 back, sixteen at a time out of the two windows */
+                const uint32_t maxb = mip - anchor < match ? mip - anchor : match;
+                const uint32_t fhas = mip >= fb && mip <= fb + 256u ? mip - fb : 0u;      /* bytes before mip that F holds */
+                const uint32_t reach = fhas < 16u ? fhas : 16u;                          /* (C holds sixteen, or all there is) */
+                const uint32_t lim = maxb < reach ? maxb : reach;
+                const uint32_t ro = mip - 1 - (uint32_t)lane - fb, rc = match - 1 - (uint32_t)lane - cb;
+                const bool act = (uint32_t)lane < lim;
+                const uint32_t ow = qz_shfl(F, act ? (int)(ro >> 2) : 0), cw = qz_shfl(C, act ? (int)(rc >> 2) : 0);
+                const bool eq = act && ((ow >> (8 * (ro & 3))) & 0xff) == ((cw >> (8 * (rc & 3))) & 0xff);
+                const uint64_t NE = ~qz_ballot(eq);
+                uint32_t back = NE ? (uint32_t)qz_ctz64(NE) : 64u;
+                if (back > lim) back = lim;
+                if (back == lim && lim < maxb) {
+                    /* everything at hand agreed and there may be more: the rest from memory (rare) */
+                    while (back < maxb) {
+                        uint32_t i = back + 1 + (uint32_t)lane;
+                        bool a2 = i <= maxb;
+                        bool ne = a2 && in[mip - i] != in[match - i];
+                        uint64_t mm = qz_ballot(ne), am = qz_ballot(a2);
+                        if (mm) { back += (uint32_t)qz_ctz64(mm); break; }
+                        back += (uint32_t)qz_popc64(am);
+                    }
+                }
+                mip -= back; match -= back;
+            }
+            const uint32_t lit = mip - anchor;
+            if (QZK_L4O_IDX(&O, O.op) >= 256) qzk_l4o_rows(&O, lane);
+            uint32_t token_at = O.op; bool tok_staged = true;
+            if (O.op + 1 + lit + (2 + 1 + QZK_LZ4_LASTLIT) + lit / 255 > cap) return 0;
+            qzk_l4o_byte(&O, 0, lane);
+            uint32_t tok;
+            if (lit >= 15) { tok = 15u << 4; qzk_l4o_len(&O, lit - 15, lane); } else tok = lit << 4;
+            if (lit != 0 && lit <= QZK_L4C_LITMAX && anchor >= fb && mip <= fb + 256) {
+                /* literals out of the window: lane i's dword holds the literals 4i - a0 .. 4i - a0 + 3 */
+                const uint32_t a0 = anchor - fb;
+                uint8_t *d = O.st + QZK_L4O_IDX(&O, O.op);
+#pragma unroll
+                for (uint32_t t = 0; t < 4; t++) { const uint32_t k = 4u * (uint32_t)lane + t - a0; if (k < lit) d[k] = (uint8_t)(F >> (8 * t)); }
+                O.op += lit;
+            } else if (lit != 0) {
+                qzk_l4o_all(&O, lane);                              /* token and length bytes first, then the run memory to memory */
+                tok_staged = false;
+                uint8_t *d = O.out + O.op; const uint8_t *sp = in + anchor;
+                for (uint32_t i = 8 * (uint32_t)lane; i + 8 <= lit; i += 512) qzk_rb_st64(d + i, qzk_rb_ld64(sp + i));
+                { const uint32_t t8 = lit & ~7u; if ((uint32_t)lane < (lit & 7u)) d[t8 + (uint32_t)lane] = sp[t8 + (uint32_t)lane]; }
+                O.op += lit;
+                O.adj = ((O.oph + O.op) & 15u) - O.op; O.hd = (O.oph + O.op) & 15u;
+            }
+            for (;;) {          /* _next_match */
+                if (lane == 0) { uint8_t *d = O.st + QZK_L4O_IDX(&O, O.op); d[0] = (uint8_t)(mip - match); d[1] = (uint8_t)((mip - match) >> 8); }
+                O.op += 2;
+                /* forward count: the input's side from F, the candidate's from C, a dword per lane; what they do not hold
+                 * (a match longer than ~230 bytes, a window that ends early) from memory */
+                const uint32_t maxlen = matchlimit - (mip + 4);
+                uint32_t mc;
+                {
+                    const uint32_t a0 = mip + 4 - fb, b0 = match + 4 - cb;             /* byte offsets in F and C (may lie outside) */
+                    const bool fin = mip + 4 >= fb && a0 < 256u, cin = match + 4 >= cb && b0 < 256u;
+                    const uint32_t fa = fin ? (256u - a0) >> 2 : 0, ca = cin ? (256u - b0) >> 2 : 0;    /* whole dwords at hand */
+                    uint32_t nd = fa < ca ? fa : ca;                                    /* dwords both hold */
+                    if (nd > (maxlen + 3) >> 2) nd = (maxlen + 3) >> 2;
+                    const uint32_t ra = fin ? a0 + 4u * (uint32_t)lane : 0u, rb = cin ? b0 + 4u * (uint32_t)lane : 0u;
+                    const bool act = (uint32_t)lane < nd;
+                    const uint32_t xa = qzk_f_x32(F, act ? ra : 0u), xb = qzk_f_x32(C, act ? rb : 0u);
+                    uint32_t x = act ? xa ^ xb : 0u;
+                    const uint32_t left = maxlen - 4u * (uint32_t)lane;                 /* bytes of my dword that count */
+                    if (act && left < 4u) x &= (1u << (8 * left)) - 1u;
+                    const uint64_t mm = qz_ballot(x != 0);
+                    if (mm) {
+                        const int fl = qz_ctz64(mm);
+                        const uint32_t xf = qz_readlane(x, fl);
+                        mc = 4u * (uint32_t)fl + ((uint32_t)qz_ctz32(xf) >> 3);
+                    } else {
+                        const uint32_t covered = 4u * nd < maxlen ? 4u * nd : maxlen;
+                        mc = covered;
+                        if (covered < maxlen) mc += qzk_lz4_count(in + mip + 4 + covered, in + match + 4 + covered, maxlen - covered, lane);
+                    }
+                }
+                mip += mc + 4;
+                if (O.op + (1 + QZK_LZ4_LASTLIT) + (mc + 240) / 255 > cap) return 0;
+                if (mc >= 15) { tok += 15; qzk_l4o_len(&O, mc - 15, lane); } else tok += mc;
+                if (lane == 0) { if (tok_staged) O.st[QZK_L4O_IDX(&O, token_at)] = (uint8_t)tok; else O.out[token_at] = (uint8_t)tok; }
+                anchor = mip;
+                if ((int32_t)mip >= mfl1) { ended = true; break; }
+                /* fill table with ip-2, then test the next position right away; the window moves up if it has to */
+                if (fb + 2 > mip || mip + 24 > fb + 256) { fb = mip >= 16 ? mip - 16 : 0; F = qzk_f_load(in, n, fb, lane); }
+                const uint32_t v2 = qzk_f_u32(F, mip - 2 - fb), v0 = qzk_f_u32(F, mip - fb);
+                const uint32_t h2 = QZK_LZ4HASH(v2), h0 = QZK_LZ4HASH(v0);
+                if (lane == 0) table[h2] = QZK_L4E(epoch, mip - 2, v2);
+                qz_lds_sync();
+                const uint64_t e0 = qzk_lz4_tld64(table + h0);
+                qz_lds_sync();
+                if (lane == 0) table[h0] = QZK_L4E(epoch, mip, v0);
+                qz_lds_sync();
+                uint32_t mi, mv; QZK_L4DEC(e0, mi, mv);
+                if (mv == v0) {
+                    if (QZK_L4O_IDX(&O, O.op) >= 256) qzk_l4o_rows(&O, lane);
+                    token_at = O.op; tok_staged = true; tok = 0; match = mi;
+                    qzk_l4o_byte(&O, 0, lane);
+                    cb = match >= 16 ? match - 16 : 0; C = qzk_f_load(in, n, cb, lane);
+                    continue;
+                }
+                break;
+            }
+            if (ended) break;
+            ip = mip + 1;
+        }
+#undef QZK_L4DEC
+    }
+    /* last literals */
+    {
+        const uint32_t lr = be - anchor;
+        if (O.op + lr + 1 + (lr + 255 - 15) / 255 > cap) return 0;
+        if (QZK_L4O_IDX(&O, O.op) >= 256) qzk_l4o_rows(&O, lane);
+        if (lr >= 15) { qzk_l4o_byte(&O, 15u << 4, lane); qzk_l4o_len(&O, lr - 15, lane); } else qzk_l4o_byte(&O, lr << 4, lane);
+        qzk_l4o_all(&O, lane);
+        uint8_t *d = O.out + O.op; const uint8_t *sp = in + anchor;
+        for (uint32_t i = 8 * (uint32_t)lane; i + 8 <= lr; i += 512) qzk_rb_st64(d + i, qzk_rb_ld64(sp + i));
+        { const uint32_t t8 = lr & ~7u; if ((uint32_t)lane < (lr & 7u)) d[t8 + (uint32_t)lane] = sp[t8 + (uint32_t)lane]; }
+        O.op += lr;
+    }
+    return O.op;
+}
+
 /* K4: one LZ4 frame (<= 64 KB of content, one independent block) per wave, written to its slot:
  * LZ4F_compressFrame with {contentChecksum, contentSize, autoFlush, level < 3}. */
 /* hw_hdr: the header the reference's HARDWARE path puts in front of a chunk's frame (qzLZ4HeaderGen, src/qatzip_lz4.c:104-132):
@@ -407,18 +717,63 @@ QZ_KERNEL_MAX(64) qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t
  * latency chain per frame (probes' words, table, candidates' words, extension, count - global round trips all of them;
  * profiles/r3_lz4_ring_experiment.txt: its rate follows the waves in flight, not the latency of one), so the extra round
  * trip to the L2 per lookup is paid back several times by the waves that now fit. */
-QZ_KERNEL_OCC(64, 8) qzk_lz4c_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
-                          uint8_t *slots, uint32_t stride, uint32_t *out_len, uint32_t hw_hdr, uint16_t *tables, uint32_t *counter)
+#define QZK_L4C_TABW QZK_LZ4_HASHSZ          /* 8-byte entries per wave: 64 KiB of device memory */
+#ifndef QZK_L4C_OCC
+#define QZK_L4C_OCC 6            /* waves per SIMD the register budget is cut for: 80 VGPRs, nothing in scratch (7: 3 spilled, 8: 11) */
+#endif
+QZ_KERNEL_OCC(64, QZK_L4C_OCC) qzk_lz4c_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
+                          uint8_t *slots, uint32_t stride, uint32_t *out_len, uint32_t hw_hdr, uint64_t *tables, uint32_t *epochs, uint32_t *counter)
 {
     QZ_LDS uint32_t slot[1024];
-    uint16_t *const table = tables + (size_t)blockIdx.x * QZK_LZ4_HASHSZ;
+    QZ_LDS __attribute__((aligned(16))) uint8_t stage[QZK_L4C_OST];
+    const int lane = qz_lane();
+    uint64_t *const table = tables + (size_t)blockIdx.x * QZK_L4C_TABW;
+    /* the wave's epoch lives on between launches (the table is only ever cleared when the 16 bits run out): cleared memory
+     * and epoch 0 are what the host hands over */
+    uint32_t ep = epochs[blockIdx.x];
     for (;;) {
-        uint32_t fr = atomicAdd(counter, qz_lane() == 0 ? 1u : 0u);       /* every lane takes part, lane 0 adds (see qzk_lz77_pull_kernel) */
+        uint32_t fr = atomicAdd(counter, lane == 0 ? 1u : 0u);       /* every lane takes part, lane 0 adds (see qzk_lz77_pull_kernel) */
         fr = qz_readfirstlane(fr);
         if (fr >= nframes) break;
-        qzk_lz4c_frame<true>(src, src_len, frame_sz, fr, slots, stride, out_len, hw_hdr, table, slot, qz_lane());
+        if (++ep > 0xffffu) {
+            for (uint32_t i = (uint32_t)lane; i < QZK_L4C_TABW; i += 64) table[i] = 0;
+            ep = 1;
+        }
+        const uint64_t off = (uint64_t)fr * frame_sz;
+        const uint32_t n = (uint32_t)((src_len - off) < frame_sz ? (src_len - off) : frame_sz);
+        const uint8_t *in = src + off;
+        uint8_t *o = slots + (uint64_t)fr * stride;
+        /* frame header: magic, FLG (v1 | independent | [content size] | content checksum), BD 64 KB (qzk_lz4c_frame) */
+        if (lane == 0) {
+            o[0] = 0x04; o[1] = 0x22; o[2] = 0x4d; o[3] = 0x18;
+            o[4] = hw_hdr ? (uint8_t)0x4C : (uint8_t)((1u << 6) | (1u << 5) | (n ? 1u << 3 : 0) | (1u << 2));
+            o[5] = 4u << 4;
+            if (n || hw_hdr) { o[6] = (uint8_t)n; o[7] = (uint8_t)(n >> 8); o[8] = (uint8_t)(n >> 16); o[9] = (uint8_t)(n >> 24); o[10] = o[11] = o[12] = o[13] = 0; }
+        }
+        qz_wave_sync();
+        uint32_t pos = (n || hw_hdr) ? 14 : 6;
+        {
+            const uint32_t hc = qzk_wave_xxh32(o + 4, pos - 4, lane);
+            if (lane == 0) o[pos] = (uint8_t)(hc >> 8);
+            pos++;
+        }
+        if (n) {
+            uint32_t c = qzk_lz4_block_f(in, n, o + pos + 4, n - 1, table, ep, slot, stage, lane);
+            const uint32_t bh = c ? c : (n | 0x80000000u);
+            if (c == 0) { qzk_wave_copy(o + pos + 4, in, n, lane); c = n; }
+            if (lane == 0) { o[pos] = (uint8_t)bh; o[pos + 1] = (uint8_t)(bh >> 8); o[pos + 2] = (uint8_t)(bh >> 16); o[pos + 3] = (uint8_t)(bh >> 24); }
+            pos += 4 + c;
+        }
+        qz_lds_sync();
+        const uint32_t xx = qzk_wave_xxh32_staged(in, n, (uint8_t *)slot, lane);
+        if (lane == 0) {
+            o[pos] = o[pos + 1] = o[pos + 2] = o[pos + 3] = 0;
+            o[pos + 4] = (uint8_t)xx; o[pos + 5] = (uint8_t)(xx >> 8); o[pos + 6] = (uint8_t)(xx >> 16); o[pos + 7] = (uint8_t)(xx >> 24);
+        }
+        out_len[fr] = pos + 8;          /* wave-uniform: every lane stores the same word */
         qz_wave_sync();
     }
+    if (lane == 0) epochs[blockIdx.x] = ep;
 }
 
 /* K4 for one call above 64 KB: the frame LZ4F_compressFrame writes for it (src/qatzip_sw.c:451-456) - FLG 0x4C (blocks

@@ -196,6 +196,8 @@ class OneStream:
         import time
         import numpy as np
         L, ctx, rank, world, n, chunk = self.L, self.ctx, self.rank, self.world, self.n, self.chunk
+        if self.error:
+            return {"error": "this OneStream is unusable after an earlier failure: " + self.error}
         self.seq += 1
         err = None
         out = {}
@@ -230,7 +232,8 @@ class OneStream:
             err = "gather: " + str(e)[:150]
         t2 = time.perf_counter()
         if not _all_ok(self.pg, err is None):
-            return {"error": err or "another rank failed"}
+            self.error = err or "another rank failed"
+            return {"error": self.error}
         out = {"ms": (t2 - t0) * 1e3, "deflate_ms": (t1 - t0) * 1e3, "gather_ms": (t2 - t1) * 1e3, "comp_len": clen, "crc": crc}
         if rank == 0:
             out.update({"raw_bytes": raw.value, "member_bytes": slen.value, "crc32": "%08x" % fcrc.value})
@@ -257,6 +260,8 @@ class OneStream:
         import numpy as np
         from . import _lib
         L, ctx, rank, world, chunk = self.L, self.ctx, self.rank, self.world, self.chunk
+        if self.error:
+            return {"error": "this OneStream is unusable after an earlier failure: " + self.error}
         M = len(plan)
         mine = local_offsets(plan, rank)
         nmax = max(n for _, n in mine)
@@ -272,20 +277,19 @@ class OneStream:
                 item = work.get()
                 if item is None:
                     return
-                m, b, n, clen, crc = item
+                m, b, n, clen, crc, seq = item
                 t0 = time.perf_counter()
                 try:
                     if gat["err"] is None:
-                        self.seq += 1
                         dptr, slen, fcrc, raw = C.c_void_p(), C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
                         if self.transport == "rccl":
                             if L.qzd_rccl_gather(self.h, bufs[b].ptr, clen, n, crc, self.level, C.byref(dptr), C.byref(slen),
                                                  C.byref(fcrc), C.byref(raw)) != 0:
                                 gat["err"] = "member %d gather: %s" % (m, L.qzd_last_error(self.tctx.h).decode())
                         else:
-                            if L.qzd_shard_put(self.h, bufs[b].ptr, clen, n, crc, self.seq, self.timeout_s, None) != 0:
+                            if L.qzd_shard_put(self.h, bufs[b].ptr, clen, n, crc, seq, self.timeout_s, None) != 0:
                                 gat["err"] = "member %d put: %s" % (m, L.qzd_last_error(self.tctx.h).decode())
-                            elif rank == 0 and L.qzd_shard_finish(self.h, self.seq, self.timeout_s, self.level, C.byref(dptr),
+                            elif rank == 0 and L.qzd_shard_finish(self.h, seq, self.timeout_s, self.level, C.byref(dptr),
                                                                   C.byref(slen), C.byref(fcrc), C.byref(raw)) != 0:
                                 gat["err"] = "member %d finish: %s" % (m, L.qzd_last_error(self.tctx.h).decode())
                         if gat["err"] is None and rank == 0:
@@ -331,7 +335,10 @@ class OneStream:
                 free[b].release()
                 err = err or gat["err"] or "another rank failed before member %d" % m
                 break
-            work.put((m, b, n, clen, crc))
+            # the member's sequence number is the same on every rank whatever happens to the member: counted here, per
+            # member queued, not by the gather thread on success (after a failure the ranks' numbers diverged)
+            self.seq += 1
+            work.put((m, b, n, clen, crc, self.seq))
         work.put(None)
         th.join()
         t_end = time.perf_counter()
@@ -339,7 +346,11 @@ class OneStream:
         for extra in bufs[1:]:
             extra.free()
         if not ok:
-            return {"error": err or gat["err"] or "another rank failed"}
+            # a gather that failed on one rank may have been entered by the others (the agreement before member m cannot know
+            # how member m - 1's gather, still in flight, will end): their transport waits are bounded, and nobody uses this
+            # stream's window / communicator again
+            self.error = err or gat["err"] or "another rank failed"
+            return {"error": self.error}
         if self.pg is not None:
             self.pg.barrier()
         overl = sum(max(0.0, min(g1, d1) - max(g0, d0)) for g0, g1 in gat["busy"] for d0, d1 in defl_spans) * 1e3

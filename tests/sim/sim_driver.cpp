@@ -265,10 +265,16 @@ int sim_lz4c(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, 
 int sim_lz4c_pull(const uint8_t *src, uint64_t n, uint32_t frame_sz, uint8_t *slots, uint32_t stride, uint32_t *out_len, uint32_t waves)
 {
     uint32_t nframes = n ? (uint32_t)((n + frame_sz - 1) / frame_sz) : 1;
-    std::vector<uint16_t> tables((size_t)waves * QZK_LZ4_HASHSZ + 8, (uint16_t)0xabcd);      /* junk: every frame clears its own */
-    uint16_t *tab = (uint16_t *)(((uintptr_t)tables.data() + 15) & ~(uintptr_t)15);
+    /* the waves' tables and epochs live on from launch to launch, as on the device (cleared once); QZSIM_LZ4_EPOCH0 starts the
+     * epochs close to the 16-bit wrap so that the re-clearing is exercised */
+    static std::vector<uint64_t> tables;
+    static std::vector<uint32_t> epochs;
+    if (tables.size() < (size_t)waves * QZK_L4C_TABW) {
+        tables.assign((size_t)waves * QZK_L4C_TABW, 0ull);
+        epochs.assign(waves, getenv("QZSIM_LZ4_EPOCH0") ? (uint32_t)atoi(getenv("QZSIM_LZ4_EPOCH0")) : 0u);
+    }
     uint32_t counter = 0;
-    sim::launch(waves, 64, 0, [&] { qzk_lz4c_pull_kernel(src, n, frame_sz, nframes, slots, stride, out_len, 0, tab, &counter); });
+    sim::launch(waves, 64, 0, [&] { qzk_lz4c_pull_kernel(src, n, frame_sz, nframes, slots, stride, out_len, 0, tables.data(), epochs.data(), &counter); });
     return (int)nframes;
 }
 /* the same frames behind the hardware path's header (FLG 0x4C, content size always there) */

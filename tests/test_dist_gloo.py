@@ -98,19 +98,19 @@ def test_member_plan_covers_the_buffer_in_order():
 HW_M, SL_M, TOTAL_M = 16384, 3 * 16384, 2 * (7 * 16384) + 333        # three members over two ranks: 6 + 6 + (2 chunks and a bit)
 
 
-def _member_worker(rank, world, port, q):
+def _member_worker(rank, world, port, q, total=TOTAL_M, hw=HW_M, sl=SL_M):
     sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    plan = S.member_plan(TOTAL_M, world, HW_M, SL_M)
-    logical = datagen.gen_bytes("silesia", TOTAL_M, 9)
+    plan = S.member_plan(total, world, hw, sl)
+    logical = datagen.gen_bytes("silesia", total, 9)
     members = []
     for m, shards in enumerate(plan):
         off, n = shards[rank]
         mine = logical[off:off + n]                                    # the striped volume: my shard of member m
         last_holder = max(r for r in range(world) if shards[r][1] or r == 0)
-        rc, used, comp, _ = O.sw_compress("RAW", mine, HW_M, 1, last=1 if rank == last_holder else 0) if (n or rank == last_holder) else (0, 0, b"", 0)
+        rc, used, comp, _ = O.sw_compress("RAW", mine, hw, 1, last=1 if rank == last_holder else 0) if (n or rank == last_holder) else (0, 0, b"", 0)
         assert rc == 0 and used == len(mine)
         recs = S.all_gather_records(dist, S.pack_record(len(mine), len(comp), zlib.crc32(mine)), world)
         offs, raw, total, crc = S.fold_records(recs)
@@ -120,21 +120,20 @@ def _member_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_three_members_from_two_ranks_are_what_the_software_path_writes():
-    world = 2
+def _members_against_the_software_path(world, total, hw, sl, nmembers, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    ps = [ctx.Process(target=_member_worker, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_member_worker, args=(r, world, port, q, total, hw, sl)) for r in range(world)]
     for p in ps:
         p.start()
-    got = dict(q.get(timeout=120) for _ in ps)
+    got = dict(q.get(timeout=300) for _ in ps)
     for p in ps:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    logical = datagen.gen_bytes("silesia", TOTAL_M, 9)
-    plan = S.member_plan(TOTAL_M, world, HW_M, SL_M)
-    assert len(plan) == 3
+    logical = datagen.gen_bytes("silesia", total, 9)
+    plan = S.member_plan(total, world, hw, sl)
+    assert len(plan) == nmembers
+    HW_M = hw
     out, expect, pos = b"", b"", 0
     for m, shards in enumerate(plan):
         _, _, raw, total, crc = got[0][m]
@@ -150,3 +149,24 @@ def test_three_members_from_two_ranks_are_what_the_software_path_writes():
     assert pos == len(logical) and out == expect
     rc, used, back = O.sw_decompress("GZIP_EXT", out, len(logical) + 64)            # and the sequence decodes to the buffer, in order
     assert rc == 0 and used == len(out) and back == logical
+
+
+def test_three_members_from_two_ranks_are_what_the_software_path_writes():
+    _members_against_the_software_path(2, TOTAL_M, HW_M, SL_M, 3, 31500 + os.getpid() % 2000)
+
+
+def test_eight_ranks_ragged_members():
+    """BASELINE config 5's shape in small: EIGHT ranks, members whose last one is ragged - three ranks hold a chunk of it, one
+    the last 123 bytes, four nothing at all (they still take part in the record exchange, the rank before them closes
+    the member's stream) - against one qzCompress call per member of the software path (src/qatzip.c:1691-1718: the
+    engine's in-order retire across accelerators)"""
+    hw, sl = 4096, 2 * 4096
+    total = 2 * (8 * sl) + 3 * hw + 123                                             # two full members, then three chunks and 123 bytes
+    plan = S.member_plan(total, 8, hw, sl)
+    tail = [n for _, n in plan[-1]]
+    assert sum(tail) == 3 * hw + 123 and tail.count(0) == 4 and sorted(x for x in tail if x) == [123, hw, hw, hw]
+    for r in range(8):                                                              # every rank's own bytes lie back to back in its buffer
+        loc = S.local_offsets(plan, r)
+        assert [o for o, _ in loc] == [sum(n for _, n in loc[:i]) for i in range(len(loc))]
+        assert [n for _, n in loc] == [plan[m][r][1] for m in range(len(plan))]
+    _members_against_the_software_path(8, total, hw, sl, 3, 33500 + os.getpid() % 2000)

@@ -172,3 +172,20 @@ def test_two_sessions_on_one_gpu_at_once():
     for t in th:
         t.join()
     assert not errs, errs
+
+
+def test_decode_without_room_for_its_scratch(ctx, monkeypatch):
+    """the K-lane phase A wants ~10 bytes of token scratch per output byte.  When that cannot be had the decode
+    goes on with one sub-stream per segment (a third of it), then with a wave per segment (none) - the caller gets its bytes,
+    not QZ_DATA_ERROR for valid data.  QATZIP_AMD_SCRATCH_MAX stands in for the allocation that fails."""
+    n = 8 << 20
+    src = datagen.gen_bytes("silesia", n, 31)
+    rc, _, comp, _ = O.sw_compress("RAW", src, 65536, 1, cap=n * 9 // 8 + 65536)
+    assert rc == 0
+    for cap_bytes in (48 << 20, 1 << 20):          # room for one sub-stream per segment (K = 1: ~30 MB); room for nothing
+        monkeypatch.setenv("QATZIP_AMD_SCRATCH_MAX", str(cap_bytes))
+        iu, out, crc = _inflate(ctx, comp, n, 65536)
+        assert out == src and iu == len(comp) and crc == (zlib.crc32(src) & 0xffffffff), cap_bytes
+    monkeypatch.delenv("QATZIP_AMD_SCRATCH_MAX")
+    iu, out, crc = _inflate(ctx, comp, n, 65536)
+    assert out == src

@@ -140,7 +140,8 @@ def _members_worker(rank, world, port, total, transport, q):
     ctx.close()
 
 
-@pytest.mark.parametrize("world,total", [(3, 3 * (3 * SLICE_M) + 2 * CH_M + 4321), (2, 4 * (2 * SLICE_M))])
+@pytest.mark.parametrize("world,total", [(3, 3 * (3 * SLICE_M) + 2 * CH_M + 4321), (2, 4 * (2 * SLICE_M)),
+                                         (8, 2 * (8 * SLICE_M) + 3 * CH_M + 321)])       # eight ranks, a ragged third member: four ranks hold nothing of it
 def test_members_of_a_larger_buffer_follow_each_other_like_calls(world, total):
     """>= 3 members x 3 ranks (sharing this box's GPU: the IPC window is the same path): the concatenation is, byte for
     byte, what the software path writes for one qzCompress call per member (src/qatzip_sw.c:77-256, the in-order retire it
