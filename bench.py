@@ -420,8 +420,8 @@ def raw_sweep(ctx, qz, d_src, mb, sizes=(16384, 65536, 131072)):
                     "ratio": round(cl / n, 4), "lz77_ms_first_batch": round(k1[0], 2),
                     "deflate_kernel_ms": round(kc, 2), "deflate_frac": round(alg / (kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kc > 0 else None,
                     "inflate_kernel_ms": round(kd, 2), "inflate_frac": round(alg / (kd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kd > 0 else None,
-                    "deflate_traffic": pmc_traffic("r4_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),), ("qzk_lz77_pull_kernel",)),
-                    "inflate_traffic": pmc_traffic("r4_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),),
+                    "deflate_traffic": pmc_traffic("r5_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),), ("qzk_lz77_pull_kernel",)),
+                    "inflate_traffic": pmc_traffic("r5_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),),
                                                    ("qzk_inflate_spec_kernel", "qzk_lz_resolve_kernel"))}
     assert ctx.crc32(d_b, n) == ctx.crc32(view(qz, d_src, 0, n), n)
     d_c.free(); d_b.free()
@@ -458,8 +458,8 @@ def lz4_leg(ctx, qz, d_src, mb):
             "ratio": round(cl / n, 4),
             "compress_kernel_ms": round(kc, 2), "compress_frac": round(alg / (kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kc > 0 else None,
             "decompress_kernel_ms": round(kd, 2), "decompress_frac": round(alg / (kd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kd > 0 else None,
-            "compress_traffic": pmc_traffic("r4_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4c_pull_kernel",)),
-            "decompress_traffic": pmc_traffic("r4_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4d_kernel",)),
+            "compress_traffic": pmc_traffic("r5_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4c_pull_kernel",)),
+            "decompress_traffic": pmc_traffic("r5_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4d_kernel",)),
             "note": "64 KB frames, XXH32 content checksum made and verified in-kernel; call rates host call to host return, "
                     "kernel_ms / frac = (U + C) over the kernels' HIP-event time over the HBM peak"}
 
@@ -536,7 +536,13 @@ def one_stream_leg(ctx, qz, pg, rank, world, d_src, slice_mb, members, steps, nd
     ranks' own CPU CRC-32s of member 0, and a prefix of member 0's payload against the oracle."""
     import zlib
     from qatzip_amd import shard
-    note = progress or (lambda what: None)                           # where the leg stands, for the line of a run that timed out
+    t_leg = time.perf_counter()
+
+    def note(what):                                                  # where the leg stands: for the line of a run that timed out ...
+        if progress:
+            progress(what)
+        if os.environ.get("QATZIP_AMD_BENCH_TRACE"):                 # ... and, rank by rank, for whoever debugs one
+            print("[one-stream leg, rank %d, +%.1f s] %s" % (rank, time.perf_counter() - t_leg, what), file=sys.stderr, flush=True)
     # the ranks of this leg share one node by contract: RCCL's bootstrap sockets may use the loopback interface (the
     # container's hostname need not resolve); a launcher that knows better sets the variable itself
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
@@ -547,20 +553,34 @@ def one_stream_leg(ctx, qz, pg, rank, world, d_src, slice_mb, members, steps, nd
     plan = shard.member_plan(total, world, CHUNK, sl)
     mine = shard.local_offsets(plan, rank)
     need = sum(n for _, n in mine)
-    # this rank's shards, back to back: the bench buffer, repeated when the plan is longer than it (synthetic either way)
-    if need <= d_src.nbytes:
-        src = view(qz, d_src, 0, need)
-        own = None
-    else:
-        own = src = ctx.alloc(need)
-        for off in range(0, need, d_src.nbytes):
-            ctx._chk(ctx.L.qzd_d2d(ctx.h, src.ptr + off, d_src.ptr, min(d_src.nbytes, need - off)))
+    # this rank's shards, back to back: the bench buffer, repeated when the plan is longer than it (synthetic either way).
+    # What can fail on ONE rank here (device memory: eight ranks rehearsing on one GPU share its HBM) is agreed upon before any
+    # transport is set up - a rank that left alone would leave the others waiting in the transport's first broadcast
+    note("buffers: %d MiB of shards per rank" % (need >> 20))
+    own = src = host = d_out = None
     n0 = mine[0][1]
-    host = src.download(n0) if n0 <= (1 << 30) else None
+    prep_err = None
+    try:
+        if need <= d_src.nbytes:
+            src = view(qz, d_src, 0, need)
+        else:
+            own = src = ctx.alloc(need)
+            for off in range(0, need, d_src.nbytes):
+                ctx._chk(ctx.L.qzd_d2d(ctx.h, src.ptr + off, d_src.ptr, min(d_src.nbytes, need - off)))
+        host = src.download(n0) if n0 <= (1 << 30) else None
+        d_out = ctx.alloc(total // 2 + (1 << 26)) if rank == 0 else None      # the bench data compresses to < 0.4: half is room enough
+    except Exception as e:   # noqa: BLE001
+        prep_err = "rank %d could not prepare its buffers (%d MiB of shards%s): %s" % (
+            rank, need >> 20, ", %d MiB of output" % ((total // 2 + (1 << 26)) >> 20) if rank == 0 else "", str(e)[:120])
     my_crc = zlib.crc32(host.tobytes()) & 0xffffffff if host is not None else 0
     out = {"ranks": world, "members": len(plan), "slice_MiB": slice_mb, "member_raw_MiB": world * slice_mb,
            "buffer_GB": round(total / 1e9, 2), "steps": steps}
-    d_out = ctx.alloc(total // 2 + (1 << 26)) if rank == 0 else None      # the bench data compresses to < 0.4: half is room enough
+    if not shard._all_ok(pg, prep_err is None):
+        for b in (own, d_out):
+            if b is not None:
+                b.free()
+        out["error"] = prep_err or "another rank could not prepare its buffers (device memory shared by %d ranks?)" % world
+        return out
     best = None
     for transport in ("ipc", "rccl"):
         if transport == "rccl" and ndev is not None and ndev < world:
@@ -806,8 +826,8 @@ def main():
         # FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note) and are quoted
         # only when that file was taken from the sources that are running now (SHA-256 over qatzip_amd/csrc) with this
         # command's --mb - null otherwise, never stale.
-        traffic = pmc_traffic("r4_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_lz77_pull_kernel",))
-        traffic_dec = pmc_traffic("r4_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_inflate_spec_kernel", "qzk_lz_resolve_kernel"))
+        traffic = pmc_traffic("r5_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_lz77_pull_kernel",))
+        traffic_dec = pmc_traffic("r5_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_inflate_spec_kernel", "qzk_lz_resolve_kernel"))
         value = 2.0 * raw_total * args.steps / dt / 1e9
         ratio = comp_total / raw_total
         # algorithmic bytes of the K1 launches of the timed region: every input byte read once, every compressed byte
@@ -837,6 +857,12 @@ def main():
                          "chunks_per_launch": round(k1_chunks / max(k1_launches, 1), 1),
                          "full_launch_alone_ms": round(k_ms[0], 3), "full_launch_chunks": probe_n // CHUNK,
                          "fused": "K2 (Huffman coding) and the chunk CRC-32 run inside this kernel's waves",
+                         # where this design stops (profiles/r5_k1_without_k2.txt): the same launch with K2
+                         # compiled out - the parse and the CRC alone, measured once on an MI355X, not by this run
+                         "design_ceiling_GBps": {"value": 58.5, "compress_input_GBps": 42.2, "launch_ms_4GiB": 101.8,
+                                                 "what": "qzk_lz77_pull_kernel with K2 compiled out (-DQZK_K1_NOK2), 4 GiB, (U + C) / launch; K2 in "
+                                                         "the wave costs 12.6 of 114.5 ms, the parse is bound by its table requests: parked",
+                                                 "source": "profiles/r5_k1_without_k2.txt"},
                          "other_kernels_ms": {"separate K2 / CRC launches": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
                                               "inflate kernels (last call)": round(inf_ms[0], 3),
                                               "of which qzk_lz_resolve_kernel": round(inf_ms[2], 3),
@@ -847,8 +873,8 @@ def main():
         dec_alg = float(comp_len[-1]) + float(call_n[-1])
         dec_ms = inf_ms[3] + inf_ms[2] if inf_ms[3] > 0 else inf_ms[0]          # phase A + phase B kernels (or the wave-per-segment kernel)
         if dec_ms > 0:
-            res["roofline_decode"] = {"bound": "hbm", "kernel": "qzk_inflate_spec_kernel<4> (phase A: Huffman decoding, four lanes per segment) + "
-                                                                "qzk_lz_resolve_kernel (phase B: matches)",
+            res["roofline_decode"] = {"bound": "hbm", "kernel": "qzk_inflate_spec_kernel<K> (phase A: Huffman decoding, K lanes per segment) + "
+                                                                "qzk_lz_resolve_kernel (phase B: the batch engine of qzk_lz_batch.h)",
                                       "achieved": round(dec_alg / (dec_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(dec_alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic_dec,
                                       "algorithmic_bytes": int(dec_alg), "launch_ms": round(dec_ms, 3),

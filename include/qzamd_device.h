@@ -214,6 +214,12 @@ int qzd_lz4_decompress_frames(qzd_ctx *ctx, const uint8_t *d_comp, uint8_t *d_ou
 typedef struct qzd_shard qzd_shard;
 int qzd_shard_root_create(qzd_ctx *ctx, uint32_t world, uint64_t cap_bytes, uint8_t handle_out[64], qzd_shard **out);
 int qzd_shard_attach(qzd_ctx *ctx, uint32_t rank, uint32_t world, const uint8_t handle[64], uint64_t cap_bytes, qzd_shard **out);
+/* round 5: the compressed shards travel through one SLOT per non-root rank (an allocation of its own, mapped by that rank
+ * alone) instead of one window of world x shard bytes - hipIpcOpenMemHandle never came back for a window above 2 GiB.
+ * Root: qzd_shard_slot_handle(root, r, handle) for every rank r >= 1; rank r: qzd_shard_attach_slot(mine, that handle)
+ * before its first qzd_shard_put(). */
+int qzd_shard_slot_handle(qzd_shard *root, uint32_t rank, uint8_t handle_out[64]);
+int qzd_shard_attach_slot(qzd_shard *shard, const uint8_t handle[64]);
 int qzd_shard_put(qzd_shard *s, const uint8_t *d_comp, uint64_t comp_len, uint64_t raw_len, uint32_t crc32, uint32_t seq,
                   double timeout_s, uint64_t *h_offset);
 /* level: the comp_lvl the shards were deflated at (the header's XFL byte follows it, as in a qzCompress call) */

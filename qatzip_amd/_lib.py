@@ -59,6 +59,8 @@ def load(build_if_missing=True):
     L.qzd_chunk_lens.argtypes = [vp, vp, C.c_uint32]
     L.qzd_shard_root_create.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_char_p, C.POINTER(vp)]
     L.qzd_shard_attach.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(vp)]
+    L.qzd_shard_slot_handle.argtypes = [vp, C.c_uint32, C.c_char_p]
+    L.qzd_shard_attach_slot.argtypes = [vp, C.c_char_p]
     L.qzd_shard_put.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_uint64)]
     L.qzd_shard_finish.argtypes = [vp, C.c_uint32, C.c_double, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                    C.POINTER(C.c_uint64)]
@@ -92,7 +94,7 @@ def exported_symbols():
             "qzd_lz4_compress_frames", "qzd_lz4_compress_frames_hw", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats",
             "qzd_adler32_chunks", "qzd_adler32_combine", "qzd_stream_copy_peak", "qzd_deflate_raw_from_host",
             "qzd_deflate_slots", "qzd_inflate_stream_to_host", "qzd_inflate_stream_from_host", "qzamd_async_stats", "qzd_shard_root_create",
-            "qzd_shard_attach", "qzd_lz4_compress_linked", "qzd_shard_put", "qzd_shard_finish", "qzd_shard_close", "qzd_crc32_combine",
+            "qzd_shard_attach", "qzd_shard_slot_handle", "qzd_shard_attach_slot", "qzd_lz4_compress_linked", "qzd_shard_put", "qzd_shard_finish", "qzd_shard_close", "qzd_crc32_combine",
             "qzd_crc32_fold", "qzd_pcie_peak", "qzd_rccl_unique_id", "qzd_rccl_create", "qzd_rccl_gather", "qzd_rccl_close"]
 
 

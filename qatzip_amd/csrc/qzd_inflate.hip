@@ -56,10 +56,10 @@
  * of a segment share its tables in LDS, start at evenly spaced bits and fall into step with each other.  How many: the chip
  * seats 2048 waves of this kernel, and a launch that does not fill it ends with its longest lane - so up to 8192 segments
  * sixteen lanes each (1 GiB of 128 KB segments: 17.1 -> 14.6 ms; 256 MiB of 64 KB: 11.2 -> 8.6; 16 MiB: 5.7 -> 4.1), eight up
- * to 16384, four beyond (a full chip is better served by fewer lanes falling into step).  Exceptions, both measured:
- * segments above 256 KB hold so many blocks that sixteen pieces per block outgrow the chain (QZK_CHAIN_MAXEL) and come back
- * through the serial kernel (1 GiB of 512 KB: 89 ms with eight lanes, 221 with sixteen); segments of 16 KB and less give
- * sixteen lanes under a hundred bytes each. */
+ * to 16384, four beyond (a full chip is better served by fewer lanes falling into step).  Exception, measured: segments of
+ * 16 KB and less give sixteen lanes under a hundred bytes each.  (Round 4 also kept sixteen lanes from segments above 256 KB:
+ * twenty blocks of sixteen pieces outgrew a piece list of 160 and came back through the serial kernel - 1 GiB of 512 KB: 89 ms
+ * with eight lanes, 221 with sixteen; the list holds 640 now.) */
 #define QZD_SPEC_LANES 4u
 #define QZD_SPEC_LANES_FEW 8u
 #define QZD_SPEC_FEW_SEGS 16384u
@@ -67,7 +67,7 @@
 #define QZD_SPEC_FEWER_SEGS 8192u
 static uint32_t spec_lanes(const qzk_infseg *hs, uint32_t nsegs)
 {
-    uint32_t K = nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 16384u + 64u && hs[0].out_cap <= 262144u + 64u ? QZD_SPEC_LANES_FEWER
+    uint32_t K = nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 16384u + 64u && hs[0].out_cap <= 524288u + 64u ? QZD_SPEC_LANES_FEWER
                : nsegs <= QZD_SPEC_FEW_SEGS ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
     const char *ke = getenv("QATZIP_AMD_INFLATE_K");
     if (ke) { int v = atoi(ke); if (v == 1 || v == 4 || v == 8 || v == 16 || v == 32) K = (uint32_t)v; }

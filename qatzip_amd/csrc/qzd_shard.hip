@@ -27,24 +27,63 @@
 
 typedef struct { uint64_t raw_len, comp_len; uint32_t crc, seq, done, pad; } qzd_shard_rec;    /* 32 bytes */
 
+/* Round 5: the window is several allocations, none of them large.  The eight-rank rehearsal (bench.py --gpus 8 on one GPU)
+ * stood still in hipIpcOpenMemHandle as soon as the one window of world x shard bytes passed 2 GiB (2049 MiB: every rank
+ * but the root never came back; 512 MiB and 1.1 GiB windows had worked) - and BASELINE config 5's window would have been
+ * 8 x 575 MB.  Now: a small CONTROL window (the records) that every rank maps, one SLOT per non-root rank (a shard's
+ * worth, < 600 MB for the largest member a gzip-ext header can describe) that only its rank maps, and the member itself
+ * in plain device memory of the root, put together by device-to-device copies out of the slots when all have arrived
+ * (2 ms for 4.6 GB at the HBM's rate). */
 struct qzd_shard {
     qzd_ctx *ctx;
     uint32_t rank, world;
-    uint64_t cap;                   /* payload capacity of the window */
-    uint8_t *win;                   /* the window, in this process's address space (root: its own allocation) */
+    uint64_t cap;                   /* payload capacity of a member */
+    uint64_t slot_cap;              /* ... and of one rank's slot */
+    uint8_t *win;                   /* the control window, in this process's address space (root: its own allocation) */
+    uint8_t *member;                /* root: [24-byte header | payload cap | 8-byte trailer] */
+    uint8_t **slots;                /* root: world pointers (slot 0 unused: the root's shard goes straight into the member) */
+    uint8_t *myslot;                /* a non-root rank's own slot, mapped */
     bool owner;
 };
 
 #define QZD_SHARD_HDR 24u
 /* two sets of records, used alternately by the streams (seq & 1): ranks run one stream ahead of each other at most - a
  * rank publishes its record for stream n + 1 as soon as its own shard is coded, while the root may still be collecting
- * stream n, but nobody gets past waiting for the root's record of n + 1, which the root writes when n is closed */
+ * stream n, but nobody gets past waiting for the root's record of n + 1, which the root writes when n is closed (its
+ * slots read out) - so a slot is never written while the root still reads it */
 #define QZD_SHARD_SETS 2u
-static size_t win_bytes(uint32_t world, uint64_t cap) { return (size_t)QZD_SHARD_SETS * world * sizeof(qzd_shard_rec) + QZD_SHARD_HDR + cap + 8 + 256; }
-static uint8_t *win_payload(qzd_shard *s) { return s->win + (size_t)QZD_SHARD_SETS * s->world * sizeof(qzd_shard_rec) + QZD_SHARD_HDR; }
+static size_t ctl_bytes(uint32_t world) { return (size_t)QZD_SHARD_SETS * world * sizeof(qzd_shard_rec) + 256; }
 static qzd_shard_rec *win_recs(qzd_shard *s, uint32_t seq) { return (qzd_shard_rec *)s->win + (size_t)(seq & (QZD_SHARD_SETS - 1)) * s->world; }
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+static void shard_free(qzd_shard *s)
+{
+    if (!s) return;
+    if (s->owner) {
+        if (s->win) hipFree(s->win);
+        if (s->member) hipFree(s->member);
+        if (s->slots) { for (uint32_t r = 1; r < s->world; r++) if (s->slots[r]) hipFree(s->slots[r]); free(s->slots); }
+    } else {
+        if (s->win) hipIpcCloseMemHandle(s->win);
+        if (s->myslot) hipIpcCloseMemHandle(s->myslot);
+    }
+    delete s;
+}
+
+static int ipc_handle(qzd_ctx *c, void *p, uint8_t out[64])
+{
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the 64 bytes of the ABI");
+    hipError_t e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        snprintf(c->err, sizeof(c->err), "hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
+        return QZD_ERR_HIP;
+    }
+    memset(out, 0, 64);
+    memcpy(out, &h, sizeof(h));
+    return QZD_OK;
+}
 
 extern "C" int qzd_shard_root_create(qzd_ctx *c, uint32_t world, uint64_t cap_bytes, uint8_t handle_out[64], qzd_shard **out)
 {
@@ -53,22 +92,26 @@ extern "C" int qzd_shard_root_create(qzd_ctx *c, uint32_t world, uint64_t cap_by
     hipSetDevice(c->device);
     qzd_shard *s = new (std::nothrow) qzd_shard();
     if (!s) return QZD_ERR_HIP;
-    s->ctx = c; s->rank = 0; s->world = world; s->cap = cap_bytes; s->owner = true; s->win = NULL;
-    const size_t nb = win_bytes(world, cap_bytes);
-    if (hipMalloc(&s->win, nb) != hipSuccess) { delete s; return QZD_ERR_HIP; }
-    hipMemset(s->win, 0, (size_t)QZD_SHARD_SETS * world * sizeof(qzd_shard_rec) + QZD_SHARD_HDR);
+    s->ctx = c; s->rank = 0; s->world = world; s->cap = cap_bytes; s->slot_cap = (cap_bytes + world - 1) / world;
+    s->owner = true; s->win = NULL; s->member = NULL; s->myslot = NULL;
+    s->slots = (uint8_t **)calloc(world, sizeof(uint8_t *));
+    bool ok = s->slots != NULL && hipMalloc(&s->win, ctl_bytes(world)) == hipSuccess &&
+              hipMalloc(&s->member, QZD_SHARD_HDR + cap_bytes + 8 + 256) == hipSuccess;
+    for (uint32_t r = 1; ok && r < world; r++) ok = hipMalloc(&s->slots[r], s->slot_cap + 256) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); snprintf(c->err, sizeof(c->err), "shard window: device memory for %u slots of %llu bytes", world, (unsigned long long)s->slot_cap); shard_free(s); return QZD_ERR_HIP; }
+    hipMemset(s->win, 0, ctl_bytes(world));
     hipDeviceSynchronize();
-    hipIpcMemHandle_t h;
-    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the 64 bytes of the ABI");
-    hipError_t e = hipIpcGetMemHandle(&h, s->win);
-    if (e != hipSuccess) {
-        snprintf(c->err, sizeof(c->err), "hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
-        hipFree(s->win); delete s; return QZD_ERR_HIP;
-    }
-    memset(handle_out, 0, 64);
-    memcpy(handle_out, &h, sizeof(h));
+    if (ipc_handle(c, s->win, handle_out) != QZD_OK) { shard_free(s); return QZD_ERR_HIP; }
     *out = s;
     return QZD_OK;
+}
+
+/* root: the handle of rank r's slot (1 <= r < world), for that rank's qzd_shard_attach_slot() */
+extern "C" int qzd_shard_slot_handle(qzd_shard *s, uint32_t rank, uint8_t handle_out[64])
+{
+    if (!s || !s->owner || !handle_out || rank == 0 || rank >= s->world) return QZD_ERR_PARAM;
+    hipSetDevice(s->ctx->device);
+    return ipc_handle(s->ctx, s->slots[rank], handle_out);
 }
 
 extern "C" int qzd_shard_attach(qzd_ctx *c, uint32_t rank, uint32_t world, const uint8_t handle[64], uint64_t cap_bytes, qzd_shard **out)
@@ -78,7 +121,8 @@ extern "C" int qzd_shard_attach(qzd_ctx *c, uint32_t rank, uint32_t world, const
     hipSetDevice(c->device);
     qzd_shard *s = new (std::nothrow) qzd_shard();
     if (!s) return QZD_ERR_HIP;
-    s->ctx = c; s->rank = rank; s->world = world; s->cap = cap_bytes; s->owner = false; s->win = NULL;
+    s->ctx = c; s->rank = rank; s->world = world; s->cap = cap_bytes; s->slot_cap = (cap_bytes + world - 1) / world;
+    s->owner = false; s->win = NULL; s->member = NULL; s->slots = NULL; s->myslot = NULL;
     hipIpcMemHandle_t h;
     memcpy(&h, handle, sizeof(h));
     hipError_t e = hipIpcOpenMemHandle((void **)&s->win, h, hipIpcMemLazyEnablePeerAccess);
@@ -90,16 +134,28 @@ extern "C" int qzd_shard_attach(qzd_ctx *c, uint32_t rank, uint32_t world, const
     return QZD_OK;
 }
 
+/* a non-root rank: map its own slot (the handle the root made with qzd_shard_slot_handle for this rank) */
+extern "C" int qzd_shard_attach_slot(qzd_shard *s, const uint8_t handle[64])
+{
+    if (!s || s->owner || !handle || s->myslot) return QZD_ERR_PARAM;
+    hipSetDevice(s->ctx->device);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    hipError_t e = hipIpcOpenMemHandle((void **)&s->myslot, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { s->myslot = NULL; snprintf(s->ctx->err, sizeof(s->ctx->err), "hipIpcOpenMemHandle (slot): %s", hipGetErrorString(e)); return QZD_ERR_HIP; }
+    return QZD_OK;
+}
+
 extern "C" void qzd_shard_close(qzd_shard *s)
 {
     if (!s) return;
     hipSetDevice(s->ctx->device);
     hipDeviceSynchronize();
-    if (s->owner) hipFree(s->win); else hipIpcCloseMemHandle(s->win);
-    delete s;
+    shard_free(s);
 }
 
-/* every rank, the root included: publish my record, find my offset, send my shard.  seq (!= 0) names the stream: the
+/* every rank, the root included: publish my record, wait for the ranks before me (my offset; and the root's record is what
+ * says that the stream before this one has been read out of the slots), send my shard.  seq (!= 0) names the stream: the
  * window is reused for the next one with the next number.  timeout_s bounds every wait. */
 extern "C" int qzd_shard_put(qzd_shard *s, const uint8_t *d_comp, uint64_t comp_len, uint64_t raw_len, uint32_t crc32,
                              uint32_t seq, double timeout_s, uint64_t *h_offset)
@@ -107,6 +163,7 @@ extern "C" int qzd_shard_put(qzd_shard *s, const uint8_t *d_comp, uint64_t comp_
     if (!s || seq == 0 || (comp_len && !d_comp)) return QZD_ERR_PARAM;
     qzd_ctx *c = s->ctx;
     hipSetDevice(c->device);
+    if (s->rank && !s->myslot) { snprintf(c->err, sizeof(c->err), "shard %u: its slot was never attached", s->rank); return QZD_ERR_PARAM; }
     qzd_shard_rec *recs = win_recs(s, seq);
     qzd_shard_rec mine; mine.raw_len = raw_len; mine.comp_len = comp_len; mine.crc = crc32; mine.seq = seq; mine.done = 0; mine.pad = 0;
     HIPCHK(c, hipMemcpy(recs + s->rank, &mine, sizeof(mine), hipMemcpyHostToDevice));
@@ -128,9 +185,10 @@ extern "C" int qzd_shard_put(qzd_shard *s, const uint8_t *d_comp, uint64_t comp_
         for (uint32_t r = 0; r < s->rank; r++) off += h[r].comp_len;
         free(h);
     }
-    if (off + comp_len > s->cap) { snprintf(c->err, sizeof(c->err), "shard window too small"); return QZD_ERR_DSTCAP; }
-    /* the gather: my compressed shard goes where it belongs in the root's HBM (a peer write over xGMI) */
-    if (comp_len) HIPCHK(c, hipMemcpyAsync(win_payload(s) + off, d_comp, comp_len, hipMemcpyDeviceToDevice, c->st[0]));
+    if (off + comp_len > s->cap || (s->rank && comp_len > s->slot_cap)) { snprintf(c->err, sizeof(c->err), "shard window too small"); return QZD_ERR_DSTCAP; }
+    /* the gather: my compressed shard goes to the root's HBM - into my slot (a peer write over xGMI); the root's own
+     * straight to the head of the member */
+    if (comp_len) HIPCHK(c, hipMemcpyAsync(s->rank ? s->myslot : s->member + QZD_SHARD_HDR, d_comp, comp_len, hipMemcpyDeviceToDevice, c->st[0]));
     HIPCHK(c, hipStreamSynchronize(c->st[0]));
     const uint32_t done = seq;
     HIPCHK(c, hipMemcpy((uint8_t *)(recs + s->rank) + offsetof(qzd_shard_rec, done), &done, 4, hipMemcpyHostToDevice));
@@ -138,9 +196,9 @@ extern "C" int qzd_shard_put(qzd_shard *s, const uint8_t *d_comp, uint64_t comp_
     return QZD_OK;
 }
 
-/* root only: wait until every shard has arrived, fold the trailer (crc32_combine in rank order, ISIZE mod 2^32), write
- * the gzip-ext header with both sizes in front of the payload and the trailer behind it.  *d_stream points at the
- * finished member inside the window (valid until the next stream or qzd_shard_close). */
+/* root only: wait until every shard has arrived, put them together (slot r to its offset in the member), fold the trailer
+ * (crc32_combine in rank order, ISIZE mod 2^32), write the gzip-ext header with both sizes in front of the payload and the
+ * trailer behind it.  *d_stream points at the finished member (valid until the next stream or qzd_shard_close). */
 /* the member's 24-byte gzip-ext header with both sizes (src/qatzip_sw.c:61-75,158-166; XFL follows the level as zlib's own
  * gzip header does: 4 = fastest, 2 = best, 0 otherwise) and its trailer */
 static void member_frame(unsigned char hdr[24], unsigned char tr[8], int level, uint64_t raw, uint64_t comp, uint32_t crc)
@@ -172,17 +230,23 @@ extern "C" int qzd_shard_finish(qzd_shard *s, uint32_t seq, double timeout_s, in
         struct timespec ts = {0, 20000}; nanosleep(&ts, NULL);
     }
     uint64_t raw = 0, comp = 0; uint32_t crc = 0;
+    uint8_t *pay = s->member + QZD_SHARD_HDR;
     for (uint32_t r = 0; r < s->world; r++) {
         crc = r == 0 ? h[r].crc : qzd_crc32_combine(crc, h[r].crc, h[r].raw_len);
+        if (r && h[r].comp_len) {
+            if (comp + h[r].comp_len > s->cap || h[r].comp_len > s->slot_cap) { free(h); snprintf(c->err, sizeof(c->err), "shard window too small"); return QZD_ERR_DSTCAP; }
+            hipError_t e = hipMemcpyAsync(pay + comp, s->slots[r], h[r].comp_len, hipMemcpyDeviceToDevice, c->st[0]);
+            if (e != hipSuccess) { free(h); snprintf(c->err, sizeof(c->err), "shard root: slot %u -> member: %s", r, hipGetErrorString(e)); return QZD_ERR_HIP; }
+        }
         raw += h[r].raw_len; comp += h[r].comp_len;
     }
     free(h);
     if (raw > 0xffffffffull || comp > 0xffffffffull) { snprintf(c->err, sizeof(c->err), "a gzip-ext member holds less than 4 GiB"); return QZD_ERR_PARAM; }
     unsigned char hdr[24], tr[8];
     member_frame(hdr, tr, level, raw, comp, crc);
-    uint8_t *pay = win_payload(s);
-    HIPCHK(c, hipMemcpy(pay - QZD_SHARD_HDR, hdr, 24, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(pay + comp, tr, 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpyAsync(pay - QZD_SHARD_HDR, hdr, 24, hipMemcpyHostToDevice, c->st[0]));
+    HIPCHK(c, hipMemcpyAsync(pay + comp, tr, 8, hipMemcpyHostToDevice, c->st[0]));
+    HIPCHK(c, hipStreamSynchronize(c->st[0]));                      /* the slots are free again when this returns */
     *d_stream = pay - QZD_SHARD_HDR; *stream_len = QZD_SHARD_HDR + comp + 8;
     if (crc_out) *crc_out = crc;
     if (raw_total) *raw_total = raw;

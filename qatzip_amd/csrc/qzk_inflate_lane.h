@@ -172,7 +172,11 @@ typedef struct { uint64_t lit_off; uint64_t seq_off; } qzk_tokseg;             /
 #define QZK_INF_ESPEC (-6)         /* speculative phase A could not finish this segment: decode it serially */
 #define QZK_PIECE_RAW 0xffffffffu  /* qzk_chain_el.sub: not a sub-stream but seq_count stored bytes at input offset seq_first */
 typedef struct { uint32_t sub, seq_first, seq_count, lit_first, lrun_skip; } qzk_chain_el;
-#define QZK_CHAIN_MAXEL 160       /* pieces per segment (K per Huffman block of the segment, and per round that continues one) */
+#ifndef QZK_CHAIN_MAXEL
+#define QZK_CHAIN_MAXEL 640       /* pieces per segment (K per Huffman block of the segment, and per round that continues one): a 512 KB
+                                   * segment holds ~20 blocks, sixteen lanes each (round 4: 160 - such segments came back through the
+                                   * serial kernel, 1.5 GB/s); 12.5 KiB of device memory per segment */
+#endif
 typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chain;
 /* scratch a segment needs: literals <= out_cap (+ staging slack), sequences <= out_cap / 3 (+ tail) */
 #define QZK_TOK_LITCAP(out_cap) ((((uint64_t)(out_cap) + 31) & ~(uint64_t)31) + 32)
@@ -1007,7 +1011,7 @@ __device__ unsigned long long qzk_stamp_b[2];
                                     * workgroup leaves with its slowest segment, and segments differ */
 #endif
 #ifndef QZK_RES_OCC
-#define QZK_RES_OCC 6              /* waves per SIMD the register budget is cut for: 75 VGPRs, nothing in scratch (7 -> 4 spilled, 8 -> 12) */
+#define QZK_RES_OCC 8              /* waves per SIMD the register budget is cut for: ~57 VGPRs, nothing in scratch (the segment index is wave-uniform: the records are addressed from scalar registers - 75 VGPRs before) */
 #endif
 
 QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8_t *comp, uint8_t *out, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
@@ -1024,7 +1028,7 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8
     const int lane = qz_lane();
     const uint32_t widx = blockIdx.x * QZK_RES_WAVES + (threadIdx.x >> 6);
     if (widx >= (order ? count : nsegs)) return;
-    const uint32_t sidx = order ? order[widx] : widx;
+    const uint32_t sidx = qz_uniform(order ? order[widx] : widx);  /* wave-uniform: the segment's records are addressed from scalar registers */
     if (sidx >= nsegs) return;
     const qzk_infseg sg = segs[sidx];
     if (res[sidx].status < 0 || (sg.flags & QZK_INF_COUNT_ONLY)) return;

@@ -211,7 +211,8 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
         if (h_mode != 0) { qzk_longtab_load(LR, DR, T, S.lmax, S.dmax); qzk_dsyms_load(&DS, T->dsorted, T->dcount); }
         S.state = QZK_LS_SYM;
         QZK_SPROF(1);                                               /* [1] starts and tables */
-        const uint32_t tag = (epoch << 8) | (round & 255u);      /* a segment takes at most QZK_CHAIN_MAXEL (160) rounds: no two of a launch share a tag */
+        static_assert(QZK_CHAIN_MAXEL < 1024, "a round's tag has ten bits");
+        const uint32_t tag = (epoch << 10) | (round & 1023u);    /* a segment takes at most QZK_CHAIN_MAXEL rounds (each adds a piece): no two of a launch share a tag */
         /* a lane that started beyond the end of the block (the block was shorter than guessed) or that never falls into
          * step decodes garbage: the end of the segment's input stops it; lane 0 is always right */
         const uint32_t give_up = j == 0 ? 0xffffffffu : limit_bits + 64;

@@ -69,6 +69,16 @@ QZ_DEV uint32_t qzk_wave_xxh32(const uint8_t *p, uint32_t n, int lane)
     return h;
 }
 
+/* XXH32 of fewer than sixteen bytes (a frame header's descriptor): no stripes, wave-uniform */
+QZ_DEV uint32_t qzk_xxh32_small(const uint8_t *p, uint32_t n)
+{
+    uint32_t h = QZK_XP5 + n, pos = 0;
+    while (pos + 4 <= n) { h = qzk_rotl(h + qz_ld32(p + pos) * QZK_XP3, 17) * QZK_XP4; pos += 4; }
+    while (pos < n) { h = qzk_rotl(h + p[pos] * QZK_XP5, 11) * QZK_XP1; pos++; }
+    h ^= h >> 15; h *= QZK_XP2; h ^= h >> 13; h *= QZK_XP3; h ^= h >> 16;
+    return h;
+}
+
 /* The same hash for a frame's content (tens of KB): the four accumulator chains stay serial, but their words arrive as
  * whole 16-byte stripes - every lane fetches two of the next 128 while lanes 0-3 work through the 128 before them out of
  * `stage` (2 KiB of LDS, 16-byte aligned), instead of four lanes fetching dwords 16 bytes apart.  Round 5: the decoder got
@@ -418,7 +428,11 @@ QZ_DEV uint32_t qzk_f_load(const uint8_t *in, uint32_t n, uint32_t fb, int lane)
     for (uint32_t t = 0; t < 4; t++) if (o + t < n) v |= (uint32_t)in[o + t] << (8 * t);
     return v;
 }
+#ifdef QZ_SIM
 QZ_DEV uint32_t qzk_alignb(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * sh)); }
+#else
+QZ_DEV uint32_t qzk_alignb(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }     /* one v_alignbyte_b32 (sh = 0..3) */
+#endif
 /* the dword at byte r of the window, r of the lane's own (r + 4 <= 256; every lane takes part) */
 QZ_DEV uint32_t qzk_f_x32(uint32_t F, uint32_t r)
 {
@@ -457,10 +471,10 @@ QZ_DEV uint32_t qzk_lz4_block_f(const uint8_t *in, uint32_t n, uint8_t *out, uin
     const uint32_t matchlimit = be - QZK_LZ4_LASTLIT;
     bool ended = false;
     if (n >= QZK_LZ4_MFLIMIT + 1) {
-        const uint32_t in0 = qz_ld32(in);                           /* what lz4's zero-initialised table points at */
+        const uint32_t in0 = qz_uniform(qz_ld32(in));               /* what lz4's zero-initialised table points at (wave-uniform: a scalar register) */
         uint32_t fb = 0, F = qzk_f_load(in, n, 0, lane);
-#define QZK_L4DEC(e_, cand_, cv_) do { const bool mine_ = (uint32_t)((e_) >> 48) == epoch; \
-            cand_ = mine_ ? (uint32_t)((e_) >> 32) & 0xffffu : 0u; cv_ = mine_ ? (uint32_t)(e_) : in0; } while (0)
+#define QZK_L4DEC(e_, cand_, cv_) do { const uint32_t hi_ = (uint32_t)((e_) >> 32); const bool mine_ = (hi_ >> 16) == epoch; \
+            cand_ = mine_ ? hi_ & 0xffffu : 0u; cv_ = mine_ ? (uint32_t)(e_) : in0; } while (0)
         ip = 1;
         for (;;) {
             /* ---------------- search streak from ip ---------------- */
@@ -472,8 +486,12 @@ QZ_DEV uint32_t qzk_lz4_block_f(const uint8_t *in, uint32_t n, uint8_t *out, uin
             for (;;) {
                 const uint32_t W = j0 == 0 ? QZK_LZ4_W0 : 64u;
                 const bool inw = (uint32_t)lane < W;
-                const uint32_t j = j0 + (uint32_t)lane, t = j ? j - 1 : 0, b = t >> 6, r = t & 63;
-                const uint32_t f = ip + (j ? 1 + 32 * b * (b + 1) + (b + 1) * r : 0), step = j ? (63 + j) >> 6 : 1;
+                uint32_t f, step;
+                if (j0 == 0) { f = ip + (uint32_t)lane; step = 1; }  /* the first 64 probes of a streak are one byte apart */
+                else {
+                    const uint32_t j = j0 + (uint32_t)lane, t = j - 1, b = t >> 6, r = t & 63;
+                    f = ip + 1 + 32 * b * (b + 1) + (b + 1) * r; step = (63 + j) >> 6;
+                }
                 const bool can = (int32_t)(f + step) <= mfl1;        /* else this probe is the `goto _last_literals` */
                 const bool live = inw && can;
                 uint32_t v = 0, h = 0, cand = 0, cv = 0;
@@ -534,8 +552,8 @@ QZ_DEV uint32_t qzk_lz4_block_f(const uint8_t *in, uint32_t n, uint8_t *out, uin
             uint32_t mip = mpos, match = mcand;
             uint32_t cb = match >= 16 ? match - 16 : 0;
             uint32_t C = qzk_f_load(in, n, cb, lane);               /* the candidate's neighbourhood: the sequence's one load */
-            {   /* backward extension: lane i compares the bytes i + 1 back, sixteen at a time out of the two windows */
-                const uint32_t maxb = mip - anchor < match ? mip - anchor : match;
+            const uint32_t maxb = mip - anchor < match ? mip - anchor : match;
+            if (maxb != 0) {   /* backward extension: lane i compares the bytes i + 1 back, sixteen at a time out of the two windows */
                 const uint32_t fhas = mip >= fb && mip <= fb + 256u ? mip - fb : 0u;      /* bytes before mip that F holds */
                 const uint32_t reach = fhas < 16u ? fhas : 16u;                          /* (C holds sixteen, or all there is) */
                 const uint32_t lim = maxb < reach ? maxb : reach;
@@ -567,11 +585,14 @@ QZ_DEV uint32_t qzk_lz4_block_f(const uint8_t *in, uint32_t n, uint8_t *out, uin
             uint32_t tok;
             if (lit >= 15) { tok = 15u << 4; qzk_l4o_len(&O, lit - 15, lane); } else tok = lit << 4;
             if (lit != 0 && lit <= QZK_L4C_LITMAX && anchor >= fb && mip <= fb + 256) {
-                /* literals out of the window: lane i's dword holds the literals 4i - a0 .. 4i - a0 + 3 */
+                /* literals out of the window (lane i holds the window's bytes 4i .. 4i + 3) */
                 const uint32_t a0 = anchor - fb;
                 uint8_t *d = O.st + QZK_L4O_IDX(&O, O.op);
-#pragma unroll
-                for (uint32_t t = 0; t < 4; t++) { const uint32_t k = 4u * (uint32_t)lane + t - a0; if (k < lit) d[k] = (uint8_t)(F >> (8 * t)); }
+                for (uint32_t k0 = 0; k0 < lit; k0 += 64) {         /* literal k = byte a0 + k of the window: lane k fetches it from its owner */
+                    const uint32_t k = k0 + (uint32_t)lane, r = a0 + k;
+                    const uint32_t w = qz_shfl(F, (int)((r >> 2) & 63u));
+                    if (k < lit) d[k] = (uint8_t)(w >> (8 * (r & 3u)));
+                }
                 O.op += lit;
             } else if (lit != 0) {
                 qzk_l4o_all(&O, lane);                              /* token and length bytes first, then the run memory to memory */
@@ -719,7 +740,7 @@ QZ_KERNEL_MAX(64) qzk_lz4c_kernel(const uint8_t *src, uint64_t src_len, uint32_t
  * trip to the L2 per lookup is paid back several times by the waves that now fit. */
 #define QZK_L4C_TABW QZK_LZ4_HASHSZ          /* 8-byte entries per wave: 64 KiB of device memory */
 #ifndef QZK_L4C_OCC
-#define QZK_L4C_OCC 6            /* waves per SIMD the register budget is cut for: 80 VGPRs, nothing in scratch (7: 3 spilled, 8: 11) */
+#define QZK_L4C_OCC 7            /* waves per SIMD the register budget is cut for (measured, ms per GiB: 6 - 80 VGPRs, no scratch - 44.3; 7 - 3 spilled - 42.1; 8 - 11 spilled - 41.6..42.6) */
 #endif
 QZ_KERNEL_OCC(64, QZK_L4C_OCC) qzk_lz4c_pull_kernel(const uint8_t *src, uint64_t src_len, uint32_t frame_sz, uint32_t nframes,
                           uint8_t *slots, uint32_t stride, uint32_t *out_len, uint32_t hw_hdr, uint64_t *tables, uint32_t *epochs, uint32_t *counter)
@@ -753,7 +774,7 @@ QZ_KERNEL_OCC(64, QZK_L4C_OCC) qzk_lz4c_pull_kernel(const uint8_t *src, uint64_t
         qz_wave_sync();
         uint32_t pos = (n || hw_hdr) ? 14 : 6;
         {
-            const uint32_t hc = qzk_wave_xxh32(o + 4, pos - 4, lane);
+            const uint32_t hc = qzk_xxh32_small(o + 4, pos - 4);        /* 2 or 10 bytes */
             if (lane == 0) o[pos] = (uint8_t)(hc >> 8);
             pos++;
         }
@@ -773,7 +794,13 @@ QZ_KERNEL_OCC(64, QZK_L4C_OCC) qzk_lz4c_pull_kernel(const uint8_t *src, uint64_t
         out_len[fr] = pos + 8;          /* wave-uniform: every lane stores the same word */
         qz_wave_sync();
     }
-    if (lane == 0) epochs[blockIdx.x] = ep;
+    {   /* (the address is made again here, from scalar registers: kept alive across the loop it cost two VGPRs their place) */
+        uint32_t *e2 = epochs;
+#ifndef QZ_SIM
+        asm volatile("" : "+s"(e2));
+#endif
+        if (lane == 0) e2[blockIdx.x] = ep;
+    }
 }
 
 /* K4 for one call above 64 KB: the frame LZ4F_compressFrame writes for it (src/qatzip_sw.c:451-456) - FLG 0x4C (blocks

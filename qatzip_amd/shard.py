@@ -4,6 +4,7 @@ the shard) from which every rank derives its output offset and rank 0 folds the 
 compressed shards into rank 0's HBM (OneStream: IPC window or RCCL).  The host arithmetic is covered on CPU by
 tests/test_dist_gloo.py; checking a member against the oracle is the callers' business (tests/, bench.py) - nothing in
 this package loads the oracle."""
+import os
 import struct
 
 
@@ -164,8 +165,24 @@ class OneStream:
         self.cap = world * (_lib.max_deflate_len(shard_bytes, chunk) + 64)
         # the transport has a context of its own (its own streams): run_members() keeps a gather on the wire while the next
         # member is being deflated on ctx
-        self.tctx = tctx = _lib.Context(ctx.device)
         err = None
+        self.tctx = tctx = None
+        trace = os.environ.get("QATZIP_AMD_BENCH_TRACE")
+
+        def step(what):
+            if trace:
+                import sys
+                import time
+                print("[OneStream %s, rank %d, t=%.1f] %s" % (transport, rank, time.time() % 1000, what), file=sys.stderr, flush=True)
+        step("transport context")
+        try:
+            self.tctx = tctx = _lib.Context(ctx.device)
+        except Exception as e:   # noqa: BLE001 - a rank that cannot get its context must not leave the others in the broadcast below
+            err = "transport context: " + str(e)[:150]
+        if not _all_ok(pg, err is None):
+            self.error = err or "another rank could not make its transport context"
+            self.close()
+            return
         if transport == "rccl":
             idb = C.create_string_buffer(128)
             if rank == 0 and L.qzd_rccl_unique_id(idb) != 0:
@@ -178,16 +195,43 @@ class OneStream:
                 err = "rccl init: " + L.qzd_last_error(tctx.h).decode()
         else:
             hbuf = C.create_string_buffer(64)
+            step("window of %d MiB" % (self.cap >> 20))
             if rank == 0 and L.qzd_shard_root_create(tctx.h, world, self.cap, hbuf, C.byref(self.h)) != 0:
                 err = "root window: " + L.qzd_last_error(tctx.h).decode()
+            step("handle broadcast")
             handle = broadcast_bytes(pg, hbuf.raw if rank == 0 else None, 64, 0) if world > 1 else hbuf.raw
+            step("attach")
             if rank != 0 and err is None and L.qzd_shard_attach(tctx.h, rank, world, handle, self.cap, C.byref(self.h)) != 0:
                 err = "attach: " + L.qzd_last_error(tctx.h).decode()
+            step("attached")
+            if world > 1:
+                # one slot per non-root rank (qzd_shard.hip: no allocation of the window is large - a window above 2 GiB never
+                # came back from hipIpcOpenMemHandle); the root's handles travel as one blob, every rank maps its own
+                blob = None
+                if rank == 0:
+                    blob = bytearray(64 * world)
+                    if err is None:
+                        for r in range(1, world):
+                            hb = C.create_string_buffer(64)
+                            if L.qzd_shard_slot_handle(self.h, r, hb) != 0:
+                                err = "slot handle %d: %s" % (r, L.qzd_last_error(tctx.h).decode()); break
+                            blob[64 * r:64 * r + 64] = hb.raw
+                    blob = bytes(blob)
+                blob = broadcast_bytes(pg, blob, 64 * world, 0)
+                if rank != 0 and err is None and L.qzd_shard_attach_slot(self.h, blob[64 * rank:64 * rank + 64]) != 0:
+                    err = "attach slot: " + L.qzd_last_error(tctx.h).decode()
+                step("slot attached")
         if not _all_ok(pg, err is None):
             self.error = err or "another rank could not set the %s transport up" % transport
             self.close()
             return
-        self.d_comp = ctx.alloc(_lib.max_deflate_len(shard_bytes, chunk))
+        try:
+            self.d_comp = ctx.alloc(_lib.max_deflate_len(shard_bytes, chunk))
+        except Exception as e:   # noqa: BLE001
+            err = "staging buffer: " + str(e)[:150]
+        if not _all_ok(pg, err is None):
+            self.error = err or "another rank could not allocate its staging buffer"
+            self.close()
 
     def run(self, d_src, want_member=False):
         """one member.  Rank 0 gets {"raw_bytes", "member_bytes", "ms", "deflate_ms", "gather_ms", "crc32", ("stream")};
