@@ -244,6 +244,21 @@ def cpu_baseline(shard_mb: int, base_mb: int, max_workers: int):
     import datagen
     cpus, model = host_cpu()
     nw = max(1, min(len(cpus), max_workers))
+    # a container's CFS quota is what the box really gives: 128 physical cores were visible on the MI355X box, cpu.max said
+    # "1600000 100000" = 16 CPUs, and the summed rate stood still from 16 workers on (gpurun_out/r5l_cpu.log: 8 / 16 / 32 / 64 / 128
+    # pinned workers 1.9 / 3.5 / 3.6 / 3.0 / 3.3 GB/s) - more workers than that only measure the scheduler's throttling
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        nw = max(1, min(nw, int(quota)))
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     path = os.path.join(shm, "qatzip_amd_bench_%d.bin" % os.getpid())
     datagen.gen("silesia", max(base_mb, shard_mb + 16) << 20, 20250523).tofile(path)
@@ -301,7 +316,9 @@ def cpu_baseline(shard_mb: int, base_mb: int, max_workers: int):
     res = {"value": head["value"], "unit": "GB/s", "cores": head["workers"], "kind": "libz" if pinned else "port",
            "compress": head["compress"], "decompress": head["decompress"], "spread": head["spread"], "passes": head["passes"],
            "one_worker": (libz1 if pinned else port1), "cpu_model": model, "physical_cores": len(cpus),
-           "sample": "%d worker process(es), each pinned to one physical core, x %d MiB contiguous shards of the same buffer, "
+           "cgroup_cpu_quota": quota,
+           "sample": ("the container's CFS quota is %.0f CPUs of the %d physical cores: " % (quota, len(cpus)) if quota is not None and quota < len(cpus) else "") +
+                     "%d worker process(es), each pinned to one physical core, x %d MiB contiguous shards of the same buffer, "
                      "GZIP_EXT L1 64 KB chunks, compress + decompress, three passes started together, median pass of the "
                      "summed per-worker rates (%.0f s of CPU work in all)" % (len(many), many[0]["n"] >> 20, cpu_s),
            "ratio": round(sum(r.get("clen", 0) for r in many) / max(1, sum(r["n"] for r in many if "clen" in r)), 4),
@@ -315,8 +332,9 @@ def cpu_baseline(shard_mb: int, base_mb: int, max_workers: int):
 
 
 # ------------------------------------------------------------------ extra legs (outside the timed region)
-def api_leg(base, tile, mb):
-    """qzCompress / qzDecompress themselves, host to host on qzMalloc(PINNED_MEM) buffers: PCIe both ways included"""
+def api_leg(base, tile, mb, timed=3):
+    """qzCompress / qzDecompress themselves, host to host on qzMalloc(PINNED_MEM) buffers: PCIe both ways included.  One pass
+    that sizes the session's buffers, then `timed` passes: the median of each direction"""
     import ctypes as C
     from qatzip_amd import api as A
     n = mb << 20
@@ -331,7 +349,8 @@ def api_leg(base, tile, mb):
         hsrc[off:off + k] = base[:k]
     res = {}
     comp_len = 0
-    for it in range(2):                                            # first pass sizes the session's buffers
+    tcs, tds = [], []
+    for it in range(1 + timed):                                    # first pass sizes the session's buffers
         sl, dl = C.c_uint(n), C.c_uint(cap)
         t0 = time.perf_counter()
         rc = L.qzCompress(C.byref(s.s), C.cast(p_src, C.c_char_p), C.byref(sl), p_dst, C.byref(dl), 1)
@@ -343,11 +362,15 @@ def api_leg(base, tile, mb):
         rc = L.qzDecompress(C.byref(s.s), C.cast(p_dst, C.c_char_p), C.byref(sl2), p_back, C.byref(dl2))
         td = time.perf_counter() - t0
         assert rc == 0 and dl2.value == n, rc
+        if it:
+            tcs.append(tc); tds.append(td)
+    tc, td = sorted(tcs)[len(tcs) // 2], sorted(tds)[len(tds) // 2]
     back = np.ctypeslib.as_array((C.c_ubyte * n).from_address(p_back))
     assert np.array_equal(back[:1 << 20], hsrc[:1 << 20]) and np.array_equal(back[-(1 << 20):], hsrc[-(1 << 20):])
     res = {"api_bytes_MiB": mb, "api_compress_GBps": round(n / tc / 1e9, 3), "api_decompress_GBps": round(n / td / 1e9, 3),
+           "api_decompress_ms": [round(t * 1e3, 2) for t in tds],
            "api_pinned": int(L.qzMemFindAddr(p_src + 12345)), "api_note": "one qzCompress + one qzDecompress call, host to host, "
-           "qzMalloc(PINNED_MEM) source and destination, PCIe included"}
+           "qzMalloc(PINNED_MEM) source and destination, PCIe included; the median of %d passes each" % timed}
     for p in (p_src, p_dst, p_back):
         L.qzFree(p)
     s.close()

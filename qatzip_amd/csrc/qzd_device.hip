@@ -154,7 +154,36 @@ extern "C" int qzd_device_count(void)
     return n;
 }
 
-extern "C" int qzd_create(int device, qzd_ctx **out)
+/* A stream with a HARDWARE QUEUE OF ITS OWN.  The runtime seats ordinary streams on a pool of four hardware queues (per
+ * priority), whichever has the fewest users; the packets of a queue go in order, so two streams that share one run their
+ * kernels and copies one behind the other.  Which streams share depends on what the process created before: the pieces of
+ * qzd_inflate_stream_from_host took 50.3 ms or 61.5 for the same 2 GiB member - a helper's marker scan waited behind all
+ * 14 ms of the copy in, or behind its sibling's phase A (profiles/r5_api_decompress_pieces.txt).  A stream created with a
+ * CU mask is never pooled; the mask here names every CU.  (Such a stream is a blocking one: this library puts nothing on
+ * the null stream while the streams made here are busy.)  Falls back to a stream of the highest priority, then to an
+ * ordinary one. */
+static hipError_t stream_own_queue(hipStream_t *st, int device)
+{
+    hipDeviceProp_t prop;
+    if (!getenv("QATZIP_AMD_POOLED_STREAMS") && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+        uint32_t mask[32];
+        const uint32_t cus = (uint32_t)std::min(prop.multiProcessorCount, 1024), words = (cus + 31) / 32;
+        for (uint32_t w = 0; w < words; w++) mask[w] = w + 1 < words || (cus & 31u) == 0 ? 0xffffffffu : (1u << (cus & 31u)) - 1u;
+        if (hipExtStreamCreateWithCUMask(st, words, mask) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+    }
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    if (hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+static int ctx_create(int device, qzd_ctx **out, bool helper);
+extern "C" int qzd_create(int device, qzd_ctx **out) { return ctx_create(device, out, false); }
+/* the context of a helper thread (a piece of qzd_inflate_stream_from_host): it launches on st[0] and nowhere else, and every
+ * stream it does not create is one fewer on the hardware queues its siblings' kernels go through */
+int qzd_create_helper(int device, qzd_ctx **out) { return ctx_create(device, out, true); }
+static int ctx_create(int device, qzd_ctx **out, bool helper)
 {
     if (!out) return QZD_ERR_PARAM;
     *out = NULL;
@@ -162,16 +191,18 @@ extern "C" int qzd_create(int device, qzd_ctx **out)
     qzd_ctx *c = new (std::nothrow) qzd_ctx();
     if (!c) return QZD_ERR_HIP;
     memset(c, 0, sizeof(*c));
-    c->device = device;
+    c->device = device; c->helper = helper;
 #define QZD_CREATE_FAIL do { qzd_destroy(c); return QZD_ERR_HIP; } while (0)   /* no half-built context leaks */
     for (int i = 0; i < QZD_NBUF; i++) {
-        if (hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking) != hipSuccess) QZD_CREATE_FAIL;
+        if (helper && i > 0) c->st[i] = c->st[0];
+        else if ((helper ? stream_own_queue(&c->st[i], device) : hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking)) != hipSuccess) QZD_CREATE_FAIL;
         hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->k1done[i], hipEventDisableTiming);
         for (int k = 0; k < 4; k++) hipEventCreate(&c->ev[i][k]);
     }
     hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
-    if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess) QZD_CREATE_FAIL;
+    if (helper) c->st_copy = c->st_out = c->st[0];
+    else if (stream_own_queue(&c->st_copy, device) != hipSuccess || stream_own_queue(&c->st_out, device) != hipSuccess) QZD_CREATE_FAIL;
     for (int i = 0; i < QZD_NBUF + 1; i++) hipEventCreateWithFlags(&c->cp_ev[i], hipEventDisableTiming);
     for (int i = 0; i < 8; i++) hipEventCreateWithFlags(&c->so_ev[i], hipEventDisableTiming);
     c->so_host = NULL; c->so_nat = NULL; c->so_sent = 0;
@@ -210,12 +241,13 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     for (int i = 0; i < QZD_NBUF; i++) {
         hipFree(c->slots[i]);
         /* handles may be missing: qzd_create comes here from its failure paths */
-        if (c->st[i]) hipStreamDestroy(c->st[i]);
+        if (c->st[i] && !(c->helper && i > 0)) hipStreamDestroy(c->st[i]);
         if (c->done[i]) hipEventDestroy(c->done[i]);
         if (c->k1done[i]) hipEventDestroy(c->k1done[i]);
         if (i == 0) {
             for (int k = 0; k < 8; k++) if (c->so_ev[k]) hipEventDestroy(c->so_ev[k]);
-            if (c->st_copy) hipStreamDestroy(c->st_copy);
+            if (c->st_copy && !c->helper) hipStreamDestroy(c->st_copy);
+            if (c->st_out && !c->helper) hipStreamDestroy(c->st_out);
             for (int k = 0; k < QZD_NBUF + 1; k++) if (c->cp_ev[k]) hipEventDestroy(c->cp_ev[k]);
         }
         for (int k = 0; k < 4; k++) if (c->ev[i][k]) hipEventDestroy(c->ev[i][k]);
@@ -951,7 +983,8 @@ extern "C" int qzd_sync(qzd_ctx *c)
     if (!c) return QZD_ERR_PARAM;
     hipSetDevice(c->device);
     const hipError_t e0 = hipStreamSynchronize(c->st[0]), e1 = hipStreamSynchronize(c->st[1]), e2 = hipStreamSynchronize(c->st_copy);
-    HIPCHK(c, e0); HIPCHK(c, e1); HIPCHK(c, e2);
+    const hipError_t e3 = hipStreamSynchronize(c->st_out);
+    HIPCHK(c, e0); HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
     for (uint32_t k = 0; k < c->k1ev_n; k++) {      /* harvest the K1 launch timings of the call that just finished */
         float t = 0;
         if (hipEventElapsedTime(&t, c->k1ev[k][0], c->k1ev[k][1]) == hipSuccess) {

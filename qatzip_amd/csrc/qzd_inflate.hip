@@ -33,6 +33,7 @@
 #include <mutex>
 #include <thread>
 #include <string.h>
+#include <string>
 #include <vector>
 
 #include "qzd_internal.h"
@@ -63,12 +64,13 @@
 #define QZD_SPEC_LANES 4u
 #define QZD_SPEC_LANES_FEW 8u
 #define QZD_SPEC_FEW_SEGS 16384u
+#define QZD_SPEC_FEW_SEGS_BIG 32768u    /* segments above 16 KB (round 5, 2 GiB of 64 KB: 12.5 ms with four lanes, 11.0 with eight; 65536 segments: the same either way) */
 #define QZD_SPEC_LANES_FEWER 16u
 #define QZD_SPEC_FEWER_SEGS 8192u
 static uint32_t spec_lanes(const qzk_infseg *hs, uint32_t nsegs)
 {
     uint32_t K = nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 16384u + 64u && hs[0].out_cap <= 524288u + 64u ? QZD_SPEC_LANES_FEWER
-               : nsegs <= QZD_SPEC_FEW_SEGS ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
+               : nsegs <= (hs[0].out_cap > 16384u + 64u ? QZD_SPEC_FEW_SEGS_BIG : QZD_SPEC_FEW_SEGS) ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
     const char *ke = getenv("QATZIP_AMD_INFLATE_K");
     if (ke) { int v = atoi(ke); if (v == 1 || v == 4 || v == 8 || v == 16 || v == 32) K = (uint32_t)v; }
     /* it needs a compressed-length hint (qzk_infseg.pad) and segments that write output and begin with no history */
@@ -249,7 +251,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         HIPCHK(c, hipStreamSynchronize(st));
         uint32_t nredo = 0;
         for (uint32_t i = 0; i < nsegs; i++) if (st_res[i].status == QZK_INF_ESPEC) st_ord[nredo++] = i;
-        if (getenv("QATZIP_AMD_TRACE")) {
+        if (nredo && getenv("QATZIP_AMD_TRACE")) {
             uint32_t hist[64] = {0};
             for (uint32_t i = 0; i < nredo; i++) { const uint32_t w = st_res[st_ord[i]].nblocks; hist[w < 64 ? w : 63]++; }
             fprintf(stderr, "[two_phase] K=%u: %u of %u segments handed back to the serial kernel; reasons:", K, nredo, nsegs);
@@ -301,10 +303,10 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         }
         HIPCHK(c, hipEventRecord(c->ev[1][2], st));
         for (uint32_t p = 0; p < parts; p++) {       /* a pageable destination makes these block the host: all launches are out already */
-            HIPCHK(c, hipStreamWaitEvent(c->st[1], c->so_ev[p], 0));
-            HIPCHK(c, hipMemcpyAsync(c->so_host + off[p], d_out + off[p], off[p + 1] - off[p], hipMemcpyDeviceToHost, c->st[1]));
+            HIPCHK(c, hipStreamWaitEvent(c->st_out, c->so_ev[p], 0));
+            HIPCHK(c, hipMemcpyAsync(c->so_host + off[p], d_out + off[p], off[p + 1] - off[p], hipMemcpyDeviceToHost, c->st_out));
         }
-        HIPCHK(c, hipStreamSynchronize(c->st[1]));
+        HIPCHK(c, hipStreamSynchronize(c->st_out));
         c->so_sent = off[parts];
     }
     HIPCHK(c, ctl_copy(st_res, d_res, rb, st));
@@ -324,7 +326,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
 static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qzk_infseg *hs, uint32_t nsegs,
                              const uint32_t *h_order, uint32_t count, qzk_infres *h_res, uint8_t *h_dst, hipStream_t st, hipStream_t out_st = NULL)
 {
-    if (!out_st) out_st = c->st[1];
+    if (!out_st) out_st = c->st_out;
     if (nsegs != c->tp.nsegs || count == 0) return QZD_ERR_PARAM;
     const uint32_t K = c->tp.K;                                      /* sub-streams per segment of the phase A that ran */
     qzk_infseg *d_segs = (qzk_infseg *)c->tp.segs; qzk_infres *d_res = (qzk_infres *)c->tp.res;
@@ -771,8 +773,16 @@ after_lanes:
  * as a piece's last candidate), an error status, a destination too small - abandons the pieces: the input is all on the
  * device by then, and the call goes through inflate_stream() as before, which reports what is wrong. */
 #define QZD_PIPE_MAX 8u
-#define QZD_PIPE_PIECES 2u                /* see profiles/r4_api_decompress.txt: more pieces lose to each other on the chip */
-#define QZD_PIPE_MIN_BYTES (12u << 20)     /* compressed bytes a piece holds at least (~32 MiB of output, 512 segments) */
+/* The pieces GROW: the output cannot leave before the first piece has been through both phases, and a launch of phase A
+ * lasts as long as its slowest segment however few there are (3.8 ms for 16 MiB or 64) - so the first piece is small, 3 % of
+ * the member, and every later one is as much larger as the link needs to stay busy: piece p + 1 must be decoded when piece
+ * p has left.  Round 5 (profiles/r5_api_decompress_pieces.txt, 2047 MiB): two pieces cut at a third 53.5 ms, four equal ones
+ * 50.1, six cut at 3 / 8 / 17 / 33 / 60 % 47.3 = 45.3 GB/s, 0.80 of the link.  (Rounds 4's finding that more pieces lose was
+ * made with helpers that shared hardware queues: see stream_own_queue in qzd_device.hip.) */
+#define QZD_PIPE_FIRST_PCT 3u              /* the first piece, percent of the member ... */
+#define QZD_PIPE_MIN_BYTES (12u << 20)     /* ... but this many compressed bytes at least (~32 MiB of output, 512 segments) */
+#define QZD_PIPE_GROW_NUM 9u               /* every piece 1.8 times the one before */
+#define QZD_PIPE_GROW_DEN 5u
 struct qzd_pipe {
     std::mutex m; std::condition_variable cv;
     uint32_t P;
@@ -781,8 +791,11 @@ struct qzd_pipe {
     bool cand_ok[QZD_PIPE_MAX]; uint32_t lastc[QZD_PIPE_MAX];       /* the last candidate at or before the piece's end */
     bool chain_ok[QZD_PIPE_MAX]; uint32_t nxt[QZD_PIPE_MAX]; uint64_t oo[QZD_PIPE_MAX];   /* the chain after the piece */
     bool final_seen; uint64_t total_in, total_out;
+    uint32_t crc[QZD_PIPE_MAX]; uint64_t crc_len[QZD_PIPE_MAX]; bool want_crc;      /* CRC-32 of every piece's output, taken while later pieces are still on their way out */
     bool failed;
     std::chrono::steady_clock::time_point t0;
+    std::vector<std::string> log;           /* QATZIP_AMD_TRACE: the pieces' steps, printed when the call is over (printing them
+                                             * as they happen moved the helpers' launches: 61.6 ms without the trace, 50.8 with) */
 };
 
 static void pipe_fail(qzd_pipe *S, uint32_t p)
@@ -809,8 +822,12 @@ static void pipe_piece_body(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, con
     hipSetDevice(H->device);
     static const bool trace = getenv("QATZIP_AMD_TRACE") != NULL;   /* developer aid: when each step of each piece was over */
     auto lap = [&](const char *what) {
-        if (trace) fprintf(stderr, "[pipe] piece %u %-18s at %8.3f ms\n", p, what,
-                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S->t0).count());
+        if (!trace) return;
+        char line[160];
+        snprintf(line, sizeof(line), "[pipe] piece %u %-18s at %8.3f ms", p, what,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S->t0).count());
+        std::lock_guard<std::mutex> g(S->m);
+        S->log.push_back(line);
     };
     hipStream_t st = H->st[0];
     const bool last = p + 1 == S->P;
@@ -871,6 +888,7 @@ static void pipe_piece_body(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, con
         if (S->failed) { g.unlock(); pipe_fail(S, p); return; }
     }
     bool ok = true; uint64_t t_in = 0;
+    const uint64_t oo0 = oo;                                        /* where my output begins */
     if (!fin) {
         uint32_t k = 0;
         while (k < start.size() && start[k] < want) k++;
@@ -909,11 +927,25 @@ static void pipe_piece_body(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, con
         H->inf_ms[3] = 0;
     }
     for (uint32_t i = 0; i < ns; i++) ps[i].flags = ps[i].flags == 0x80000000u ? 0 : QZK_INF_COUNT_ONLY;
-    if (two_phase_resolve(H, d_src, d_dst, ps.data(), ns, chain.data(), (uint32_t)chain.size(), pr.data(), h_dst, st, c->st[1]) != QZD_OK) { pipe_fail(S, p); return; }
+    if (two_phase_resolve(H, d_src, d_dst, ps.data(), ns, chain.data(), (uint32_t)chain.size(), pr.data(), h_dst, st, c->st_out) != QZD_OK) { pipe_fail(S, p); return; }
     for (uint32_t i : chain) if (pr[i].status < 0) { pipe_fail(S, p); return; }
-    if (trace) fprintf(stderr, "[pipe] piece %u phase B kernels %.3f ms, %u segments\n", p, H->inf_ms[2], (uint32_t)chain.size());
+    if (trace) {
+        char line[160];
+        snprintf(line, sizeof(line), "[pipe] piece %u phase B kernels %.3f ms, %u segments", p, H->inf_ms[2], (uint32_t)chain.size());
+        std::lock_guard<std::mutex> g(S->m);
+        S->log.push_back(line);
+    }
     { std::lock_guard<std::mutex> g(S->m); c->inf_ms[2] += H->inf_ms[2]; c->inf_ms[0] += H->inf_ms[2]; }
     lap("phase B, sent");
+    if (S->want_crc && oo > oo0) {
+        /* my output's CRC-32 (the caller combines the pieces'): one pass over 2 GiB after the last piece had left cost the call
+         * 0.7 ms with the link idle; this way only the last piece's share of it is left */
+        uint32_t crc = 0;
+        if (qzd_crc32(H, d_dst + oo0, oo - oo0, &crc) != QZD_OK) { pipe_fail(S, p); return; }
+        std::lock_guard<std::mutex> g(S->m);
+        S->crc[p] = crc; S->crc_len[p] = oo - oo0;
+        c->inf_ms[1] += H->inf_ms[1]; H->inf_ms[1] = 0;
+    }
 }
 
 /* d_src: where the n bytes at h_src are to stand on the device (they are all there when this returns, whatever it
@@ -926,14 +958,29 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
     if (n == 0 || n > 0xffffffffull) return QZD_ERR_PARAM;
     hipSetDevice(c->device);
     *h_sent = 0;
-    uint32_t P = (uint32_t)std::min<uint64_t>(QZD_PIPE_PIECES, n / QZD_PIPE_MIN_BYTES);
-    const char *pe = getenv("QATZIP_AMD_PIPE");                     /* pieces (0 / 1: the whole member at once) */
-    if (pe) P = (uint32_t)std::min<int>(QZD_PIPE_MAX, std::max(0, atoi(pe)));
+    /* the plan: cut[0] = 0 < cut[1] < ... < cut[P] = n */
+    uint64_t cut[QZD_PIPE_MAX + 1];
+    uint32_t P = 0;
+    {
+        uint64_t len = std::max<uint64_t>(n * QZD_PIPE_FIRST_PCT / 100, QZD_PIPE_MIN_BYTES), at = 0;
+        cut[0] = 0;
+        while (P + 1 < QZD_PIPE_MAX && at + len + len / 2 < n) {    /* (a last piece smaller than half its predecessor joins it) */
+            at = (at + len) & ~(uint64_t)4095; cut[++P] = at;
+            len = len * QZD_PIPE_GROW_NUM / QZD_PIPE_GROW_DEN;
+        }
+        cut[++P] = n;
+    }
+    const char *pe = getenv("QATZIP_AMD_PIPE");                     /* pieces (0 / 1: the whole member at once); equal ones unless QATZIP_AMD_PIPE_CUTS says where */
+    if (pe) {
+        P = (uint32_t)std::min<int>(QZD_PIPE_MAX, std::max(0, atoi(pe)));
+        for (uint32_t p = 0; p <= P; p++) cut[p] = p == P ? n : (n * p / P) & ~(uint64_t)4095;
+    }
     if (!seg_hint) P = 0;
     for (uint32_t p = 0; p < P; p++) {
-        if (!c->pipe_ctx[p] && qzd_create(c->device, &c->pipe_ctx[p]) != QZD_OK) { P = p; break; }
+        if (!c->pipe_ctx[p] && qzd_create_helper(c->device, &c->pipe_ctx[p]) != QZD_OK) { P = p; break; }
         if (!c->pipe_ev[p] && hipEventCreateWithFlags(&c->pipe_ev[p], hipEventDisableTiming) != hipSuccess) { P = p; break; }
     }
+    if (P >= 2) cut[P] = n;                                         /* (fewer helpers than planned: the last one takes the rest) */
     if (P < 2) {
         HIPCHK(c, hipMemcpy(d_src, h_src, n, hipMemcpyHostToDevice));
         return inflate_stream(c, d_src, n, d_dst, dst_cap, seg_hint, h_in_used, h_out_len, h_crc, h_dst, h_sent);
@@ -942,13 +989,8 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
     qzd_pipe S;
     S.t0 = std::chrono::steady_clock::now();
     S.P = P; S.final_seen = false; S.failed = false; S.total_in = S.total_out = 0;
-    for (uint32_t p = 0; p < QZD_PIPE_MAX; p++) { S.issued[p] = S.cand_ok[p] = S.chain_ok[p] = false; S.lastc[p] = S.nxt[p] = 0; S.oo[p] = 0; }
-    uint64_t cut[QZD_PIPE_MAX + 1];
-    /* the first two pieces half as large as the others: the output cannot leave before the first piece's phases are over */
-    /* two pieces: a third of the member, then the rest (more: the first two half as large as the others) - the output
-     * cannot leave before the first piece's phases are over, and the second piece's phase A hides behind the first one's way out */
-    for (uint32_t p = 0; p <= P; p++)
-        cut[p] = p == P ? n : p == 0 ? 0 : P == 2 ? (n / 3) & ~(uint64_t)4095 : (n * (2 * p - (p >= 2 ? 2 : 1)) / (2 * P - 2)) & ~(uint64_t)4095;
+    for (uint32_t p = 0; p < QZD_PIPE_MAX; p++) { S.issued[p] = S.cand_ok[p] = S.chain_ok[p] = false; S.lastc[p] = S.nxt[p] = 0; S.oo[p] = 0; S.crc[p] = 0; S.crc_len[p] = 0; }
+    S.want_crc = h_crc != NULL;
     if (const char *ce = getenv("QATZIP_AMD_PIPE_CUTS")) {          /* developer aid: the pieces' boundaries in percent, "10,40" */
         uint32_t k = 1;
         for (const char *q = ce; *q && k < P; k++) { cut[k] = (n * (uint64_t)std::min(100, std::max(0, atoi(q))) / 100) & ~(uint64_t)4095; while (*q && *q != ',') q++; if (*q) q++; }
@@ -979,6 +1021,7 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
     }
     landed(P - 1);
     for (auto &t : th) t.join();
+    for (const std::string &l : S.log) fprintf(stderr, "%s\n", l.c_str());
     HIPCHK(c, hipStreamSynchronize(c->st_copy));
     if (!copy_ok) {
         snprintf(c->err, sizeof(c->err), "host-to-device copy of a piece failed");
@@ -989,7 +1032,13 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
         return inflate_stream(c, d_src, n, d_dst, dst_cap, seg_hint, h_in_used, h_out_len, h_crc, h_dst, h_sent);
     }
     *h_in_used = S.total_in; *h_out_len = S.total_out; *h_sent = 1;
-    if (h_crc) return qzd_crc32(c, d_dst, S.total_out, h_crc);
+    if (h_crc) {
+        uint32_t crc = 0; uint64_t have = 0;
+        for (uint32_t p = 0; p < P; p++)
+            if (S.crc_len[p]) { crc = have ? qzd_crc32_combine(crc, S.crc[p], S.crc_len[p]) : S.crc[p]; have += S.crc_len[p]; }
+        if (have != S.total_out) return qzd_crc32(c, d_dst, S.total_out, h_crc);     /* (cannot happen: every piece on the chain reports) */
+        *h_crc = crc;
+    }
     return QZD_OK;
 }
 
@@ -1008,6 +1057,15 @@ extern "C" int qzd_spec_prof(unsigned long long *out, uint32_t nwaves)
         return hipMemcpyFromSymbol(out + 4, HIP_SYMBOL(qzk_stamp_b), 16, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
     }
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(qzk_spec_prof), (size_t)(nwaves < 8192 ? nwaves : 8192) * 64, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef QZK_SPEC_PROF
+extern __device__ unsigned int qzk_spec_seg[1 << 17];
+/* profiling builds: the per-segment clocks of the last phase A (launch order), n <= 131072 */
+extern "C" int qzd_spec_seg_prof(unsigned int *out, uint32_t n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(qzk_spec_seg), (size_t)(n < (1u << 17) ? n : (1u << 17)) * 4, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -19,6 +19,9 @@ struct qzd_ctx {
     int device;
     hipStream_t st[QZD_NBUF];
     hipStream_t st_copy; hipEvent_t cp_ev[QZD_NBUF + 1];   /* host input arrives batch by batch while the previous batch is parsed */
+    hipStream_t st_out;                                     /* decoded output on its way to the host; like st_copy a stream with a
+                                                             * hardware queue of its own (qzd_device.hip, stream_own_queue) */
+    bool helper;                                            /* a piece's helper context (qzd_inflate_stream_from_host): one stream */
     hipEvent_t done[QZD_NBUF], k1done[QZD_NBUF];
     uint32_t cus;                                   /* compute units of the device */
     /* output slots of the LZ4 frame kernel (the deflate pipeline's scratch lives in the device's pool, qzd_k1pool) */
@@ -83,6 +86,7 @@ struct qzd_k1pool {
 
 /* grow the aux scratch pair to at least n bytes */
 int qzd_aux_reserve(qzd_ctx *c, size_t n);
+int qzd_create_helper(int device, qzd_ctx **out);
 
 /* host-side CRC-32 helpers (zlib crc32_combine semantics) */
 extern "C" uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);

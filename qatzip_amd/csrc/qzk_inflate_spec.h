@@ -20,10 +20,14 @@
  *      neighbour's tokens take over from that mark.  Lane 0 is right by construction, hence by induction every lane on
  *      the chain is.  A lane that is not in step by the end of a neighbour's share simply carries on into the next
  *      one's (round 3's version gave up there and handed the segment back: the segments that never fell into step
- *      were decoded twice, and set the pace); a lane that decodes garbage stops at the end of the segment's input;
+ *      were decoded twice, and set the pace).  Round 5 bounds what a lane can waste: one whose share begins behind
+ *      the block's END_BLOCK - known as soon as a lane ON THE TRUE STREAM has met it - leaves at its next marked trip,
+ *      and no lane goes more than QZK_SPEC_REACH shares without falling into step (what is left is shared out again);
  *   3. lane 0 walks the chain (the stops travel through cross-lane reads, not memory), appends the pieces to the
  *      segment's piece list (what phase B, qzk_lz_resolve_kernel, stitches together) and takes over the bit position
- *      behind the block's END_BLOCK for the next round.
+ *      behind the block's END_BLOCK for the next round.  A lane whose piece ended up on nobody's chain takes it back
+ *      (its sub-stream's counters return to where the round began): junk no longer fills the scratch of a lane that the
+ *      segment's later blocks need.
  * What does not fit (bad data, a sub-stream outgrowing its scratch, too many pieces) is answered with QZK_INF_ESPEC
  * and the host decodes that segment with the serial kernel: this kernel delivers a validated segment or nothing.
  * Same place in the reference as the rest of K3: zlib inflate(), src/qatzip_sw.c:339.
@@ -40,6 +44,9 @@
 #endif
 #ifndef QZK_SPEC_EVERY
 #define QZK_SPEC_EVERY 32          /* ... then one trip in so many (a power of two) */
+#endif
+#ifndef QZK_SPEC_REACH
+#define QZK_SPEC_REACH(K) ((K) >= 16 ? 6u : 4u)    /* shares a lane decodes from its start before it gives the rest back */
 #endif
 #define QZK_SPEC_MINBITS 512u      /* a block is split only when every lane gets at least this much of it */
 /* scratch of the sub-streams: lane 0 may have to decode the whole segment alone (nobody falls into step with a flat
@@ -71,13 +78,20 @@ static uint32_t qzk_spec_stats[1 << 20];
 #endif
 #ifdef QZK_SPEC_PROF           /* profiling builds only (tools/prof_spec.py): shader clocks of the hot loop's parts, per wave */
 __device__ unsigned long long qzk_spec_prof[8192][8];
+__device__ unsigned int qzk_spec_seg[1 << 17];      /* per segment (launch place): shader clocks / 64 from its wave's start to the segment's end */
 __device__ unsigned long long qzk_stamp[8];     /* wall-clock (100 MHz) first entry / last exit of: marker scan, phase A, phase B */
 #define QZK_STAMP_IN(k) do { if ((threadIdx.x & 63) == 0) atomicMin(&qzk_stamp[2 * (k)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
 #define QZK_STAMP_OUT(k) do { if ((threadIdx.x & 63) == 0) atomicMax(&qzk_stamp[2 * (k) + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
 #define QZK_PCLK() ((unsigned long long)__builtin_readcyclecounter())
 #define QZK_SPROF(k) do { const unsigned long long c_ = QZK_PCLK(); pacc[k] += c_ - pt; pt = c_; } while (0)
+/* the looks at a neighbour's trail: a trip in which ANY lane of the wave looks costs the whole wave the look (two loads from
+ * L2 and their wait); plook = the wave's clocks in there, nlook = such trips */
+#define QZK_LOOK_IN() const bool any_ = qz_ballot(at_ >= wake) != 0; const unsigned long long lk_ = any_ ? QZK_PCLK() : 0ull
+#define QZK_LOOK_OUT() do { if (any_) { plook += QZK_PCLK() - lk_; nlook++; } } while (0)
 #else
 #define QZK_SPROF(k) ((void)0)
+#define QZK_LOOK_IN() ((void)0)
+#define QZK_LOOK_OUT() ((void)0)
 #endif
 template <int K>
 QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
@@ -87,6 +101,19 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
 {
     constexpr int SPW = 64 / K;                                     /* segments per wave */
     QZ_LDS uint16_t roots[SPW][QZK_LANE_ROOTSZ];
+    /* Round 5: where the group's block ENDS, as soon as a lane has seen its END_BLOCK (the lowest such position: a lane that
+     * decodes garbage can only claim an end beyond its own start).  The shares of a round are a guess of the block's length,
+     * and a lane whose share begins beyond the real end decodes the NEXT blocks' bits with this block's tables: nothing ever
+     * puts it in step, it ran to the end of the segment's input - 1400 to 5800 trips where its group-mates made 270 (the
+     * emulator's trip counts over the bench data, profiles/r5_phaseA_tail.txt), the whole wave waiting, and the junk tokens
+     * filled its scratch, so that it sat out the segment's later blocks.  Now such a lane leaves at its next marked trip. */
+    QZ_LDS uint32_t gend[SPW];
+    /* Only a lane that decodes the TRUE stream may say where the block ends (a lane not yet in step meets a false END_BLOCK
+     * once in ~30 000 symbols: some forty times per 64 MiB).  Who is on the true stream is known link by link: lane 0 is; a lane
+     * that fell into step with lane t's trail vouches for t from there on, if it is vouched for itself.  Every lane leaves its
+     * link (gnext) and its END_BLOCK (geob) when it stops; whoever is confirmed walks the links in front of it. */
+    QZ_LDS uint32_t gconf[SPW], geob[64];
+    QZ_LDS uint8_t gnext[64];
 #ifdef QZK_SPEC_PROF
     QZK_STAMP_IN(1);
 #endif
@@ -126,11 +153,12 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
     int seg_status = QZK_INF_ESPEC;                                 /* set to FINAL / FLUSH when the segment ends well */
     uint32_t why = 0;                                               /* developer aid: why the segment was handed back */
     bool seg_done = !live;                                          /* lane 0: nothing more to do for this segment */
-    uint32_t cont_at = 0, prev_span = 0; bool cont = false, cont_past = false, cont_grow = false;                        /* lane 0: the block goes on at this bit (a lane on the chain ran out of scratch) */
+    uint32_t cont_at = 0, prev_span = 0, blk_at = 0; bool cont = false, cont_past = false, cont_grow = false;                        /* lane 0: the block goes on at this bit (a lane on the chain ran out of scratch) */
     uint32_t c_last = 0, c_lmax = 0, c_dmax = 0, c_lbase = 0;       /* ... with the tables it has */
 
 #ifdef QZK_SPEC_PROF
-    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = QZK_PCLK();
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = QZK_PCLK(), plook = 0, nlook = 0;
+    const unsigned long long p_start = pt; unsigned long long p_segdone = 0;
     const unsigned long long p_begin = __builtin_amdgcn_s_memrealtime();       /* the 100 MHz clock every wave agrees on */
 #endif
     for (uint32_t round = 0;; round++) {
@@ -164,7 +192,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                     else S.state = QZK_LS_HDR;
                 } else if (S.state == QZK_LS_SYM) {
                     const uint32_t at = 8u * S.b.pos - (uint32_t)S.b.bc;
-                    h_mode = 1; h_end = at; h_last = S.last; h_lmax = (uint32_t)S.lmax; h_dmax = (uint32_t)S.dmax; h_lbase = S.lbase;
+                    h_mode = 1; h_end = at; blk_at = at; h_last = S.last; h_lmax = (uint32_t)S.lmax; h_dmax = (uint32_t)S.dmax; h_lbase = S.lbase;
                     /* what the group shares: the rest of the segment, or - from the second block on - a block as long as
                      * the previous one (zlib closes a block every 32767 symbols, so blocks of a segment are alike).
                      * Too little to share: span 0 parks the other lanes, lane 0 decodes alone */
@@ -188,7 +216,12 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
             }
         }
         QZK_SPROF(0);                                               /* [0] headers */
+#ifdef QZK_SPEC_PROF
+        if (j == 0 && live && seg_done && !p_segdone) p_segdone = QZK_PCLK() - p_start;
+#endif
         if (j == 0 && h_span != 0) prev_span = h_span;
+        if (j == 0) { gend[g] = 0xffffffffu; gconf[g] = 1u; }
+        gnext[lane] = 0xff; geob[lane] = 0xffffffffu;
         qz_wave_sync();                                             /* the tables (LDS) and their ranges (the segment's record) are the group's now */
         h_mode = qz_shfl(h_mode, gbase); h_end = qz_shfl(h_end, gbase); h_span = qz_shfl(h_span, gbase); h_last = qz_shfl(h_last, gbase);
         h_lmax = qz_shfl(h_lmax, gbase); h_dmax = qz_shfl(h_dmax, gbase); h_lbase = qz_shfl(h_lbase, gbase);
@@ -197,6 +230,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
 
         /* ---- 2. the group decodes the block ---- */
         bool active = h_mode != 0 && (j == 0 || h_span != 0);
+        const uint32_t my_at = h_end + (uint32_t)j * h_span;       /* where my share of this round begins */
         if (active && (j > 0 || h_mode == 2)) {                     /* my guessed start (lane 0 stands behind the header, or goes to where the chain broke) */
             const uint32_t at = h_end + (uint32_t)j * h_span;
             if (j > 0 && (at + 64 >= limit_bits || (at >> 3) + 64 > S.b.end || QZK_NLIT(O) > lit_cap || O.nseq > seq_cap)) active = false;
@@ -219,7 +253,16 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
         /* the last lane decodes to the end of the block, however much longer than guessed the block is - but not alone for
          * long: a share beyond its own it stops, and what is left of the block is shared out again (a round of its own, the
          * guess doubled).  Blocks of one segment differ: 32767 symbols are a few KB of matches or 36 KB of literals. */
-        const uint32_t over = h_span != 0 && j == K - 1 && over_shares < 1000u ? h_end + ((uint32_t)K + over_shares) * h_span : 0xffffffffu;
+        uint32_t over = h_span != 0 && j == K - 1 && over_shares < 1000u ? h_end + ((uint32_t)K + over_shares) * h_span : 0xffffffffu;
+        /* ... and no lane goes more than QZK_SPEC_REACH shares without falling into step with anybody: where the codes are
+         * all of one length (bytes that do not compress) a decoder that started off a boundary stays off it for thousands of
+         * symbols, and the shares of a short guess are far smaller than that distance - the lanes used to run until their
+         * scratch was full, five times the trips of the round's useful ones (profiles/r5_phaseA_tail.txt).  Lane 0 too: what
+         * it would decode alone is shared out again with the guess doubled.  (Measured, tools/run/r5_p.sh and r5_q.sh: 3 shares
+         * break chains that 4 complete - 64 MiB: 7.2 against 3.7 ms; 8 for all lanes, or for the lanes known to be on the true
+         * stream only, costs 1 GiB of 64 KB segments - eight lanes each - 10.4-11.1 ms against 7.9; with sixteen lanes a share is
+         * half as long and 6 does better than 4: 1 GiB of 128 KB segments 10.6 against 11.8 ms.) */
+        if (h_span != 0 && (uint64_t)my_at + (uint64_t)QZK_SPEC_REACH(K) * h_span < over) over = my_at + QZK_SPEC_REACH(K) * h_span;
         /* lane 0 knows where in the segment's output it stands, so a match that reaches back before the segment stops it at
          * once (the others are checked by phase B).  It is what ends the decode of a candidate that is no segment - 00 00 FF FF
          * inside compressed data: without it lane 0, which nothing else bounds, read garbage until 64 KB of output had come
@@ -252,8 +295,11 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
             } \
             if (st.kind == QZK_ST_RUN && (QZK_NLIT(O) > lit_cap || O.nseq > seq_cap || at_ >= give_up || at_ >= over)) { \
                 st.kind = QZK_ST_REDO; st.cidx = at_ >= give_up ? 1u : at_ >= over ? 4u : 2u; st.at = at_; } \
+            if (st.kind == QZK_ST_RUN && j != 0 && my_at >= *(volatile uint32_t *)&gend[g]) {      /* my share lies behind the block's end: I am decoding garbage */ \
+                st.kind = QZK_ST_REDO; st.cidx = 5u; st.at = at_; } \
             if (rp == 0xffffffffu && target != (uint32_t)j) wake = 0;           /* the neighbour may have written since */ \
         } \
+        QZK_LOOK_IN(); \
         if (at_ >= wake) { \
             while (h_span != 0 && target + 1 < (uint32_t)K && at_ >= h_end + (target + 1) * h_span) { target++; cursor = 0; } \
             const uint32_t next_terr_ = h_span != 0 && target + 1 < (uint32_t)K ? h_end + (target + 1) * h_span : 0xffffffffu; \
@@ -273,6 +319,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
             wake = again_ ? 0u : rp != 0xffffffffu && rp + 1 < next_terr_ ? rp + 1 : next_terr_; \
             QZK_PIN(rp); QZK_PIN(wake); QZK_PIN(cursor);            /* the waits for the marks just read belong in here */ \
         } \
+        QZK_LOOK_OUT(); \
         if (st.kind == QZK_ST_RUN && at_ == rp) { st.kind = QZK_ST_SYNC; st.target = target; st.cidx = cursor; } \
         const bool allow = rp - at_ > 56u;                          /* a mark within reach: one symbol a trip, so that no boundary is stepped over */
 
@@ -324,20 +371,42 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 }
                 if (st.kind != QZK_ST_RUN) {
                     if (O.lrun) qzk_tok_seq(&O, 0u, 0u);            /* my piece ends with its pending literals */
+                    qzk_tok_flush(&O);                              /* ... and is in memory whole: a later round's may be taken back */
                     st.nlit = QZK_NLIT(O); st.nseq = O.nseq; st.olen = S.op;
                     active = false;
+                    /* my link and my END_BLOCK for whoever confirms me; if I am confirmed already, I confirm what lies in front
+                     * of me (the lanes of a wave run in lockstep and this block has no wave-wide operation in it: nobody else's
+                     * bookkeeping interleaves with mine) */
+                    if (st.kind == QZK_ST_SYNC) gnext[lane] = (uint8_t)st.target;
+                    if (st.kind == QZK_ST_EOB) geob[lane] = st.at;
+                    if ((*(volatile uint32_t *)&gconf[g] >> j) & 1u) {
+                        uint32_t t = (uint32_t)j;
+                        for (int hop = 0; hop < K; hop++) {
+                            const uint32_t e = *(volatile uint32_t *)&geob[gbase + (int)t];
+                            if (e != 0xffffffffu) atomicMin(&gend[g], e);       /* the block's end, from a lane that is right */
+                            const uint32_t nx = *(volatile uint8_t *)&gnext[gbase + (int)t];
+                            if (nx >= (uint32_t)K || nx == t) break;
+                            atomicOr(&gconf[g], 1u << nx);
+                            t = nx;
+                        }
+                    }
                 }
             }
         }
 #undef QZK_SPEC_PRE
         QZK_SPROF(2);                                               /* [2] the decode phase of the round (to its slowest lane) */
+#if defined(QZ_SIM) && defined(QZK_SPEC_STATS)
+        if (getenv("QZDBG_SPEC") && live && sidx == (uint32_t)atoi(getenv("QZDBG_SPEC")))
+            fprintf(stderr, "round %u lane %2d: start %8u span %6u stop kind %u cidx %u at %8u trips %5u  target %u cursor %u rp %u wake %u limit %u nlit %u/%u nseq %u/%u ridx %u\n", round, j, my_at, h_span, st.kind, st.cidx,
+                    st.kind == QZK_ST_RUN ? 0u : st.at, ntrip, target, cursor, rp, wake, limit_bits, QZK_NLIT(O), lit_cap, O.nseq, seq_cap, ridx);
+#endif
 #ifdef QZK_SPEC_STATS          /* emulator builds only (tools/spec_stats.py): trips of every lane and round */
-        if (live && round < 8) qzk_spec_stats[(sidx * K + (uint32_t)j) * 8 + round] = ntrip | st.kind << 28;
+        if (live && round < 8) qzk_spec_stats[(sidx * K + (uint32_t)j) * 8 + round] = (ntrip & 0xffffffu) | (st.kind == QZK_ST_REDO ? (st.cidx & 15u) << 24 : 0u) | st.kind << 28;
 #endif
         qz_wave_sync();
         /* ---- 3. lane 0 walks the chain of this round; the stops of the lanes it visits come through cross-lane reads ---- */
         {
-            uint32_t cur = 0, c_nlit = 0, c_nseq = 0, c_lrun = 0, c_olen = 0;
+            uint32_t cur = 0, c_nlit = 0, c_nseq = 0, c_lrun = 0, c_olen = 0, onchain = 0;
             bool from_rec = false, ok = false, walking = j == 0 && h_mode != 0;
             int bad_status = 0;
             for (int hop = 0; hop < K; hop++) {
@@ -347,7 +416,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 s.nlit0 = qz_shfl(st.nlit0, src); s.nseq0 = qz_shfl(st.nseq0, src); s.olen0 = qz_shfl(st.olen0, src);
                 s.nlit = qz_shfl(st.nlit, src); s.nseq = qz_shfl(st.nseq, src); s.olen = qz_shfl(st.olen, src);
                 if (!walking) continue;
-                const bool broke = s.kind == QZK_ST_REDO && (s.cidx == 1u || s.cidx == 2u || s.cidx == 4u) && cur != 0;
+                const bool broke = s.kind == QZK_ST_REDO && (s.cidx == 4u || ((s.cidx == 1u || s.cidx == 2u || s.cidx == 5u) && cur != 0));
                 if (s.kind != QZK_ST_SYNC && s.kind != QZK_ST_EOB && !broke) {
                     /* a lane on the chain decodes the true stream: what stopped it (cidx 3: bad data, the end of the input, the
                      * capacity) is the segment's own error; lane 0 out of scratch (its sub-stream holds a whole segment) or
@@ -362,6 +431,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 else { e.seq_first = s.nseq0; e.lit_first = s.nlit0; e.lrun_skip = 0; total_out += s.olen - s.olen0; }
                 e.seq_count = s.nseq - e.seq_first;
                 C->el[nel++] = e;
+                onchain |= 1u << cur;
                 if (broke) {
                     /* the lane's sub-stream is full (or it ran past the input it was told of): its piece stands, and the block
                      * goes on from where it stopped in a round of its own - lane 0's sub-stream has room for all of it */
@@ -371,7 +441,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                     continue;
                 }
                 if (s.kind == QZK_ST_EOB) {
-                    ok = true; blk_bits = s.at - h_end;
+                    ok = true; blk_bits = s.at - blk_at;            /* (the whole block, not its last round's part: a guess from that left lane 0 alone with the next one) */
                     qzk_lseek(&S.b, s.at >> 3); qzk_lrefill(&S.b); QZK_DROP(&S.b, s.at & 7);   /* I carry on behind the block */
                     if (h_last) { seg_status = QZK_INF_FINAL; seg_done = true; } else S.state = QZK_LS_HDR;
                     walking = false;
@@ -380,6 +450,26 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 const qzk_rec *q = recs + ((uint64_t)(sidx * K + s.target) * QZK_SPEC_NREC + s.cidx);
                 cur = s.target; from_rec = true;
                 c_nlit = qzk_ld32_l2(&q->nlit); c_nseq = qzk_ld32_l2(&q->nseq); c_lrun = qzk_ld32_l2(&q->lrun); c_olen = qzk_ld32_l2(&q->olen);
+            }
+            /* a lane whose piece of this round is on nobody's chain takes it back: what it decoded was off the symbol
+             * boundaries (or behind the block's end) and nobody will read it - left in place it filled the lane's sub-stream,
+             * and a lane without scratch sits out every later round of the segment (lane 0 was seen decoding a whole block
+             * alone behind fifteen full lanes).  The piece began at (nlit0, nseq0) with nothing pending; the 16 bytes and the
+             * pair it began inside are in memory since the lane last stopped */
+            onchain = qz_shfl(onchain, gbase);
+            if (live && j != 0 && st.kind != QZK_ST_RUN && !((onchain >> j) & 1u)) {
+                O.lw = st.nlit0; O.nseq = st.nseq0; O.lrun = 0; O.lfull = 0; O.qfull = 0;
+                O.l0 = O.l1 = O.l2 = O.l3 = O.l4 = 0; O.q0 = O.q1 = 0;
+                const uint32_t c = O.lw & 15u;
+                if (c) {
+                    const qzk_u32x4 v = *(const qzk_u32x4 *)(O.lp + (O.lw & ~15u));
+                    const uint32_t w = c >> 2, m = (1u << (8u * (c & 3u))) - 1u;      /* whole dwords below w, m of dword w */
+                    O.l0 = w > 0 ? v[0] : v[0] & m;
+                    O.l1 = w > 1 ? v[1] : w == 1 ? v[1] & m : 0u;
+                    O.l2 = w > 2 ? v[2] : w == 2 ? v[2] & m : 0u;
+                    O.l3 = w == 3 ? v[3] & m : 0u;
+                }
+                if (O.nseq & 1u) O.q0 = ((const uint64_t *)O.sq)[O.nseq - 1u];
             }
             QZK_SPROF(3);
             if (j == 0 && h_mode != 0) {
@@ -392,8 +482,11 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
 #ifdef QZK_SPEC_PROF
     QZK_STAMP_OUT(1);
     QZK_SPROF(3);                                                   /* [3] chain walks and the rest */
+    if (j == 0 && live && sidx < (1u << 17)) qzk_spec_seg[sidx] = (unsigned int)((p_segdone ? p_segdone : QZK_PCLK() - p_start) >> 6);
     if (blockIdx.x < 8192) {
-        if (lane == 0) { for (int k = 0; k < 4; k++) qzk_spec_prof[blockIdx.x][k] = pacc[k];
+        if (lane == 0) { for (int k = 0; k < 3; k++) qzk_spec_prof[blockIdx.x][k] = pacc[k];
+                         qzk_spec_prof[blockIdx.x][2] += pacc[3];                   /* (the chain walks: 0.1-0.3 %) */
+                         qzk_spec_prof[blockIdx.x][3] = nlook << 40 | (plook & ((1ull << 40) - 1));
                          qzk_spec_prof[blockIdx.x][5] = p_begin << 32 | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull); }   /* begin | end */
         atomicMax(&qzk_spec_prof[blockIdx.x][4], pacc[6]);          /* the lane longest in the hot loop: its clocks there ... */
         atomicMax(&qzk_spec_prof[blockIdx.x][6], pacc[7]);          /* ... the most trips of a lane ... */

@@ -375,6 +375,7 @@ QZ_DEV uint32_t qzk_lz4_block(const uint8_t *in, uint32_t n, uint8_t *out, uint3
  *     stores of lane 0).
  * A streak that goes beyond its first sixteen probes (data that does not compress) reads its probes' words from memory as
  * before; literal runs above 128 bytes are copied memory to memory. */
+static_assert(QZK_LZ4_W0 <= 64u && QZK_LZ4_W0 + 4u + 128u + 16u <= 256u, "the first probe window and the literals behind it fit the register window");
 #define QZK_L4C_OST 832u            /* staging: a flush leaves < 256 + 16 bytes, a sequence adds at most 1 + 2 + 128 + 2 + 258 */
 #define QZK_L4C_LITMAX 128u
 typedef struct { uint8_t *st; uint8_t *out; uint32_t oph, op, adj, hd; } qzk_l4o;
@@ -480,7 +481,7 @@ QZ_DEV uint32_t qzk_lz4_block_f(const uint8_t *in, uint32_t n, uint8_t *out, uin
             /* ---------------- search streak from ip ---------------- */
             {   /* the window covers the literals so far (when they are few enough to go through it) and the first probes */
                 const uint32_t lo = ip - anchor <= QZK_L4C_LITMAX ? anchor : (ip >= 16 ? ip - 16 : 0);
-                if (fb > lo || ip + 20 > fb + 256) { fb = lo; F = qzk_f_load(in, n, fb, lane); }
+                if (fb > lo || ip + QZK_LZ4_W0 + 4 > fb + 256) { fb = lo; F = qzk_f_load(in, n, fb, lane); }   /* (the first window's probes and their four bytes) */
             }
             uint32_t j0 = 0, mpos = 0, mcand = 0; bool found = false;
             for (;;) {
@@ -529,7 +530,11 @@ QZ_DEV uint32_t qzk_lz4_block_f(const uint8_t *in, uint32_t n, uint8_t *out, uin
                 /* insert every probed position up to and including the hit (or the whole window): per key the highest
                  * (rest of the hash, lane) wins, its hash is served, the other hashes on that key go round again */
                 const int last_ins = got ? fl : (first_dead < (int)W ? first_dead - 1 : (int)W - 1);
-                {
+                if (SUS == 0) {
+                    /* no two lanes of the window share a key, let alone a hash: every lane is its hash's last writer */
+                    if (live && lane <= last_ins) table[h] = QZK_L4E(epoch, f, v);
+                    qz_lds_sync();                                  /* (the next window's lookups come behind these stores) */
+                } else {
                     bool pend = live && lane <= last_ins;
                     const uint32_t val = (((h >> 10) << 6) | (uint32_t)lane) + 1;
                     while (qz_ballot(pend)) {
@@ -640,7 +645,7 @@ QZ_DEV uint32_t qzk_lz4_block_f(const uint8_t *in, uint32_t n, uint8_t *out, uin
                 anchor = mip;
                 if ((int32_t)mip >= mfl1) { ended = true; break; }
                 /* fill table with ip-2, then test the next position right away; the window moves up if it has to */
-                if (fb + 2 > mip || mip + 24 > fb + 256) { fb = mip >= 16 ? mip - 16 : 0; F = qzk_f_load(in, n, fb, lane); }
+                if (fb + 2 > mip || mip + 1 + QZK_LZ4_W0 + 4 > fb + 256) { fb = mip >= 16 ? mip - 16 : 0; F = qzk_f_load(in, n, fb, lane); }
                 const uint32_t v2 = qzk_f_u32(F, mip - 2 - fb), v0 = qzk_f_u32(F, mip - fb);
                 const uint32_t h2 = QZK_LZ4HASH(v2), h0 = QZK_LZ4HASH(v0);
                 if (lane == 0) table[h2] = QZK_L4E(epoch, mip - 2, v2);

@@ -29,19 +29,24 @@ ctx.inflate_stream(d_c, clen, d_o, ck << 10, want_crc=False)
 assert ctx.L.qzd_spec_prof(None, C.c_uint32(0)) == 0           # reset (the atomics accumulate)
 ctx.inflate_stream(d_c, clen, d_o, ck << 10, want_crc=False)
 nseg = n // (ck << 10)
-K = int(os.environ.get("QATZIP_AMD_INFLATE_K", "8" if nseg <= 16384 else "4"))
+K = int(os.environ.get("QATZIP_AMD_INFLATE_K", "16" if nseg <= 8192 and ck > 16 else "8" if nseg <= (32768 if ck > 16 else 16384) else "4"))
 spw = 64 // K
 nw = min(8192, (nseg + spw - 1) // spw + 1)                   # + 1: a candidate that is no segment makes one more
 buf = np.zeros((nw, 8), np.uint64)
 assert ctx.L.qzd_spec_prof(buf.ctypes.data_as(C.c_void_p), C.c_uint32(nw)) == 0
 b = buf.astype(np.float64)
+look_clk = (buf[:, 3] & np.uint64((1 << 40) - 1)).astype(np.float64); look_n = (buf[:, 3] >> np.uint64(40)).astype(np.float64)
+b[:, 3] = 0                                                     # (column 3: the looks at trails, part of the decode rounds' clocks)
 tot = b[:, :4].sum(1)
 print("%d MiB / %d KiB chunks: %d waves; shader clocks per wave mean %.2f M, max %.2f M" % (mb, ck, nw, tot.mean() / 1e6, tot.max() / 1e6))
 for w, label in ((slice(None), "all waves"), (np.argsort(-tot)[:max(1, nw // 16)], "the slowest sixteenth")):
     x = b[w]; t = x[:, :4].sum()
     print("  %s (%.2f M clocks a wave):" % (label, t / len(x) / 1e6))
-    for k, name in enumerate(["block headers (lane 0 of every group)", "starts, long-code tables", "decode rounds, to their slowest lane", "chain walks, results"]):
+    for k, name in enumerate(["block headers (lane 0 of every group)", "starts, long-code tables", "decode rounds and chain walks"]):
         print("    %-40s %5.1f %%" % (name, 100 * x[:, k].sum() / t))
+    lc, ln = look_clk[w], look_n[w]
+    print("    of the rounds: looks at a neighbour's trail %.1f %% of the wave's clocks - %.0f of a wave's %.0f trips have a lane looking, %.0f clocks each" %
+          (100 * lc.sum() / t, ln.mean(), x[:, 6].mean(), lc.sum() / max(1.0, ln.sum())))
     print("    inside the rounds: the busiest lane is in the hot loop %.1f %% of the round time; its trips %.0f a wave, %.0f clocks a trip;"
           " %.0f trips a lane on average" %
           (100 * x[:, 4].sum() / x[:, 2].sum(), x[:, 6].mean(), x[:, 4].sum() / x[:, 6].sum(), x[:, 7].sum() / 64 / len(x)))

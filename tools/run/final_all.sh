@@ -1,7 +1,13 @@
-# one gpurun call at the end of a round: the profile passes, the bench lines, the whole GPU suite
+# one gpurun call at the end of a round: the profile passes, the decode kernels' counters, phase A's per-segment times, the
+# bench lines, the fuzz campaigns on the hardware, the whole GPU suite
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export PYTHONPATH=$GRAFT_REPO_ROOT
 bash tools/profile_round.sh 4096 > gpurun_out/profile_round.log 2>&1
+bash tools/run/pmc_decode.sh > gpurun_out/pmc_decode.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/pmc_show.py dec qzk_inflate_spec qzk_lz_resolve > gpurun_out/decode_counters.txt 2>&1
+QATZIP_AMD_SO=$GRAFT_REPO_ROOT/build/var/lib_sprof.so timeout 300 python tools/prof_phaseA_tail.py 64 256 1024 4096 > gpurun_out/phaseA_tail.txt 2>&1
 bash tools/run/bench_final.sh > gpurun_out/bench_final.log 2>&1
+bash tools/run/fuzz_gpu.sh > gpurun_out/fuzz_both.log 2>&1
 bash tools/run/full_gpu.sh > gpurun_out/full_gpu_tail.log 2>&1
-tail -n 5 gpurun_out/full_gpu_tail.log
+tail -n 5 gpurun_out/full_gpu_tail.log; tail -n 12 gpurun_out/phaseA_tail.txt; tail -n 30 gpurun_out/bench_final.log | cut -c1-900
