@@ -178,6 +178,16 @@ static hipError_t stream_own_queue(hipStream_t *st, int device)
     (void)hipGetLastError();
     return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
+/* the two copy streams of a piece-wise decode, made when the first such call comes: a process of many sessions that only
+ * ever make small calls (the reference's fleet shape) must not pay for them - sixty-four sessions with two queues of their
+ * own each ran the small-call sweep at a fifth of its rate (hardware queues are few; profiles/r5_small_calls.txt) */
+int qzd_pipe_streams(qzd_ctx *c)
+{
+    if (c->pq_copy && c->pq_out) return QZD_OK;
+    if (!c->pq_copy && stream_own_queue(&c->pq_copy, c->device) != hipSuccess) { c->pq_copy = NULL; return QZD_ERR_HIP; }
+    if (!c->pq_out && stream_own_queue(&c->pq_out, c->device) != hipSuccess) { c->pq_out = NULL; return QZD_ERR_HIP; }
+    return QZD_OK;
+}
 static int ctx_create(int device, qzd_ctx **out, bool helper);
 extern "C" int qzd_create(int device, qzd_ctx **out) { return ctx_create(device, out, false); }
 /* the context of a helper thread (a piece of qzd_inflate_stream_from_host): it launches on st[0] and nowhere else, and every
@@ -202,7 +212,8 @@ static int ctx_create(int device, qzd_ctx **out, bool helper)
     }
     hipEventCreate(&c->ev_begin); hipEventCreate(&c->ev_end);
     if (helper) c->st_copy = c->st_out = c->st[0];
-    else if (stream_own_queue(&c->st_copy, device) != hipSuccess || stream_own_queue(&c->st_out, device) != hipSuccess) QZD_CREATE_FAIL;
+    else if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess ||
+             hipStreamCreateWithFlags(&c->st_out, hipStreamNonBlocking) != hipSuccess) QZD_CREATE_FAIL;
     for (int i = 0; i < QZD_NBUF + 1; i++) hipEventCreateWithFlags(&c->cp_ev[i], hipEventDisableTiming);
     for (int i = 0; i < 8; i++) hipEventCreateWithFlags(&c->so_ev[i], hipEventDisableTiming);
     c->so_host = NULL; c->so_nat = NULL; c->so_sent = 0;
@@ -248,6 +259,8 @@ extern "C" void qzd_destroy(qzd_ctx *c)
             for (int k = 0; k < 8; k++) if (c->so_ev[k]) hipEventDestroy(c->so_ev[k]);
             if (c->st_copy && !c->helper) hipStreamDestroy(c->st_copy);
             if (c->st_out && !c->helper) hipStreamDestroy(c->st_out);
+            if (c->pq_copy) hipStreamDestroy(c->pq_copy);
+            if (c->pq_out) hipStreamDestroy(c->pq_out);
             for (int k = 0; k < QZD_NBUF + 1; k++) if (c->cp_ev[k]) hipEventDestroy(c->cp_ev[k]);
         }
         for (int k = 0; k < 4; k++) if (c->ev[i][k]) hipEventDestroy(c->ev[i][k]);

@@ -69,7 +69,10 @@
 #define QZD_SPEC_FEWER_SEGS 8192u
 static uint32_t spec_lanes(const qzk_infseg *hs, uint32_t nsegs)
 {
-    uint32_t K = nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 16384u + 64u && hs[0].out_cap <= 524288u + 64u ? QZD_SPEC_LANES_FEWER
+    /* segments above 128 KB hold many blocks one behind the other: thirty-two lanes (round 5, 1 GiB of 512 KB segments:
+     * phase A 35.2 -> 18.4 ms, of 256 KB: 21.3 -> 13.9; at 64 KB sixteen lanes do better, 3.8 against 4.3 ms for 64 MiB) */
+    uint32_t K = nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 131072u + 64u && hs[0].out_cap <= 524288u + 64u ? 32u
+               : nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 16384u + 64u && hs[0].out_cap <= 524288u + 64u ? QZD_SPEC_LANES_FEWER
                : nsegs <= (hs[0].out_cap > 16384u + 64u ? QZD_SPEC_FEW_SEGS_BIG : QZD_SPEC_FEW_SEGS) ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
     const char *ke = getenv("QATZIP_AMD_INFLATE_K");
     if (ke) { int v = atoi(ke); if (v == 1 || v == 4 || v == 8 || v == 16 || v == 32) K = (uint32_t)v; }
@@ -617,7 +620,11 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
     const bool lanes = force_path ? force_path[0] == 'l' : true;   /* every candidate carries a length hint: K lanes per segment at any count */
     bool lanes_nomem = false;                                       /* the token scratch could not be had: the wave-per-segment passes below */
     {
-        if (scan_ok && seg_hint && ns > 1 && lanes) {
+        /* (a lone segment above 16 KB too: sixteen lanes decode 64 KB in 0.50 + 0.45 ms where the wave-per-segment kernel of
+         * path 4 takes 1.85 - one thread of 64 KB qzDecompress calls 0.229 -> 0.423 Gbit/s, sixteen threads 3.6 -> 5.1;
+         * QATZIP_AMD_LONE_WAVE=1 is the old way) */
+        static const bool lone_lanes = getenv("QATZIP_AMD_LONE_WAVE") == NULL;
+        if (scan_ok && seg_hint && (ns > 1 || (lone_lanes && seg_hint > 16384u)) && lanes) {
             auto clen = [&](uint32_t k) { return (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k]; };
             std::vector<uint32_t> order(ns);
             {   /* largest compressed size first (32-byte classes): lanes of a wave carry similar work, the longest start first */
@@ -927,7 +934,7 @@ static void pipe_piece_body(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, con
         H->inf_ms[3] = 0;
     }
     for (uint32_t i = 0; i < ns; i++) ps[i].flags = ps[i].flags == 0x80000000u ? 0 : QZK_INF_COUNT_ONLY;
-    if (two_phase_resolve(H, d_src, d_dst, ps.data(), ns, chain.data(), (uint32_t)chain.size(), pr.data(), h_dst, st, c->st_out) != QZD_OK) { pipe_fail(S, p); return; }
+    if (two_phase_resolve(H, d_src, d_dst, ps.data(), ns, chain.data(), (uint32_t)chain.size(), pr.data(), h_dst, st, c->pq_out) != QZD_OK) { pipe_fail(S, p); return; }
     for (uint32_t i : chain) if (pr[i].status < 0) { pipe_fail(S, p); return; }
     if (trace) {
         char line[160];
@@ -976,6 +983,7 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
         for (uint32_t p = 0; p <= P; p++) cut[p] = p == P ? n : (n * p / P) & ~(uint64_t)4095;
     }
     if (!seg_hint) P = 0;
+    if (P >= 2 && qzd_pipe_streams(c) != QZD_OK) { (void)hipGetLastError(); P = 0; }
     for (uint32_t p = 0; p < P; p++) {
         if (!c->pipe_ctx[p] && qzd_create_helper(c->device, &c->pipe_ctx[p]) != QZD_OK) { P = p; break; }
         if (!c->pipe_ev[p] && hipEventCreateWithFlags(&c->pipe_ev[p], hipEventDisableTiming) != hipSuccess) { P = p; break; }
@@ -1015,14 +1023,14 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
         S.cv.notify_all();
     };
     for (uint32_t p = 0; p < P; p++) {
-        if (copy_ok && (hipMemcpyAsync(d_src + cut[p], h_src + cut[p], cut[p + 1] - cut[p], hipMemcpyHostToDevice, c->st_copy) != hipSuccess ||
-                        hipEventRecord(c->pipe_ev[p], c->st_copy) != hipSuccess)) copy_ok = false;
+        if (copy_ok && (hipMemcpyAsync(d_src + cut[p], h_src + cut[p], cut[p + 1] - cut[p], hipMemcpyHostToDevice, c->pq_copy) != hipSuccess ||
+                        hipEventRecord(c->pipe_ev[p], c->pq_copy) != hipSuccess)) copy_ok = false;
         if (p) landed(p - 1);
     }
     landed(P - 1);
     for (auto &t : th) t.join();
     for (const std::string &l : S.log) fprintf(stderr, "%s\n", l.c_str());
-    HIPCHK(c, hipStreamSynchronize(c->st_copy));
+    HIPCHK(c, hipStreamSynchronize(c->pq_copy));
     if (!copy_ok) {
         snprintf(c->err, sizeof(c->err), "host-to-device copy of a piece failed");
         return QZD_ERR_HIP;

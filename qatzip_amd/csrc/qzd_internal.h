@@ -19,8 +19,10 @@ struct qzd_ctx {
     int device;
     hipStream_t st[QZD_NBUF];
     hipStream_t st_copy; hipEvent_t cp_ev[QZD_NBUF + 1];   /* host input arrives batch by batch while the previous batch is parsed */
-    hipStream_t st_out;                                     /* decoded output on its way to the host; like st_copy a stream with a
-                                                             * hardware queue of its own (qzd_device.hip, stream_own_queue) */
+    hipStream_t st_out;                                     /* decoded output on its way to the host */
+    hipStream_t pq_copy, pq_out;                            /* the same two for a piece-wise decode (qzd_inflate_stream_from_host): streams
+                                                             * with hardware queues of their own, made by the first such call
+                                                             * (qzd_device.hip, stream_own_queue / qzd_pipe_streams) */
     bool helper;                                            /* a piece's helper context (qzd_inflate_stream_from_host): one stream */
     hipEvent_t done[QZD_NBUF], k1done[QZD_NBUF];
     uint32_t cus;                                   /* compute units of the device */
@@ -87,6 +89,7 @@ struct qzd_k1pool {
 /* grow the aux scratch pair to at least n bytes */
 int qzd_aux_reserve(qzd_ctx *c, size_t n);
 int qzd_create_helper(int device, qzd_ctx **out);
+int qzd_pipe_streams(qzd_ctx *c);
 
 /* host-side CRC-32 helpers (zlib crc32_combine semantics) */
 extern "C" uint32_t qzd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
