@@ -198,6 +198,13 @@ static int ctx_create(int device, qzd_ctx **out, bool helper)
     if (!out) return QZD_ERR_PARAM;
     *out = NULL;
     if (hipSetDevice(device) != hipSuccess) return QZD_ERR_HIP;
+    {
+        /* QATZIP_AMD_SYNC=block: a thread that waits for the device sleeps instead of spinning.  For hosts with fewer cores
+         * (or a smaller CPU quota) than processes: the reference's fleet shape, P pinned processes of synchronous calls -
+         * tools/fleet.sh, profiles/r5_fleet.txt */
+        static const char *sy = getenv("QATZIP_AMD_SYNC");
+        if (sy && sy[0] == 'b') { if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError(); }
+    }
     qzd_ctx *c = new (std::nothrow) qzd_ctx();
     if (!c) return QZD_ERR_HIP;
     memset(c, 0, sizeof(*c));

@@ -30,6 +30,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <string.h>
@@ -327,7 +328,8 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
  * h_order = the real ones in output order.  With h_dst the output leaves for the host range by range behind the launches
  * (off_of / end_of give a range's bytes).  Results (phase B can still find a bad distance) come back in h_res. */
 static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qzk_infseg *hs, uint32_t nsegs,
-                             const uint32_t *h_order, uint32_t count, qzk_infres *h_res, uint8_t *h_dst, hipStream_t st, hipStream_t out_st = NULL)
+                             const uint32_t *h_order, uint32_t count, qzk_infres *h_res, uint8_t *h_dst, hipStream_t st, hipStream_t out_st = NULL,
+                             const std::function<void()> *while_leaving = NULL /* called once the output's copies are queued, before they are waited for */)
 {
     if (!out_st) out_st = c->st_out;
     if (nsegs != c->tp.nsegs || count == 0) return QZD_ERR_PARAM;
@@ -363,6 +365,7 @@ static int two_phase_resolve(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, 
             HIPCHK(c, hipStreamWaitEvent(out_st, c->so_ev[p], 0));
             HIPCHK(c, hipMemcpyAsync(h_dst + off[p], d_out + off[p], off[p + 1] - off[p], hipMemcpyDeviceToHost, out_st));
         }
+        if (while_leaving) (*while_leaving)();
         HIPCHK(c, hipStreamSynchronize(out_st));
         c->so_sent = off[parts];
     }
@@ -798,7 +801,7 @@ struct qzd_pipe {
     bool cand_ok[QZD_PIPE_MAX]; uint32_t lastc[QZD_PIPE_MAX];       /* the last candidate at or before the piece's end */
     bool chain_ok[QZD_PIPE_MAX]; uint32_t nxt[QZD_PIPE_MAX]; uint64_t oo[QZD_PIPE_MAX];   /* the chain after the piece */
     bool final_seen; uint64_t total_in, total_out;
-    uint32_t crc[QZD_PIPE_MAX]; uint64_t crc_len[QZD_PIPE_MAX]; bool want_crc;      /* CRC-32 of every piece's output, taken while later pieces are still on their way out */
+    std::mutex m_crc; uint32_t crc[QZD_PIPE_MAX]; uint64_t crc_len[QZD_PIPE_MAX]; bool want_crc;      /* CRC-32 of every piece's output, taken while later pieces are still on their way out */
     bool failed;
     std::chrono::steady_clock::time_point t0;
     std::vector<std::string> log;           /* QATZIP_AMD_TRACE: the pieces' steps, printed when the call is over (printing them
@@ -934,7 +937,16 @@ static void pipe_piece_body(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, con
         H->inf_ms[3] = 0;
     }
     for (uint32_t i = 0; i < ns; i++) ps[i].flags = ps[i].flags == 0x80000000u ? 0 : QZK_INF_COUNT_ONLY;
-    if (two_phase_resolve(H, d_src, d_dst, ps.data(), ns, chain.data(), (uint32_t)chain.size(), pr.data(), h_dst, st, c->pq_out) != QZD_OK) { pipe_fail(S, p); return; }
+    /* my output's CRC-32 (the caller combines the pieces'), taken on the caller's context - idle while the pieces run - behind
+     * my phase B and WHILE my output leaves: one pass over 2 GiB after the last piece had left cost the call 0.7 ms with the
+     * link idle */
+    uint32_t crc_mine = 0; bool crc_done = false;
+    const std::function<void()> crc_fn = [&] {
+        std::lock_guard<std::mutex> g(S->m_crc);
+        crc_done = hipStreamWaitEvent(c->st[0], H->ev[1][2], 0) == hipSuccess && qzd_crc32(c, d_dst + oo0, oo - oo0, &crc_mine) == QZD_OK;
+    };
+    if (two_phase_resolve(H, d_src, d_dst, ps.data(), ns, chain.data(), (uint32_t)chain.size(), pr.data(), h_dst, st, c->pq_out,
+                          S->want_crc && oo > oo0 ? &crc_fn : NULL) != QZD_OK) { pipe_fail(S, p); return; }
     for (uint32_t i : chain) if (pr[i].status < 0) { pipe_fail(S, p); return; }
     if (trace) {
         char line[160];
@@ -944,15 +956,7 @@ static void pipe_piece_body(qzd_ctx *H, qzd_ctx *c, qzd_pipe *S, uint32_t p, con
     }
     { std::lock_guard<std::mutex> g(S->m); c->inf_ms[2] += H->inf_ms[2]; c->inf_ms[0] += H->inf_ms[2]; }
     lap("phase B, sent");
-    if (S->want_crc && oo > oo0) {
-        /* my output's CRC-32 (the caller combines the pieces'): one pass over 2 GiB after the last piece had left cost the call
-         * 0.7 ms with the link idle; this way only the last piece's share of it is left */
-        uint32_t crc = 0;
-        if (qzd_crc32(H, d_dst + oo0, oo - oo0, &crc) != QZD_OK) { pipe_fail(S, p); return; }
-        std::lock_guard<std::mutex> g(S->m);
-        S->crc[p] = crc; S->crc_len[p] = oo - oo0;
-        c->inf_ms[1] += H->inf_ms[1]; H->inf_ms[1] = 0;
-    }
+    if (crc_done) { std::lock_guard<std::mutex> g(S->m); S->crc[p] = crc_mine; S->crc_len[p] = oo - oo0; }
 }
 
 /* d_src: where the n bytes at h_src are to stand on the device (they are all there when this returns, whatever it

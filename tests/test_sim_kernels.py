@@ -295,6 +295,38 @@ def test_speculative_inflate_matches_serial(sim):
     assert taken > 50            # the speculative kernel really decoded most of the ordinary segments itself
 
 
+def test_speculative_inflate_where_lanes_do_not_fall_into_step(sim):
+    """codes of one length (bytes drawn evenly from 64 or 256 values: a decoder that starts off a symbol boundary stays off
+    it) and of nearly one length (48 values), alone and between text: the lanes of a group run their bounded reach without
+    falling into step, give the rest back, take their unused pieces back - the bytes are zlib's all the same, through
+    the continuation rounds or through the serial kernel (qzk_inflate_spec.h, QZK_SPEC_REACH)"""
+    seg_dt = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
+    res_dt = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
+    sim.sim_inflate_spec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    rng = np.random.default_rng(77)
+    text = datagen.gen_bytes("text", 40000, 3)
+    flat64 = bytes(rng.integers(0, 64, 65536, dtype=np.uint8))
+    flat48 = bytes(rng.integers(0, 48, 65536, dtype=np.uint8))
+    flat256 = bytes(rng.integers(0, 256, 30000, dtype=np.uint8))
+    chunks = [flat64, flat48, text[:20000] + flat64[:30000] + text[20000:35000], flat48[:25000] + text + flat48[25000:],
+              flat256 + text[:9000] + flat64[:20000]]
+    for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_HUFFMAN_ONLY):
+        co = zlib.compressobj(1, zlib.DEFLATED, -15, 8, strategy)
+        pieces = [co.compress(ch) + co.flush(zlib.Z_FULL_FLUSH) for ch in chunks[:-1]]
+        pieces.append(co.compress(chunks[-1]) + co.flush())
+        comp = b"".join(pieces); src = b"".join(chunks); n = len(src)
+        segs, off, oo = [], 0, 0
+        for pc, ch in zip(pieces, chunks):
+            segs.append((off, oo, len(comp) - off, len(ch), 0, len(pc))); off += len(pc); oo += len(ch)
+        cbuf = np.frombuffer(comp + b"\0" * 64, np.uint8).copy()
+        sa = np.array(segs, dtype=seg_dt)
+        for K in (4, 8, 16, 32):
+            out = np.full(n + 64, 0xAA, np.uint8); res = np.zeros(len(segs), res_dt)
+            sim.sim_inflate_spec(cbuf.ctypes.data, out.ctypes.data, sa.ctypes.data, res.ctypes.data, len(segs), K)
+            assert bytes(out[:n]) == src and bytes(out[n:]) == b"\xaa" * 64, (strategy, K)
+            assert (res["status"] >= 0).all() and [int(r["in_used"]) for r in res] == [len(pc) for pc in pieces], (strategy, K, res)
+
+
 def test_damaged_streams_end_in_an_error_or_in_zlibs_own_bytes(sim):
     """a decoder must never crash, hang or write outside its output: a segment with flipped bits (most of them in the block
     header, which is decoded in LDS and registers since round 4) or cut short is reported as an error - or, when zlib decodes
