@@ -41,7 +41,7 @@ for mb, ck in shapes:
     nw = min(8192, (nseg + spw - 1) // spw)
     buf = np.zeros((nw, 8), np.uint64)
     assert ctx.L.qzd_spec_prof(buf.ctypes.data_as(C.c_void_p), C.c_uint32(nw)) == 0
-    wav = buf[:, :4].astype(np.float64).sum(1) / 1e6
+    wav = buf[:, :3].astype(np.float64).sum(1) / 1e6                # (column 3 holds the looks at trails: tools/prof_spec.py)
     q = lambda a, p: float(np.percentile(a, p))
     print("%d MiB / %d KiB segments: %d segments, K = %d lanes each, %d waves; phase A %.2f ms (HIP events)" % (mb, ck, nseg, K, nw, ms[0] - ms[2]))
     print("  per segment (M clocks from its wave's start to its last block): p50 %.2f  p90 %.2f  p99 %.2f  max %.2f" % (q(seg, 50), q(seg, 90), q(seg, 99), seg.max()))
