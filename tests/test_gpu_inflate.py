@@ -189,3 +189,28 @@ def test_decode_without_room_for_its_scratch(ctx, monkeypatch):
     monkeypatch.delenv("QATZIP_AMD_SCRATCH_MAX")
     iu, out, crc = _inflate(ctx, comp, n, 65536)
     assert out == src
+
+
+def test_marker_scan_finds_what_the_reference_scan_finds(ctx, monkeypatch):
+    """the 00 00 FF FF scan (sixteen positions a lane through two 8-byte loads and a cross-lane read) against the scan it
+    replaced, over streams with markers at every alignment, at the buffer's very end, in the wave's last lane, and with
+    false ones inside the data: QATZIP_AMD_MARKER_CHECK makes the device layer run both and fail on any difference - a
+    missed marker would only send the decode down a slower path, which no parity test sees"""
+    monkeypatch.setenv("QATZIP_AMD_MARKER_CHECK", "1")
+    rng = np.random.default_rng(9)
+    for chunk, n in ((1000, 300000), (1021, 290000), (4096, 1 << 20), (65536, 3 << 20), (333, 100001)):
+        src = datagen.gen_bytes("silesia", n, 77)
+        rc, _, comp, _ = O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536 + 8 * (n // chunk + 1))
+        assert rc == 0
+        iu, out, crc = _inflate(ctx, comp, n, chunk)
+        assert out == src and iu == len(comp) and crc == (zlib.crc32(src) & 0xffffffff), (chunk, n)
+    # stored blocks full of false markers (00 00 FF FF inside the data), at every byte phase
+    raw = bytearray(rng.integers(0, 256, 200000, dtype=np.uint8))
+    for i in range(0, len(raw) - 8, 37):
+        raw[i:i + 4] = b"\x00\x00\xff\xff"
+    raw[-4:] = b"\x00\x00\xff\xff"
+    src = bytes(raw)
+    rc, _, comp, _ = O.sw_compress("RAW", src, 65536, 1, cap=len(src) * 9 // 8 + 65536)
+    assert rc == 0
+    iu, out, crc = _inflate(ctx, comp, len(src), 65536)
+    assert out == src and iu == len(comp)
