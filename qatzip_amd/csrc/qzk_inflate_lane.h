@@ -1080,6 +1080,9 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8
             if ((uint32_t)lane >= n) { s_tot -= litrun + mlen; s_lit -= litrun; litrun = 0; mlen = 0; }    /* (sums of idle lanes: never read) */
             const uint32_t Tb = qz_readlane(s_tot, (int)n - 1), Lb = qz_readlane(s_lit, (int)n - 1);
             err = qzk_rb_batch(&S, lp + lbase, Lb, s_lit - litrun, litrun, mlen, dist, s_tot, Tb, lane);
+            if (err) break;                             /* (without this the next batch's 0 took its place: a match that reached
+                                                         * before the segment, decoded by a lane other than lane 0, went through
+                                                         * as a success - found by tools/sim_fuzz_corrupt.py, seed 188949) */
             lbase += Lb; b0 += n;
             cur = nxt;
         }

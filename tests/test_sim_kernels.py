@@ -327,6 +327,45 @@ def test_speculative_inflate_where_lanes_do_not_fall_into_step(sim):
             assert (res["status"] >= 0).all() and [int(r["in_used"]) for r in res] == [len(pc) for pc in pieces], (strategy, K, res)
 
 
+def test_a_match_before_the_segment_found_by_phase_b_is_an_error(sim):
+    """a distance made too large by a flipped bit, in a part of the block that a lane other than lane 0 decodes: phase A
+    cannot know (that lane does not know where in the output it stands), phase B must say so - and its answer must survive
+    the batches that follow (round 5's phase B overwrote a batch's error with the next batch's 0: tools/sim_fuzz_corrupt.py,
+    seed 188949; zlib: "invalid distance too far back", src/qatzip_sw.c:353-359 makes that QZ_DATA_ERROR)"""
+    seg_dt = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_cap", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
+    res_dt = np.dtype([("status", "<i4"), ("in_used", "<u4"), ("out_len", "<u4"), ("nblocks", "<u4")])
+    sim.sim_inflate_spec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    n = 14012
+    src = datagen.gen_bytes("runs", n, 9000 + 188949)
+    co = zlib.compressobj(1, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)      # (fixed codes: a flipped bit in a distance's extra bits stays a distance)
+    good = co.compress(src) + co.flush()
+    too_far = accepted = 0
+    for at in range(len(good) * 55 // 100, len(good) - 1):
+        for bit in range(8):
+            comp = bytearray(good); comp[at] ^= 1 << bit; comp = bytes(comp)
+            want, why = None, ""
+            try:
+                d = zlib.decompressobj(-15)
+                o = d.decompress(comp, n + 1)
+                if d.eof and len(o) == n:
+                    want = o
+            except zlib.error as e:
+                why = str(e)
+            if "too far back" not in why:
+                continue
+            for K in (4, 8):
+                cbuf = np.frombuffer(comp + b"\0" * 64, np.uint8).copy(); obuf = np.full(n + 64, 0xAA, np.uint8)
+                sa = np.array([(0, 0, len(comp), n, 0, len(comp))], dtype=seg_dt); res = np.zeros(1, res_dt)
+                sim.sim_inflate_spec(cbuf.ctypes.data, obuf.ctypes.data, sa.ctypes.data, res.ctypes.data, 1, K)
+                assert bytes(obuf[n:]) == b"\xaa" * 64, (at, bit, K)
+                if res[0]["status"] >= 0 and res[0]["out_len"] == n:
+                    assert want is not None and bytes(obuf[:n]) == want, (at, bit, K, why)
+                    accepted += 1
+                elif "too far back" in why:
+                    too_far += 1
+    assert too_far > 500 and accepted == 0, (too_far, accepted)
+
+
 def test_damaged_streams_end_in_an_error_or_in_zlibs_own_bytes(sim):
     """a decoder must never crash, hang or write outside its output: a segment with flipped bits (most of them in the block
     header, which is decoded in LDS and registers since round 4) or cut short is reported as an error - or, when zlib decodes
