@@ -120,7 +120,9 @@ def _lzmix(n, g):
             ln = int(g.choice([3, 4, 5, 6, 7, 8, 9, int(g.integers(3, 40)), int(g.integers(3, 600)), 258, 259, 257]))
             ln = min(ln, n - pos)
             for i in range(ln):                       # overlapping copies need the byte loop
-                out[pos + i] = out[pos + i - d]
+                k = pos + i - d                       # (the fixed distances 1..4 may reach before the start when pos < 4: numpy
+                out[pos + i] = out[k] if k >= -n else 0   #  then reads from the end - kept as it is, every seed's bytes are what
+                                                      #  they were - except where that index does not exist: n = 2, 3)
             pos += ln
         else:
             ln = min(int(g.integers(1, 24)), n - pos)
