@@ -31,6 +31,14 @@
  *     folded from the same dwords as they enter the ring.
  *   - zlib's window slide (strstart >= 65274 => rebase by 32768, NIL==0) is
  *     reproduced literally, so chunks up to 512 KiB and odd tail sizes match.
+ *   - round 6: a wave keeps the table entries it touched last in LDS (QZK_CNB of them, direct-mapped on a
+ *     multiplicative mix of the hash, 12 bytes each: the hash + four 16-bit window positions).  The kernel is bound by
+ *     the rate of 64-byte requests on a table no cache holds (4 GiB per device) and asks for every position of the input;
+ *     but most positions lie inside matches - text that was seen before, so their hashes were seen before too - and the
+ *     entry a lane needs is the one some lane of this wave read or wrote a few hundred bytes ago.  The cache is
+ *     write-through and always equal to the table (every insert of a hash whose entry it holds goes through the
+ *     commit below, which rewrites or replaces the entry), so a hit answers exactly what the gather would have:
+ *     CPU model on the bench data (tools/k1_cache_model.c): 256 entries take 44-48 % of the gathers, 512 take 51-55 %.
  */
 #ifndef QZK_DEFLATE_LZ77_H
 #define QZK_DEFLATE_LZ77_H
@@ -47,8 +55,20 @@
 #define QZK_NICE 8
 #define QZK_MAXINS 4
 #define QZK_HSIZE 65536            /* zlib hash_bits 16 at memLevel 9 */
+#ifndef QZK_CNBLOG
+#define QZK_CNBLOG 8               /* log2 of the entries of a wave's LDS cache of table entries (below); -1: none */
+#endif
+#if QZK_CNBLOG >= 0
+#define QZK_CNB (1 << QZK_CNBLOG)
+#else
+#define QZK_CNB 0
+#endif
 #ifndef QZK_NSLOT
+#if QZK_CNB
+#define QZK_NSLOT 256              /* the cache takes half of what the slot tables had: sixteen waves per CU still fit */
+#else
 #define QZK_NSLOT 512
+#endif
 #endif
 #ifndef QZK_RING
 #define QZK_RING 4096              /* bytes of recent input kept in LDS */
@@ -57,10 +77,14 @@
 #define QZK_K1_OCC 1               /* workgroups per CU the register budget is cut for */
 #endif
 #define QZK_RINGW (QZK_RING / 4)
-#ifndef QZK_NSLOT2
-#define QZK_NSLOT2 256              /* second slot table, keyed by the hash's high bits */
+#ifndef QZK_NSLOT2                  /* second slot table, keyed by the hash's high bits */
+#if QZK_CNB
+#define QZK_NSLOT2 128
+#else
+#define QZK_NSLOT2 256
 #endif
-#define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW + QZK_NSLOT2)   /* words of LDS one wave's parse needs */
+#endif
+#define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW + QZK_NSLOT2 + 3 * QZK_CNB)   /* words of LDS one wave's parse needs */
 #ifndef QZK_K1_WAVES
 #define QZK_K1_WAVES 16            /* waves per K1 workgroup, one chunk each; they share the lines of the candidate table */
 #endif
@@ -179,6 +203,14 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
      *     drags a 128-byte line through L2 for 16 bytes, three quarters of them less than 4 KiB back; with a dozen
      *     waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
     uint32_t *const slot = lds, *const scnt = lds + QZK_NSLOT, *const ring = lds + 2 * QZK_NSLOT, *const slot2 = ring + QZK_RINGW;
+#if QZK_CNB
+    /* the cache of table entries: ctag[s] = hash | 1 << 16 of the entry held (anything else: none - the commit's election
+     * leaves its marks here), cpos[s], cpos[QZK_CNB + s] = its four positions, newest first, as 16-bit offsets from the
+     * window origin `base` (0 = none: zlib's NIL; what has slid out of the window is NIL to every later lookup) */
+    uint32_t *const ctag = slot2 + QZK_NSLOT2, *const cpos = ctag + QZK_CNB;
+#pragma nounroll
+    for (uint32_t i = (uint32_t)qz_lane(); i < QZK_CNB; i += 64) ctag[i] = 0;
+#endif
     uint32_t rhi = 0;                      /* chunk offset the ring is filled up to (multiple of 256) */
     uint32_t crc_acc = 0;                  /* this lane's share of the chunk's CRC-32 (crcT != NULL) */
     uint32_t rnext = qzk_ld32g_fast(src, (uint64_t)chunk * chunk_sz + 4 * (uint32_t)qz_lane(), src_len);   /* my dword of the row at rhi */
@@ -241,6 +273,19 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 /* zlib slide_hash(): positions at or below the new origin become NIL - here by the `> base` test of the
                  * lookup (offsets are chunk-absolute), no pass over the table */
                 base += QZK_WSIZE;
+#if QZK_CNB
+                /* the cached positions count from the window origin: move them with it */
+                qz_lds_sync();
+#pragma nounroll
+                for (uint32_t i = (uint32_t)lane; i < 2 * QZK_CNB; i += 64) {
+                    /* (signed arithmetic: written as a saturating subtraction of the two halves, this loop crashes the
+                     * compiler's instruction selection once it has sixteen trips) */
+                    const uint32_t v = cpos[i];
+                    const int a = (int)(v & 0xffffu) - QZK_WSIZE, b = (int)(v >> 16) - QZK_WSIZE;
+                    cpos[i] = (uint32_t)(a > 0 ? a : 0) | (uint32_t)(b > 0 ? b : 0) << 16;
+                }
+                qz_lds_sync();
+#endif
             }
             if (avail_in) {
                 uint32_t more = 65536u - (fill - base);
@@ -293,10 +338,26 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         /* the previous window's table stores are ahead of this gather in the wave's memory stream (same wave, same CU) */
         qz_lds_sync();
         qzk_u32x4 ev = {0, 0, 0, 0};
+#if QZK_CNB
+        /* the entry may be in the wave's cache: only the lanes that miss ask the table */
+        const uint32_t cset = ((h * 40503u) >> (16 - QZK_CNBLOG)) & (QZK_CNB - 1);
+        const uint32_t ct = ctag[cset], cp0 = cpos[cset], cp1 = cpos[QZK_CNB + cset];
+        const bool chit = canh && ct == (h | 0x10000u);
+        QZK_C(8, (uint64_t)qz_popc64(qz_ballot(chit)) << 32);      /* profiling builds: cache hits in the high half of the window count */
+        if (canh && !chit) ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_WAVES]);
+        const bool ev_ok = ev[3] == epoch;                /* another chunk's entry: as good as empty */
+        uint32_t q0 = ev_ok ? ev[0] & 0xffffffu : 0, q1 = ev_ok ? (ev[0] >> 24) | ((ev[1] & 0xffffu) << 8) : 0,
+                 q2 = ev_ok ? (ev[1] >> 16) | ((ev[2] & 0xffu) << 16) : 0, q3 = ev_ok ? ev[2] >> 8 : 0;   /* chunk offsets, 0 = none */
+        if (chit) {
+            q0 = (cp0 & 0xffffu) ? base + (cp0 & 0xffffu) : 0; q1 = (cp0 >> 16) ? base + (cp0 >> 16) : 0;
+            q2 = (cp1 & 0xffffu) ? base + (cp1 & 0xffffu) : 0; q3 = (cp1 >> 16) ? base + (cp1 >> 16) : 0;
+        }
+#else
         if (canh) ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_WAVES]);
         const bool ev_ok = ev[3] == epoch;                /* another chunk's entry: as good as empty */
         const uint32_t q0 = ev_ok ? ev[0] & 0xffffffu : 0, q1 = ev_ok ? (ev[0] >> 24) | ((ev[1] & 0xffffu) << 8) : 0,
                        q2 = ev_ok ? (ev[1] >> 16) | ((ev[2] & 0xffu) << 16) : 0, q3 = ev_ok ? ev[2] >> 8 : 0;   /* chunk offsets, 0 = none */
+#endif
         /* chained candidates must lie above zlib's `limit` (window coordinates: strstart - MAX_DIST or NIL = 0) */
         const uint32_t lo = base + (p > QZK_MAXDIST ? p - QZK_MAXDIST : 0);
         const int maxlen = avail < 258 ? avail : 258;
@@ -550,6 +611,29 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             const qzk_u32x4 e = {n0 | (n1 << 24), (n1 >> 8) | (n2 << 16), (n2 >> 16) | (n3 << 8), epoch};
             *(qzk_u32x4 *)&tab[(size_t)bucket * QZK_K1_WAVES] = e;
         }
+#if QZK_CNB
+        {
+            /* the cache follows the table: a lane that stores its bucket's new entry puts it into the cache as well, and a
+             * lane that had to ask the table leaves the answer there (its bucket unchanged by this window - had any lane
+             * of the window entered the hash, that bucket's storing lane would be on the same cache entry and go first).
+             * One winner per cache entry: the lanes mark it - the askers, then the storing lanes over them - and who
+             * reads his own mark back writes all three words.  An entry that is marked is always rewritten, so whatever
+             * the cache holds afterwards is what the table holds. */
+            const bool ralloc = canh && !chit && !isI;
+            const uint32_t mark = (store ? 0x20040u : 0x20000u) | (uint32_t)lane;
+            if (ralloc) ctag[cset] = mark;
+            qz_lds_sync();
+            if (store) ctag[cset] = mark;
+            qz_lds_sync();
+            if ((store || ralloc) && ctag[cset] == mark) {
+                const uint32_t e0 = store ? n0 : q0, e1 = store ? n1 : q1, e2 = store ? n2 : q2, e3 = store ? n3 : q3;
+                const uint32_t r0 = e0 > base ? e0 - base : 0, r1 = e1 > base ? e1 - base : 0, r2 = e2 > base ? e2 - base : 0,
+                               r3 = e3 > base ? e3 - base : 0;
+                cpos[cset] = r0 | r1 << 16; cpos[QZK_CNB + cset] = r2 | r3 << 16;
+                ctag[cset] = h | 0x10000u;
+            }
+        }
+#endif
         pos += (uint32_t)l;
         QZK_T(12);
     }

@@ -28,7 +28,7 @@ def _bench_buffer(ctx, total, seed=20250523):
     return d_src
 
 
-def _check_sampled_chunks(ctx, d_src, d_dst, total, n_out, crcs, nsample, seed):
+def _check_sampled_chunks(ctx, d_src, d_dst, total, n_out, crcs, nsample, seed, CHUNK=CHUNK):
     nch = (total + CHUNK - 1) // CHUNK
     lens = np.zeros(nch, np.uint32)
     ctx._chk(ctx.L.qzd_chunk_lens(ctx.h, lens.ctypes.data, nch))
@@ -88,8 +88,75 @@ def test_one_4GiB_call_per_direction_is_what_the_bench_times():
     d_back = ctx.alloc(total)
     iu, ol, crc = ctx.inflate_stream(d_dst, n_out, d_back, CHUNK, want_crc=True)
     assert iu == n_out and ol == total and crc == want
-    print("4 GiB call: %d chunk streams byte-identical to the oracle's, stream CRC and round trip equal" % checked)
+    rng = np.random.Generator(np.random.PCG64(4))
+    for k in [0, 1, total // CHUNK - 2, total // CHUNK - 1] + [int(x) for x in rng.integers(0, total // CHUNK, 256)]:
+        assert np.array_equal(d_back.download(CHUNK, k * CHUNK), d_src.download(CHUNK, k * CHUNK)), ("decoded chunk", k)
+    print("4 GiB call: %d chunk streams byte-identical to the oracle's, stream CRC, round trip and 260 decoded chunks equal" % checked)
     for b in (d_src, d_dst, d_back):
+        b.free()
+    ctx.close()
+
+
+@pytest.mark.parametrize("chunk", [16384, 131072])
+def test_raw_sweep_at_call_scale(chunk):
+    """BASELINE config 3 at the size the bench runs it: 1 GiB of QZ_DEFLATE_RAW at hw_buff_sz 16 KB (65536 segments: the
+    decoder's default rule gives each four lanes) and 128 KB (8192 segments of sixteen lanes) - sampled chunk streams
+    against the oracle, the stream's CRC from the chunks', the round trip through the default decode path (no environment
+    override), sampled decoded chunks against the input"""
+    import qatzip_amd
+    ctx = qatzip_amd.Context(0)
+    total = 1 << 30
+    d_src = _bench_buffer(ctx, total)
+    d_dst = ctx.alloc(qatzip_amd.max_deflate_len(total, chunk))
+    n_out, crcs = ctx.deflate_raw(d_src, total, chunk, 1, 1, d_dst)
+    assert len(crcs) == total // chunk
+    checked = _check_sampled_chunks(ctx, d_src, d_dst, total, n_out, crcs, 192 if chunk < 65536 else 48, 5, CHUNK=chunk)
+    crcs = np.ascontiguousarray(crcs, np.uint32)
+    want = ctx.crc32(d_src, total)
+    assert ctx.L.qzd_crc32_fold(crcs.ctypes.data, len(crcs), chunk, total) == want
+    d_back = ctx.alloc(total)
+    iu, ol, crc = ctx.inflate_stream(d_dst, n_out, d_back, chunk, want_crc=True)
+    assert iu == n_out and ol == total and crc == want
+    rng = np.random.Generator(np.random.PCG64(6))
+    nch = total // chunk
+    for k in [0, 1, nch - 2, nch - 1] + [int(x) for x in rng.integers(0, nch, 128)]:
+        assert np.array_equal(d_back.download(chunk, k * chunk), d_src.download(chunk, k * chunk)), ("decoded chunk", k)
+    print("1 GiB RAW at %d: %d chunk streams byte-identical to the oracle's, round trip equal" % (chunk, checked))
+    for b in (d_src, d_dst, d_back):
+        b.free()
+    ctx.close()
+
+
+def test_lz4_frames_at_call_scale():
+    """BASELINE config 4 at the bench's size: 1 GiB as 16384 LZ4 frames of one 64 KB block with content size and XXH32 -
+    sampled frames against the oracle's LZ4F_compressFrame, every frame decoded (XXH32 verified in-kernel), the output's
+    CRC-32 and sampled blocks against the input"""
+    import qatzip_amd
+    ctx = qatzip_amd.Context(0)
+    total = 1 << 30
+    nfr = total // CHUNK
+    d_src = _bench_buffer(ctx, total)
+    d_c = ctx.alloc(total + nfr * 64 + 4096)
+    cl, lens = ctx.lz4_compress_frames(d_src, total, d_c, CHUNK)
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    assert int(offs[-1]) == cl
+    rng = np.random.Generator(np.random.PCG64(7))
+    pick = sorted(set([0, 1, nfr - 2, nfr - 1]) | set(int(x) for x in rng.integers(0, nfr, 384)))
+    for k in pick:
+        plain = d_src.download(CHUNK, k * CHUNK).tobytes()
+        got = d_c.download(int(lens[k]), int(offs[k])).tobytes()
+        assert got == O.sw_compress("LZ4", plain, CHUNK, 1, cap=CHUNK + 200)[2], ("frame", k)
+    segs = np.zeros(nfr, qatzip_amd._lib.LZ4SEG_DT)
+    segs["in_off"] = offs[:-1]; segs["out_off"] = np.arange(nfr, dtype=np.int64) * CHUNK; segs["in_len"] = lens; segs["out_cap"] = CHUNK
+    res = np.zeros(nfr, qatzip_amd._lib.LZ4RES_DT)
+    d_back = ctx.alloc(total)
+    ctx._chk(ctx.L.qzd_lz4_decompress_frames(ctx.h, d_c.ptr, d_back.ptr, segs.ctypes.data, nfr, res.ctypes.data))
+    assert (res["status"] == 0).all() and (res["out_len"] == CHUNK).all() and (res["in_used"] == lens).all()
+    assert ctx.crc32(d_back, total) == ctx.crc32(d_src, total)
+    for k in pick[::3]:
+        assert np.array_equal(d_back.download(CHUNK, k * CHUNK), d_src.download(CHUNK, k * CHUNK)), ("decoded block", k)
+    print("1 GiB of LZ4 frames: %d frames byte-identical to the oracle's, all decoded, CRC equal" % len(pick))
+    for b in (d_src, d_c, d_back):
         b.free()
     ctx.close()
 

@@ -47,7 +47,10 @@ def main():
     buf = np.zeros(nchunks * 64, np.uint64)
     sz = L.qzd_debug_meta(h, 0, buf.ctypes.data, nchunks)
     m = buf.view(np.uint8)[:nchunks * sz].reshape(nchunks, sz)
-    prof = m[:, sz - 128:].copy().view(np.uint64).reshape(nchunks, 16).astype(np.float64)
+    raw = m[:, sz - 128:].copy().view(np.uint64).reshape(nchunks, 16)
+    hits = (raw[:, 8] >> np.uint64(32)).astype(np.float64)          # round 6: hits of the LDS entry cache ride in the window count's high half
+    raw[:, 8] &= np.uint64(0xffffffff)
+    prof = raw.astype(np.float64)
     tot = prof.mean(0)
     names = ["top/tail", "own loads", "chain walk", "cand compares", "slot detect", "serial hops", "exact path",
              "epilogue syms", "windows", "complex lanes", "suspect commits", "symbols", "commit"]
@@ -58,6 +61,7 @@ def main():
         print("  %-16s %12.0f ticks/chunk  %5.1f %%  %8.1f /window" % (names[k], tot[k], 100 * tot[k] / cyc, tot[k] / tot[8]))
     print("  windows/chunk %.0f  complex lanes/window %.2f  suspect commits/window %.2f  symbols/window %.1f"
           % (tot[8], tot[9] / tot[8], tot[10] / tot[8], tot[11] / tot[8]))
+    print("  LDS entry cache: %.1f hits/window (of 64 lookups)" % (hits.mean() / tot[8]))
     print("  exact path: %.2f lanes/window, of which %.2f leave at the first test (no earlier lane with the hash, nothing to extend)"
           % (tot[9] / tot[8], tot[15] / tot[8]))
     print("  K2 in the wave: %.0f ticks/chunk (%.1f %% on top of the parse), of which the serial tree build %.0f"
