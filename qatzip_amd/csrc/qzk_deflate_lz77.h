@@ -63,6 +63,12 @@
 #else
 #define QZK_CNB 0
 #endif
+#ifndef QZK_PF
+#define QZK_PF (QZK_CNB ? 1 : 0)   /* the next window's table entries are asked for while this window is resolved (needs the cache) */
+#endif
+#ifndef QZK_PF_MINL
+#define QZK_PF_MINL 30             /* ... and a window whose first lane without an entry comes earlier than this asks the table itself */
+#endif
 #ifndef QZK_NSLOT
 #if QZK_CNB
 #define QZK_NSLOT 256              /* the cache takes half of what the slot tables had: sixteen waves per CU still fit */
@@ -112,6 +118,35 @@ QZ_DEV qzk_u32x4 qzk_ld_bkt(const qzk_bkt *p)
 #endif
 }
 
+/* The same entry asked for AHEAD of its use (round 6: the next window's entries travel while this window is resolved).
+ * The compiler cannot be told: a load it counts is waited for at the next `s_waitcnt vmcnt(0)` it places for any load it
+ * cannot count exactly - the candidate compares' and the exact path's conditional ones, every window.  So the load is the
+ * kernel's own (the compiler sees the registers as written here) and so is the wait, at the next window's top, before the
+ * first read; between the two nothing may touch v: it is only ever passed from the one statement to the other
+ * (tools/k1_pf_audit.py checks the built code object for exactly that). */
+QZ_DEV void qzk_ld_bkt_ahead(qzk_u32x4 *v, const qzk_bkt *p)
+{
+#ifdef QZ_SIM
+    *v = *(const qzk_u32x4 *)p;
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(*v) : "v"(p) : "memory");
+#endif
+}
+QZ_DEV void qzk_wait_ahead(qzk_u32x4 *v)
+{
+#ifdef QZ_SIM
+    (void)v;
+#else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(*v) : : "memory");
+#endif
+}
+
+#ifdef QZ_SIM                       /* the emulator's tests want to know that the windows they ran took the new path */
+static unsigned long qzk_sim_count[2];         /* [0] windows that asked the table themselves, [1] windows */
+#define QZK_SIMC(k) do { if (qz_lane() == 0) qzk_sim_count[k]++; } while (0)
+#else
+#define QZK_SIMC(k) do { } while (0)
+#endif
 #if defined(QZK_PROF) && !defined(QZ_SIM)
 #define QZK_T(k) do { uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; } while (0)
 #define QZK_C(k, v) do { prof[k] += (uint64_t)(v); } while (0)
@@ -127,7 +162,7 @@ typedef struct {
     uint32_t can_store;            /* bit k: zlib could still emit block k as stored (block_start >= 0) */
     uint32_t n;                    /* chunk length */
 #ifdef QZK_PROF
-    uint64_t prof[16];             /* per-phase cycles / counters (profiling builds only) */
+    uint64_t prof[24];             /* per-phase cycles / counters (profiling builds only) */
 #endif
 } qzk_lzmeta;
 
@@ -261,8 +296,32 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     uint32_t pos = 0;                               /* next parse point (chunk offset) */
     uint32_t nsym = 0, nfull = 0, cur_bstart = 0, can_store = 0;
     mt->bstart[0] = 0;                              /* wave-uniform values: every lane stores the same word */
+#if QZK_PF
+    /* entries asked for a window ahead: lane i holds the entry of chunk offset pf_base + i as the table had it BEFORE the
+     * commit of the window that asked (pf_okm: lanes that hold one; pf_base = that window's start + its `lim`, where the
+     * next one starts unless its last symbol overshoots).  A bucket that commit stores makes the entry held here out of
+     * date (only the cache has the new one), and "was my bucket stored" must never be answered with a wrong no: every
+     * storing lane leaves pf_mark | bucket in slot[] under the low bits of its hash or, if a lane with another hash got
+     * there first, in scnt[] under the high bits (both tables are free between two windows' detection phases); a lane
+     * that finds both places taken sets pf_lost, and the next window asks the table itself as every window used to. */
+    qzk_u32x4 pf = {0, 0, 0, 0};
+    uint64_t pf_okm = 0;
+    uint32_t pf_base = 0, pf_mark = 0, wcount = 0;
+    bool pf_lost = false;
+    /* ... and the window's own stores - its symbols, its table entries - wait in registers until the next window has made
+     * its one wait for what was asked ahead: a store issued at the window's end would be the youngest thing that wait
+     * waits for (the counter is one for loads and stores), and the store's way to the L2 and back is as long as a load's */
+    uint64_t dPm = 0, dSTm = 0;
+    uint32_t dnsym = 0, dv_sym = 0, dv_h = 0, dv_e0 = 0, dv_e1 = 0, dv_e2 = 0;
+#define QZK_DEFERRED_STORES() do { \
+        if ((dPm >> lane) & 1) { const uint32_t i_ = dnsym + (uint32_t)qz_popc64(dPm & qz_below(lane)); \
+                                 olc[i_] = (uint8_t)dv_sym; odist[i_] = (uint16_t)(dv_sym >> 8); } \
+        if ((dSTm >> lane) & 1) { const qzk_u32x4 e_ = {dv_e0, dv_e1, dv_e2, epoch}; *(qzk_u32x4 *)&tab[(size_t)dv_h * QZK_K1_WAVES] = e_; } \
+        dPm = 0; dSTm = 0; } while (0)
+    bool pf_live = false;
+#endif
 #if defined(QZK_PROF) && !defined(QZ_SIM)
-    uint64_t prof[16] = {0}; uint64_t tprev = __builtin_readcyclecounter();
+    uint64_t prof[24] = {0}; uint64_t tprev = __builtin_readcyclecounter();
 #endif
 
     for (;;) {
@@ -297,6 +356,12 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         }
 
         QZK_T(0); QZK_C(8, 1);
+#if QZK_PF
+        qzk_wait_ahead(&pf);                            /* the one wait of a window that need not ask the table itself (unconditional: tools/k1_pf_audit.py follows every path) */
+        QZK_T(17);
+        QZK_DEFERRED_STORES();
+        QZK_T(18);
+#endif
         /* ---- speculative phase: all 64 lanes ---- */
         const uint32_t B = pos - base;                  /* window position of lane 0 */
         const uint32_t p = B + (uint32_t)lane;          /* my window position */
@@ -332,6 +397,21 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         const uint32_t bucket = h;
         const uint32_t key = h & (QZK_NSLOT - 1);
 
+        /* how far this window's parse may go (wave-uniform) */
+        int nvalid = look < 64 ? (int)look : 64;
+        int lim = nvalid < QZK_WLIM ? nvalid : QZK_WLIM;
+        {   /* stop before a parse point where zlib would slide / refill its window */
+            int lstop;
+            int first_short = (int)look - (QZK_MINLOOK - 1);       /* first l with lookahead < 262 */
+            if (first_short < 0) first_short = 0;
+            if (avail_in) lstop = first_short;
+            else {
+                int sl = (int)(QZK_WSIZE + QZK_MAXDIST) - (int)B;
+                lstop = first_short > sl ? first_short : sl;
+            }
+            if (lstop < 1) lstop = 1;
+            if (lim > lstop) lim = lstop;
+        }
         QZK_T(1);
         /* candidates as of the window start: one 16-byte gather; first candidate needs dist <= MAX_DIST, chained ones
          * cur_match > limit (zlib's asymmetry), and the chain ends at the first one that fails */
@@ -344,7 +424,38 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         const uint32_t ct = ctag[cset], cp0 = cpos[cset], cp1 = cpos[QZK_CNB + cset];
         const bool chit = canh && ct == (h | 0x10000u);
         QZK_C(8, (uint64_t)qz_popc64(qz_ballot(chit)) << 32);      /* profiling builds: cache hits in the high half of the window count */
+#if QZK_PF
+        /* what the window before asked for, moved down by the lanes its last symbol overshot; a lane neither the cache nor
+         * that serves ends the window three lanes early (the interior of a short match must have its entry too) - unless it
+         * comes so early that asking the table now, as every window used to, is the better deal */
+        bool evhave = false;
+        int limdata = 64;
+        {
+            const uint32_t sh = pos - pf_base;
+            if (pf_live && !pf_lost && sh < 64u - (QZK_PF_MINL + 3)) {
+                const int sl = lane + (int)sh;
+                const uint32_t a0 = qz_shfl(pf[0], sl), a1 = qz_shfl(pf[1], sl), a2 = qz_shfl(pf[2], sl), a3 = qz_shfl(pf[3], sl);
+                if (canh && !chit && sl < 64 && ((pf_okm >> (sl & 63)) & 1) && slot[key] != (pf_mark | h) && scnt[(h >> 8) & (QZK_NSLOT - 1)] != (pf_mark | h)) {
+                    ev[0] = a0; ev[1] = a1; ev[2] = a2; ev[3] = a3; evhave = true;
+                }
+            }
+            const bool lack = canh && !chit && !evhave;
+            const uint64_t LACK = qz_ballot(lack);
+            if (LACK) {
+                const int fl = qz_ctz64(LACK);
+                if (fl < QZK_PF_MINL + 3) { if (lack) { ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_WAVES]); evhave = true; } QZK_C(15, 1ull << 32); QZK_SIMC(0); }
+                else limdata = fl - 3;
+            }
+        }
+#else
+        const bool evhave = canh && !chit;
         if (canh && !chit) ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_WAVES]);
+#endif
+#if QZK_PF
+        if (lim > limdata) lim = limdata;
+        QZK_SIMC(1);
+#endif
+        QZK_T(16);
         const bool ev_ok = ev[3] == epoch;                /* another chunk's entry: as good as empty */
         uint32_t q0 = ev_ok ? ev[0] & 0xffffffu : 0, q1 = ev_ok ? (ev[0] >> 24) | ((ev[1] & 0xffffu) << 8) : 0,
                  q2 = ev_ok ? (ev[1] >> 16) | ((ev[2] & 0xffu) << 16) : 0, q3 = ev_ok ? ev[2] >> 8 : 0;   /* chunk offsets, 0 = none */
@@ -433,20 +544,26 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 
         QZK_T(4);
         /* ---- serial resolution (wave-uniform) ---- */
-        int nvalid = look < 64 ? (int)look : 64;
-        int lim = nvalid < QZK_WLIM ? nvalid : QZK_WLIM;
-        {   /* stop before a parse point where zlib would slide / refill its window */
-            int lstop;
-            int first_short = (int)look - (QZK_MINLOOK - 1);       /* first l with lookahead < 262 */
-            if (first_short < 0) first_short = 0;
-            if (avail_in) lstop = first_short;
-            else {
-                int sl = (int)(QZK_WSIZE + QZK_MAXDIST) - (int)B;
-                lstop = first_short > sl ? first_short : sl;
-            }
-            if (lstop < 1) lstop = 1;
-            if (lim > lstop) lim = lstop;
+#if QZK_PF
+        {
+            /* ask for the next window's entries now: the resolution below, the symbols and the commit (half of a window's
+             * clocks) run while they are on their way.  The parse leaves this window at or behind pos + lim. */
+            pf_base = pos + (uint32_t)lim; pf_live = true;
+            pf_mark = 0x80000000u | wcount << 16; wcount = (wcount + 1) & 0x7fffu;
+            const uint32_t ppa = pf_base + (uint32_t)lane;
+            const bool pcanh = ppa + 3 <= fill;
+            const uint32_t pw = QZK_RING4(ppa);
+            const uint32_t ph = (((pw & 0xf) << 12) ^ (((pw >> 8) & 0xff) << 6) ^ ((pw >> 16) & 0xff)) & 0xffff;
+            const uint32_t ps = ((ph * 40503u) >> (16 - QZK_CNBLOG)) & (QZK_CNB - 1);
+            const uint32_t pct = ctag[ps], pc0 = cpos[ps], pc1 = cpos[QZK_CNB + ps];
+            /* a cached entry in the table's own format (this window's commit may replace it in the cache) */
+            const uint32_t g0 = (pc0 & 0xffffu) ? base + (pc0 & 0xffffu) : 0, g1 = (pc0 >> 16) ? base + (pc0 >> 16) : 0,
+                           g2 = (pc1 & 0xffffu) ? base + (pc1 & 0xffffu) : 0, g3 = (pc1 >> 16) ? base + (pc1 >> 16) : 0;
+            pf[0] = g0 | (g1 << 24); pf[1] = (g1 >> 8) | (g2 << 16); pf[2] = (g2 >> 16) | (g3 << 8); pf[3] = epoch;
+            if (pcanh && pct != (ph | 0x10000u)) qzk_ld_bkt_ahead(&pf, &tab[(size_t)ph * QZK_K1_WAVES]);
+            pf_okm = qz_ballot(pcanh);
         }
+#endif
         uint64_t Pm = 0;
         uint64_t SHm = qz_ballot(mlen >= 3 && mlen <= QZK_MAXINS && avail - (int)mlen >= 3), S4m = qz_ballot(mlen == 4);
         int l = 0;
@@ -476,11 +593,11 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 /* early out: no earlier lane of this window carries the hash and nothing needs extending =>
                  * the speculative answer is already exact */
                 const uint64_t earlier = qz_ballot(canh && h == h_l) & qz_below(l);
+                const uint32_t ml_l = qz_readlane(mlen, l);
                 if (earlier == 0 && !((CAPM >> l) & 1)) {
                     QZK_C(15, 1);
                     Pm |= 1ull << l;
-                    uint32_t ml = qz_readlane(mlen, l);
-                    l += ml ? (int)ml : 1;
+                    l += ml_l ? (int)ml_l : 1;
                     QZK_T(6);
                     continue;
                 }
@@ -556,8 +673,12 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         const uint32_t idx = nsym + rank;
         const uint32_t step = mlen ? mlen : 1;
         if (isP) {
+#if QZK_PF
+            dv_sym = (mlen ? mlen - 3 : (w0 & 0xff)) | mdist << 8;
+#else
             olc[idx] = (uint8_t)(mlen ? mlen - 3 : (w0 & 0xff));
             odist[idx] = (uint16_t)mdist;
+#endif
         }
         {   /* a symbol that completes a 32767-symbol block (at most one per window) */
             const bool closes = isP && ((idx + 1) % QZK_LITBUF == 0);
@@ -571,6 +692,9 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 if (nfull < QZK_MAXBLK) mt->bstart[nfull] = nb;
             }
         }
+#if QZK_PF
+        dPm = Pm; dnsym = nsym;
+#endif
         nsym += (uint32_t)qz_popc64(Pm);
 
         QZK_T(7);
@@ -607,10 +731,15 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
                 if (((same >> lane) & 1) && lane < j) store = false;
             }
         }
+#if QZK_PF
+        dSTm = qz_ballot(store); dv_h = bucket;
+        dv_e0 = n0 | (n1 << 24); dv_e1 = (n1 >> 8) | (n2 << 16); dv_e2 = (n2 >> 16) | (n3 << 8);
+#else
         if (store) {
             const qzk_u32x4 e = {n0 | (n1 << 24), (n1 >> 8) | (n2 << 16), (n2 >> 16) | (n3 << 8), epoch};
             *(qzk_u32x4 *)&tab[(size_t)bucket * QZK_K1_WAVES] = e;
         }
+#endif
 #if QZK_CNB
         {
             /* the cache follows the table: a lane that stores its bucket's new entry puts it into the cache as well, and a
@@ -619,8 +748,19 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
              * One winner per cache entry: the lanes mark it - the askers, then the storing lanes over them - and who
              * reads his own mark back writes all three words.  An entry that is marked is always rewritten, so whatever
              * the cache holds afterwards is what the table holds. */
-            const bool ralloc = canh && !chit && !isI;
+            const bool ralloc = evhave && !isI;
             const uint32_t mark = (store ? 0x20040u : 0x20000u) | (uint32_t)lane;
+#if QZK_PF
+            {   /* what was asked ahead for a stored bucket is out of date now */
+                const uint32_t mk = pf_mark | h, key3 = (h >> 8) & (QZK_NSLOT - 1);
+                if (store) slot[key] = mk;
+                qz_lds_sync();
+                const bool second = store && slot[key] != mk;
+                if (second) scnt[key3] = mk;
+                qz_lds_sync();
+                pf_lost = qz_ballot(second && scnt[key3] != mk) != 0;
+            }
+#endif
             if (ralloc) ctag[cset] = mark;
             qz_lds_sync();
             if (store) ctag[cset] = mark;
@@ -638,6 +778,11 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         QZK_T(12);
     }
 
+#if QZK_PF
+    qzk_wait_ahead(&pf);                                /* nothing of this chunk's may still be on its way into a register */
+    QZK_DEFERRED_STORES();
+#undef QZK_DEFERRED_STORES
+#endif
     if (crcT) {
         /* a last match may have carried the parse to the end of the chunk past rows the ring never asked for */
         for (; rhi < n; rhi += 256) {
@@ -663,7 +808,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     if (cur_bstart >= base) can_store |= 1u << nfull;
     mt->nsym = nsym; mt->nfull = nfull; mt->can_store = can_store; mt->n = n;      /* uniform, all lanes */
 #if defined(QZK_PROF) && !defined(QZ_SIM)
-    for (int k = 0; k < 16; k++) mt->prof[k] = prof[k];
+    for (int k = 0; k < 24; k++) mt->prof[k] = prof[k];
 #endif
 #undef QZK_RING16
 #undef QZK_RING4

@@ -42,6 +42,9 @@ static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_
     g_k1_epoch += nchunks;
 }
 
+/* K1: [0] windows that asked the table themselves, [1] all windows - since the library was loaded */
+void sim_k1_counts(unsigned long *out) { out[0] = qzk_sim_count[0]; out[1] = qzk_sim_count[1]; }
+
 /* K1 only: symbols + meta of every chunk */
 int sim_lz77(const uint8_t *src, uint64_t n, uint32_t chunk_sz, uint8_t *lc, uint16_t *dist, qzk_lzmeta *meta)
 {

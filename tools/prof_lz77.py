@@ -47,26 +47,30 @@ def main():
     buf = np.zeros(nchunks * 64, np.uint64)
     sz = L.qzd_debug_meta(h, 0, buf.ctypes.data, nchunks)
     m = buf.view(np.uint8)[:nchunks * sz].reshape(nchunks, sz)
-    raw = m[:, sz - 128:].copy().view(np.uint64).reshape(nchunks, 16)
+    raw = m[:, sz - 192:].copy().view(np.uint64).reshape(nchunks, 24)
     hits = (raw[:, 8] >> np.uint64(32)).astype(np.float64)          # round 6: hits of the LDS entry cache ride in the window count's high half
     raw[:, 8] &= np.uint64(0xffffffff)
+    asked = (raw[:, 15] >> np.uint64(32)).astype(np.float64)        # windows that had to ask the table themselves (entries asked ahead: none / too few)
+    raw[:, 15] &= np.uint64(0xffffffff)
     prof = raw.astype(np.float64)
     tot = prof.mean(0)
-    names = ["top/tail", "own loads", "chain walk", "cand compares", "slot detect", "serial hops", "exact path",
-             "epilogue syms", "windows", "complex lanes", "suspect commits", "symbols", "commit"]
-    cyc = sum(tot[k] for k in (0, 1, 2, 3, 4, 5, 6, 7, 12))
+    names = ["top/tail", "own loads", "cand. loads issued", "cand compares", "slot detect", "serial hops", "exact path",
+             "epilogue syms", "windows", "complex lanes", "suspect commits", "symbols", "commit", "", "", "",
+             "entry lookup", "wait (asked ahead)", "deferred stores"]
+    PH = (0, 17, 18, 1, 16, 2, 3, 4, 5, 6, 7, 12)
+    cyc = sum(tot[k] for k in PH)
     print("kind=%s chunks=%d ratio=%.3f  lz77 %.2f ms huff %.2f ms  (clock ticks below are s_memtime units @100MHz?)"
           % (kind, nchunks, ol.value / n, ms[0], ms[1]))
-    for k in (0, 1, 2, 3, 4, 5, 6, 7, 12):
+    for k in PH:
         print("  %-16s %12.0f ticks/chunk  %5.1f %%  %8.1f /window" % (names[k], tot[k], 100 * tot[k] / cyc, tot[k] / tot[8]))
     print("  windows/chunk %.0f  complex lanes/window %.2f  suspect commits/window %.2f  symbols/window %.1f"
           % (tot[8], tot[9] / tot[8], tot[10] / tot[8], tot[11] / tot[8]))
-    print("  LDS entry cache: %.1f hits/window (of 64 lookups)" % (hits.mean() / tot[8]))
+    print("  LDS entry cache: %.1f hits/window (of 64 lookups); windows that asked the table themselves: %.1f %%" % (hits.mean() / tot[8], 100 * asked.mean() / tot[8]))
     print("  exact path: %.2f lanes/window, of which %.2f leave at the first test (no earlier lane with the hash, nothing to extend)"
           % (tot[9] / tot[8], tot[15] / tot[8]))
     print("  K2 in the wave: %.0f ticks/chunk (%.1f %% on top of the parse), of which the serial tree build %.0f"
           % (tot[13], 100 * tot[13] / cyc, tot[14]))
-    per = prof[:, [0, 1, 2, 3, 4, 5, 6, 7, 12]].sum(1)
+    per = prof[:, list(PH)].sum(1)
     print("  total ticks/chunk %.0f  (min %.0f  max %.0f)  => ideal %.2f ms at 256 CUs, 2.3 GHz"
           % (cyc, per.min(), per.max(), per.sum() / 256 / 2.3e6))
 
