@@ -31,14 +31,14 @@
  *     folded from the same dwords as they enter the ring.
  *   - zlib's window slide (strstart >= 65274 => rebase by 32768, NIL==0) is
  *     reproduced literally, so chunks up to 512 KiB and odd tail sizes match.
- *   - round 6: a wave keeps the table entries it touched last in LDS (QZK_CNB of them, direct-mapped on a
- *     multiplicative mix of the hash, 12 bytes each: the hash + four 16-bit window positions).  The kernel is bound by
- *     the rate of 64-byte requests on a table no cache holds (4 GiB per device) and asks for every position of the input;
- *     but most positions lie inside matches - text that was seen before, so their hashes were seen before too - and the
- *     entry a lane needs is the one some lane of this wave read or wrote a few hundred bytes ago.  The cache is
- *     write-through and always equal to the table (every insert of a hash whose entry it holds goes through the
- *     commit below, which rewrites or replaces the entry), so a hit answers exactly what the gather would have:
- *     CPU model on the bench data (tools/k1_cache_model.c): 256 entries take 44-48 % of the gathers, 512 take 51-55 %.
+ *   - round 6 (profiles/r6_k1_experiments.txt): two things tried against the table traffic stay in this file, compiled out.
+ *     QZK_CNBLOG >= 0: a wave keeps the table entries it touched last in LDS (direct-mapped on a multiplicative mix of the
+ *     hash, 12 bytes each: the hash + four 16-bit window positions; write-through and always equal to the table, so a hit
+ *     answers exactly what the gather would have).  Most positions lie inside matches - text seen before, whose hashes
+ *     were looked up a few hundred bytes ago: 256 entries take 44 % of the gathers (model and hardware agree) and 17 % of
+ *     the fetched bytes - and nothing of the launch's time.  QZK_PF on top: the next window's entries are asked for while
+ *     this window is resolved; the wait for them is 83 clocks a window, and the machinery costs more than the gather's
+ *     wait was.  A window is a chain of ~100 dependent LDS / cross-lane / scalar steps; memory is the smaller part of it.
  */
 #ifndef QZK_DEFLATE_LZ77_H
 #define QZK_DEFLATE_LZ77_H
@@ -56,7 +56,7 @@
 #define QZK_MAXINS 4
 #define QZK_HSIZE 65536            /* zlib hash_bits 16 at memLevel 9 */
 #ifndef QZK_CNBLOG
-#define QZK_CNBLOG 8               /* log2 of the entries of a wave's LDS cache of table entries (below); -1: none */
+#define QZK_CNBLOG (-1)            /* log2 of the entries of a wave's LDS cache of table entries; -1: none (the default: see the header) */
 #endif
 #if QZK_CNBLOG >= 0
 #define QZK_CNB (1 << QZK_CNBLOG)
@@ -71,7 +71,7 @@
 #endif
 #ifndef QZK_NSLOT
 #if QZK_CNB
-#define QZK_NSLOT 256              /* the cache takes half of what the slot tables had: sixteen waves per CU still fit */
+#define QZK_NSLOT 256              /* the cache takes half of what the slot tables had: sixteen waves per CU still fit (and cost 3 %) */
 #else
 #define QZK_NSLOT 512
 #endif
@@ -90,7 +90,7 @@
 #define QZK_NSLOT2 256
 #endif
 #endif
-#define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW + QZK_NSLOT2 + 3 * QZK_CNB)   /* words of LDS one wave's parse needs */
+#define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW + 4 + QZK_NSLOT2 + 3 * QZK_CNB)   /* words of LDS one wave's parse needs */
 #ifndef QZK_K1_WAVES
 #define QZK_K1_WAVES 16            /* waves per K1 workgroup, one chunk each; they share the lines of the candidate table */
 #endif
@@ -234,10 +234,10 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
      *   scnt[QZK_NSLOT]  per-window: number of lanes on the key
      *   slot2[QZK_NSLOT2] per-window: lowest lane on the hash's HIGH bits - a lane that has an earlier lane with its hash
      *     has one on both keys; half of the lanes the first table alone sent to the exact path had none
-     *   ring[QZK_RINGW]  the last QZK_RING bytes of input (and ~100 ahead of the parse point).  Every candidate compare
+     *   ring[QZK_RINGW + 4]  the last QZK_RING bytes of input (and ~100 ahead of the parse point).  Every candidate compare
      *     drags a 128-byte line through L2 for 16 bytes, three quarters of them less than 4 KiB back; with a dozen
      *     waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
-    uint32_t *const slot = lds, *const scnt = lds + QZK_NSLOT, *const ring = lds + 2 * QZK_NSLOT, *const slot2 = ring + QZK_RINGW;
+    uint32_t *const slot = lds, *const scnt = lds + QZK_NSLOT, *const ring = lds + 2 * QZK_NSLOT, *const slot2 = ring + QZK_RINGW + 4;
 #if QZK_CNB
     /* the cache of table entries: ctag[s] = hash | 1 << 16 of the entry held (anything else: none - the commit's election
      * leaves its marks here), cpos[s], cpos[QZK_CNB + s] = its four positions, newest first, as 16-bit offsets from the
@@ -249,13 +249,14 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
     uint32_t rhi = 0;                      /* chunk offset the ring is filled up to (multiple of 256) */
     uint32_t crc_acc = 0;                  /* this lane's share of the chunk's CRC-32 (crcT != NULL) */
     uint32_t rnext = qzk_ld32g_fast(src, (uint64_t)chunk * chunk_sz + 4 * (uint32_t)qz_lane(), src_len);   /* my dword of the row at rhi */
+    /* (the ring's first four words are kept a second time behind its last: five words from any place in it are five
+     * consecutive words - one address, constant offsets, two words an LDS instruction - instead of five wrapped indices) */
 #define QZK_RING16(dst, ca) do { const uint32_t r_ = (ca) & (QZK_RING - 1), i_ = r_ >> 2, s_ = r_ & 3; \
-        const uint32_t d0_ = ring[i_ & (QZK_RINGW - 1)], d1_ = ring[(i_ + 1) & (QZK_RINGW - 1)], d2_ = ring[(i_ + 2) & (QZK_RINGW - 1)], \
-                       d3_ = ring[(i_ + 3) & (QZK_RINGW - 1)], d4_ = ring[(i_ + 4) & (QZK_RINGW - 1)]; \
+        const uint32_t d0_ = ring[i_], d1_ = ring[i_ + 1], d2_ = ring[i_ + 2], d3_ = ring[i_ + 3], d4_ = ring[i_ + 4]; \
         (dst)[0] = qzk_alignbyte(d1_, d0_, s_); (dst)[1] = qzk_alignbyte(d2_, d1_, s_); \
         (dst)[2] = qzk_alignbyte(d3_, d2_, s_); (dst)[3] = qzk_alignbyte(d4_, d3_, s_); } while (0)
 #define QZK_RING4(ca) ({ const uint32_t r_ = (ca) & (QZK_RING - 1), i_ = r_ >> 2; \
-        qzk_alignbyte(ring[(i_ + 1) & (QZK_RINGW - 1)], ring[i_ & (QZK_RINGW - 1)], r_ & 3); })
+        qzk_alignbyte(ring[i_ + 1], ring[i_], r_ & 3); })
 #define QZK_AHEAD (64 + 258 + 6)       /* bytes of input the ring holds beyond the window start */
 
     const int lane = qz_lane();
@@ -380,7 +381,9 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             if (rhi < pos + QZK_AHEAD) {
                 do {
                     const uint32_t a = rhi + 4 * (uint32_t)lane;
-                    ring[(a >> 2) & (QZK_RINGW - 1)] = rnext;
+                    const uint32_t ri = (a >> 2) & (QZK_RINGW - 1);
+                    ring[ri] = rnext;
+                    if (ri < 4) ring[ri + QZK_RINGW] = rnext;
                     /* the chunk's CRC-32 rides along: every byte of the chunk passes here exactly once, lane l seeing the
                      * dwords at 256 r + 4 l; it folds them Horner-style (crc32_combine algebra, 8 LDS lookups a step) */
                     if (crcT && a + 4 <= n) crc_acc = qzk_k1crc_step(crcT, crc_acc, rnext);
@@ -479,23 +482,23 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
         int nc; uint32_t c0, c1, c2, c3;
         {
             uint32_t x[4][4];
-#define QZK_LDC(k, ck) do { const uint32_t ca_ = (ck); uint64_t g_ = coff + ca_; \
-        if ((int64_t)ca_ >= (int64_t)rhi - QZK_RING) QZK_RING16(x[k], ca_); \
-        else if (!guard) { x[k][0] = qz_ld32(src + g_); x[k][1] = qz_ld32(src + g_ + 4); x[k][2] = qz_ld32(src + g_ + 8); x[k][3] = qz_ld32(src + g_ + 12); } \
-        else { x[k][0] = qzk_ld32g(src, g_, src_len); x[k][1] = qzk_ld32g(src, g_ + 4, src_len); x[k][2] = qzk_ld32g(src, g_ + 8, src_len); x[k][3] = qzk_ld32g(src, g_ + 12, src_len); } } while (0)
-            /* loads are predicated on the link being live: with a dozen waves per CU the kernel is bound by the
-             * texture path (TA/TD ~ one lane-line per cycle), so dead lanes must not ride along */
-            for (int k = 0; k < 4; k++) x[k][0] = x[k][1] = x[k][2] = x[k][3] = 0;
+            /* the four candidates' first sixteen bytes.  Round 6's phase clocks (profiles/r6_k1_phases.txt): merely ISSUING these
+             * took 2200 clocks a window - four candidates, each behind its own branch on "in the ring or not", each ring
+             * read waited for inside its branch.  Now every lane reads the ring for all four places at once, whatever its
+             * links are (a dead link points at the lane's own position; an LDS address is always good), one wait; then the
+             * lanes whose candidate lies further back than the ring overwrite theirs from memory - predicated on the link
+             * being live AND far: the texture path must not carry dead lanes. */
             const bool ok0 = canh && q0 > base && pa - q0 <= QZK_MAXDIST;      /* at or below the window origin: NIL */
             const bool ok1 = ok0 && q1 > lo;
             const bool ok2 = ok1 && q2 > lo;
             const bool ok3 = ok2 && q3 > lo;
             c0 = ok0 ? q0 : pa; c1 = ok1 ? q1 : pa; c2 = ok2 ? q2 : pa; c3 = ok3 ? q3 : pa;
-            if (ok0) QZK_LDC(0, c0);
-            if (ok1) QZK_LDC(1, c1);
-            if (ok2) QZK_LDC(2, c2);
-            if (ok3) QZK_LDC(3, c3);
-#undef QZK_LDC
+            QZK_RING16(x[0], c0); QZK_RING16(x[1], c1); QZK_RING16(x[2], c2); QZK_RING16(x[3], c3);
+#define QZK_LDF(k, ck) do { const uint32_t ca_ = (ck); if ((int64_t)ca_ < (int64_t)rhi - QZK_RING) { const uint64_t g_ = coff + ca_; \
+        if (!guard) { x[k][0] = qz_ld32(src + g_); x[k][1] = qz_ld32(src + g_ + 4); x[k][2] = qz_ld32(src + g_ + 8); x[k][3] = qz_ld32(src + g_ + 12); } \
+        else { x[k][0] = qzk_ld32g(src, g_, src_len); x[k][1] = qzk_ld32g(src, g_ + 4, src_len); x[k][2] = qzk_ld32g(src, g_ + 8, src_len); x[k][3] = qzk_ld32g(src, g_ + 12, src_len); } } } while (0)
+            QZK_LDF(0, c0); QZK_LDF(1, c1); QZK_LDF(2, c2); QZK_LDF(3, c3);        /* (a dead link's place is the lane's own: never far) */
+#undef QZK_LDF
             nc = (int)ok0 + (int)ok1 + (int)ok2 + (int)ok3;
             QZK_T(2);
             /* while those loads are in flight: which lanes share a hash with an EARLIER lane of this window?

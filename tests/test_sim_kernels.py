@@ -672,3 +672,26 @@ def test_lz4_decoder_on_damaged_frames(sim):
         else:
             errors += 1
     assert errors > 120, (errors, same)
+
+
+def test_k1_entry_cache_and_asking_ahead_variant():
+    """round 6's K1 experiment stays in the kernel header behind QZK_CNBLOG / QZK_PF (profiles/r6_k1_experiments.txt): a
+    wave's LDS cache of table entries, the next window's entries asked for a window ahead, exact out-of-date marks,
+    deferred stores.  Built here as its own emulator library and held to the same bytes - window slides (128 KB chunks:
+    the cached positions move with the window's origin), runs (every lane on one hash), table reuse across chunks."""
+    so = os.path.join(SIMDIR, "libqzsim_cache.so")
+    deps = [os.path.join(SIMDIR, "sim_driver.cpp"), os.path.join(ROOT, "qatzip_amd", "csrc", "qzk_deflate_lz77.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DQZK_CNBLOG=8", "-I", SIMDIR,
+                               "-Wno-unused-function", "-o", so, os.path.join(SIMDIR, "sim_driver.cpp")])
+    S = C.CDLL(so)
+    S.sim_deflate_fused.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    cnt = (C.c_ulong * 2)()
+    for kind, n, chunk in (("silesia", 150000, 65536), ("runs", 70000, 65536), ("text", 280000, 131072), ("lzmix", 66000, 16384)):
+        src = datagen.gen_bytes(kind, n, 41)
+        out, crcs = _sim_deflate(S, src, chunk, fused=True)
+        assert out == O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)[2], (kind, n, chunk)
+        for i in range(len(crcs)):
+            assert crcs[i] == (zlib.crc32(src[i * chunk:(i + 1) * chunk]) & 0xffffffff)
+    S.sim_k1_counts(cnt)
+    assert cnt[1] > 5000 and cnt[0] < cnt[1] // 2, list(cnt)        # most windows took the entries asked ahead, not a gather of their own
