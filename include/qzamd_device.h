@@ -247,6 +247,9 @@ uint32_t qzd_crc32_fold(const uint32_t *h_crc, uint32_t nchunks, uint32_t chunk_
  * match-resolve kernel; 0 on the wave-per-segment path), [3] phase A (the Huffman-decoding kernel, with the launch for any
  * segment handed back to the one-lane kernel; 0 on the wave-per-segment path) */
 int qzd_last_inflate_timing(qzd_ctx *ctx, float ms[4]);
+/* device memory (bytes) the context's decode scratch holds at the moment - token sub-streams, marks, decode tables of the
+ * two-phase inflate; it grows with the largest call and is given back after eight calls in a row that needed under a quarter */
+uint64_t qzd_inflate_scratch_bytes(qzd_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,8 @@ def load(build_if_missing=True):
     L.qzd_crc32.argtypes = [vp, u8p, C.c_uint64, C.POINTER(C.c_uint32)]
     L.qzd_crc32_ranges.argtypes = [vp, u8p, vp, C.c_uint32, vp]
     L.qzd_last_inflate_timing.argtypes = [vp, C.POINTER(C.c_float * 4)]
+    if hasattr(L, "qzd_inflate_scratch_bytes"):            # (variant libraries built from older sources lack it; the export test does not)
+        L.qzd_inflate_scratch_bytes.argtypes = [vp]; L.qzd_inflate_scratch_bytes.restype = C.c_uint64
     L.qzd_d2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.qzd_lz4_compress_frames.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
     L.qzd_lz4_compress_frames_hw.argtypes = L.qzd_lz4_compress_frames.argtypes
@@ -90,7 +92,7 @@ def exported_symbols():
     return ["qzd_create", "qzd_destroy", "qzd_last_error", "qzd_device_count", "qzd_ctx_device", "qzd_dev_alloc", "qzd_dev_free",
             "qzd_h2d", "qzd_d2h", "qzd_host_alloc_pinned", "qzd_host_free_pinned", "qzd_deflate_raw",
             "qzd_deflate_raw_async", "qzd_sync", "qzd_result", "qzd_last_timing", "qzd_inflate_segments",
-            "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing",
+            "qzd_inflate_stream", "qzd_crc32", "qzd_crc32_ranges", "qzd_last_inflate_timing", "qzd_inflate_scratch_bytes",
             "qzd_lz4_compress_frames", "qzd_lz4_compress_frames_hw", "qzd_lz4_decompress_frames", "qzd_chunk_lens", "qzd_batch_chunks", "qzd_k1_stats",
             "qzd_adler32_chunks", "qzd_adler32_combine", "qzd_stream_copy_peak", "qzd_deflate_raw_from_host",
             "qzd_deflate_slots", "qzd_inflate_stream_to_host", "qzd_inflate_stream_from_host", "qzamd_async_stats", "qzd_shard_root_create",

@@ -199,29 +199,39 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     qzk_tokseg *tsv = (qzk_tokseg *)(c->h_aux + o_ts);
     uint32_t *st_ord = (uint32_t *)(c->h_aux + o_ord);
     memcpy(st_segs, hs, sb);
-    uint64_t lit_total = 0, seq_total = 0;
+    /* every sub-stream is one region of the scratch, literals up from its first byte, sequences down from its end
+     * (qzk_inflate_lane.h).  K == 1: a region that holds any segment; K > 1: regions sized by need (qzk_inflate_spec.h), and
+     * behind them R whole-segment regions for the segments that kernel hands back to the serial one */
+    uint64_t arena = 0, max_cap = 0;
     for (uint32_t i = 0; i < nsegs; i++) {
         const bool writes = !(hs[i].flags & QZK_INF_COUNT_ONLY);
+        if (writes && hs[i].out_cap > max_cap) max_cap = hs[i].out_cap;
         for (uint32_t j = 0; j < K; j++) {
-            const uint64_t lc = !writes ? 0 : K == 1 ? QZK_TOK_LITCAP(hs[i].out_cap) : QZK_SPEC_LITCAP(hs[i].out_cap, K, j);
-            const uint64_t sc = !writes ? 0 : K == 1 ? QZK_TOK_SEQCAP(hs[i].out_cap) : QZK_SPEC_SEQCAP(hs[i].out_cap, K, j);
-            tsv[(size_t)i * K + j].lit_off = lit_total; tsv[(size_t)i * K + j].seq_off = seq_total;
-            lit_total += lc; seq_total += sc;
+            const uint64_t rg = !writes ? 0 : K == 1 ? QZK_TOK_REGION(hs[i].out_cap) : QZK_SPEC_REGION(hs[i].out_cap, K, j);
+            tsv[(size_t)i * K + j].lit_off = arena; tsv[(size_t)i * K + j].seq_off = (arena + rg) / 8;
+            arena += rg;
         }
     }
+    const uint32_t R = K == 1 ? 0u : std::min<uint32_t>(nsegs, QZK_SPEC_HANDBACK(nsegs));
+    const uint64_t hb0 = arena, hb_rg = QZK_TOK_REGION(max_cap);
+    arena += (uint64_t)R * hb_rg;
     const size_t tabb = ((size_t)nsegs * sizeof(qzk_inf_tab) + 255) & ~(size_t)255;
     const size_t tsb = ((size_t)nsegs * K * sizeof(qzk_tokseg) + 255) & ~(size_t)255;
     const size_t chb = ((size_t)nsegs * sizeof(qzk_chain) + 255) & ~(size_t)255;
     const size_t rcb = K == 1 ? 0 : (((size_t)nsegs * K * QZK_SPEC_NREC * sizeof(qzk_rec) + 255) & ~(size_t)255);
-    const size_t litb = (lit_total + 511) & ~(uint64_t)255, seqb = seq_total * sizeof(qzk_seq);
+    const size_t litb = (arena + 1023) & ~(uint64_t)255, seqb = 0;             /* (one arena; phase B reads whole 16-byte rows past a region's literals) */
     /* output streaming: only the plain decode of a whole member (every segment writes, known output offsets) */
     const bool stream_out = run_b && c->so_host && c->so_nat && nsegs >= QZD_LANE_MIN_SEGS;
     const size_t ordb = ((size_t)nsegs * 4 + 255) & ~(size_t)255;
     const size_t need = tabb + tsb + chb + rcb + litb + seqb + ordb + 256;
-    /* the scratch grows with the largest call and shrinks again when a call needs less than a quarter of it (a 4 GiB decode
-     * leaves 44 GB behind; the next 64 KB call gives them back) */
-    if (need > c->big_cap || (c->big_cap > ((size_t)1 << 30) && need * 4 < c->big_cap)) {
-        hipDeviceSynchronize();
+    /* the scratch grows with the largest call and shrinks again when EIGHT calls in a row have needed less than a quarter of it
+     * (a 4 GiB decode leaves gigabytes behind; a session of small calls gives them back, one that alternates large and small
+     * ones keeps them - every change is a free and an allocation).  What runs on the scratch runs on this context's
+     * streams: they are waited for, not the device - helper contexts decode other pieces meanwhile */
+    if (c->big_cap > ((size_t)1 << 30) && need * 4 < c->big_cap) c->big_small++; else c->big_small = 0;
+    if (need > c->big_cap || c->big_small >= 8) {
+        c->big_small = 0;
+        hipStreamSynchronize(st); hipStreamSynchronize(c->st_out);
         if (c->d_big) hipFree(c->d_big);
         c->d_big = NULL; c->big_cap = 0;
         /* QATZIP_AMD_SCRATCH_MAX=<bytes>: a ceiling for this scratch (tests: the paths a failed allocation takes) */
@@ -244,7 +254,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     qzk_chain *ch_d = (qzk_chain *)pb; pb += chb;
     qzk_rec *rec_d = (qzk_rec *)pb; pb += rcb;
     uint8_t *lit_d = pb; pb += litb;
-    qzk_seq *seq_d = (qzk_seq *)pb; pb += (seqb + 255) & ~(size_t)255;
+    qzk_seq *seq_d = (qzk_seq *)lit_d;                  /* the same arena: a region's sequences count down from its end */
     uint32_t *ord_d = (uint32_t *)pb;
     HIPCHK(c, ctl_copy(d_segs, st_segs, sb, st));
     HIPCHK(c, ctl_copy(ts_d, tsv, (size_t)nsegs * K * sizeof(qzk_tokseg), st));
@@ -273,8 +283,8 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     else {
         const uint32_t spw = 64 / K;
         const dim3 grid((nsegs + spw - 1) / spw), blk(64);
-        static std::atomic<uint32_t> spec_epoch{0};                 /* tags the marks of a launch: scratch left by an earlier one is not mistaken for them */
-        const uint32_t epoch = ++spec_epoch;
+        static std::atomic<uint64_t> spec_epoch{0};                 /* tags the marks of a launch: scratch left by an earlier one is not mistaken for them */
+        const uint64_t epoch = ++spec_epoch;
         /* how far a block's last lane may run beyond its share before the rest is shared out again (a round more): segments
          * above 64 KB hold several blocks of very different length and pay for every lane left alone; small launches end
          * with their longest lane; a full launch of 64 KB segments is better off without the extra rounds
@@ -299,7 +309,13 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
             for (int k = 0; k < 64; k++) if (hist[k]) fprintf(stderr, " %d:%u", k, hist[k]);
             fprintf(stderr, "\n");
         }
+        if (nredo > R) return two_phase(c, d_comp, d_out, hs, nsegs, h_res, 1, st, run_b);      /* more than the hand-back area holds: this data is not what K lanes are for */
         if (nredo) {
+            for (uint32_t k = 0; k < nredo; k++) {
+                qzk_tokseg &t0 = tsv[(size_t)st_ord[k] * K];
+                t0.lit_off = hb0 + (uint64_t)k * hb_rg; t0.seq_off = (hb0 + (uint64_t)(k + 1) * hb_rg) / 8;
+            }
+            HIPCHK(c, ctl_copy(ts_d, tsv, (size_t)nsegs * K * sizeof(qzk_tokseg), st));
             HIPCHK(c, ctl_copy(ord_d, st_ord, (size_t)nredo * 4, st));
             tok_launch(ord_d, nredo);
         }
@@ -1158,6 +1174,8 @@ extern "C" int qzd_inflate_occupancy(int out[4])
     out[0] = a; out[1] = b; out[2] = c4; out[3] = d;
     return 0;
 }
+
+extern "C" uint64_t qzd_inflate_scratch_bytes(qzd_ctx *c) { return c ? (uint64_t)c->big_cap : 0; }
 
 extern "C" int qzd_last_inflate_timing(qzd_ctx *c, float ms[4])
 {

@@ -54,7 +54,7 @@ struct qzd_ctx {
     /* output streaming (qzd_inflate_stream_to_host): while set, the two-phase decoder resolves the output range by range
      * and sends each range to so_host behind its launch; so_nat[i] = array index of the segment that is i-th in the output */
     uint8_t *so_host; const uint32_t *so_nat; uint64_t so_sent; hipEvent_t so_ev[8];
-    uint8_t *d_big; size_t big_cap;                 /* device-only scratch (per-segment decode tables of K3b) */
+    uint8_t *d_big; size_t big_cap; uint32_t big_small;   /* device-only scratch (per-segment decode tables of K3b); calls in a row that needed under a quarter of it */
     uint32_t *d_cdesc; uint32_t cdesc_cap;          /* per-slot descriptors of a coalesced launch (qzd_deflate_slots) */
     uint8_t *d_lane; size_t lane_cap;               /* device-only scratch of the one-chunk-per-lane compress path (K1b) */
     float inf_ms[4];

@@ -497,7 +497,9 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 #define QZK_LDF(k, ck) do { const uint32_t ca_ = (ck); if ((int64_t)ca_ < (int64_t)rhi - QZK_RING) { const uint64_t g_ = coff + ca_; \
         if (!guard) { x[k][0] = qz_ld32(src + g_); x[k][1] = qz_ld32(src + g_ + 4); x[k][2] = qz_ld32(src + g_ + 8); x[k][3] = qz_ld32(src + g_ + 12); } \
         else { x[k][0] = qzk_ld32g(src, g_, src_len); x[k][1] = qzk_ld32g(src, g_ + 4, src_len); x[k][2] = qzk_ld32g(src, g_ + 8, src_len); x[k][3] = qzk_ld32g(src, g_ + 12, src_len); } } } while (0)
+#ifndef QZK_EXP_NOFAR   /* (timing experiment only: wrong bytes) */
             QZK_LDF(0, c0); QZK_LDF(1, c1); QZK_LDF(2, c2); QZK_LDF(3, c3);        /* (a dead link's place is the lane's own: never far) */
+#endif
 #undef QZK_LDF
             nc = (int)ok0 + (int)ok1 + (int)ok2 + (int)ok3;
             QZK_T(2);

@@ -165,7 +165,11 @@ QZ_DEV void qzk_st64u(uint8_t *p, uint64_t v) { ((qz_u64u *)p)->v = v; }
 
 /* phase A -> phase B hand-over, per segment: literal bytes + sequence records */
 typedef struct { uint32_t litrun; uint16_t mlen; uint16_t dm1; } qzk_seq;      /* mlen 0: literals only (tail) */
-typedef struct { uint64_t lit_off; uint64_t seq_off; } qzk_tokseg;             /* bytes into lits / records into seqs */
+/* a sub-stream is ONE region of the scratch (round 6): its literals grow up from the region's first byte, its sequence
+ * records DOWN from its end - record i lies at seqs[seq_off - 1 - i] - so that literal-heavy and match-heavy streams share
+ * the same room (a byte of output is a literal or a third of a match at most: text needs 1.4 bytes of scratch per byte of
+ * output, random data 1.0, only "a match every three bytes" the 2.67 that separate worst-case arrays had to hold both of) */
+typedef struct { uint64_t lit_off; uint64_t seq_off; } qzk_tokseg;             /* lits + lit_off = the region's first byte; seqs + seq_off = its end */
 /* what phase B stitches together for one segment: pieces of sub-streams, in output order.  The serial phase A
  * leaves one piece (the whole stream); the speculative one (qzk_inflate_spec.h) up to one per sub-decoder. */
 #define QZK_SPEC_MAXK 8
@@ -181,6 +185,8 @@ typedef struct { uint32_t nel, pad; qzk_chain_el el[QZK_CHAIN_MAXEL]; } qzk_chai
 /* scratch a segment needs: literals <= out_cap (+ staging slack), sequences <= out_cap / 3 (+ tail) */
 #define QZK_TOK_LITCAP(out_cap) ((((uint64_t)(out_cap) + 31) & ~(uint64_t)31) + 32)
 #define QZK_TOK_SEQCAP(out_cap) (((uint64_t)(out_cap) / 3 + 3) & ~(uint64_t)1)      /* even: sequences leave in aligned pairs */
+/* the region of a sub-stream that must hold a whole segment whatever it is made of (the one-lane kernel's): bytes, a multiple of 32 */
+#define QZK_TOK_REGION(out_cap) (QZK_TOK_LITCAP(out_cap) + 8 * QZK_TOK_SEQCAP(out_cap))
 
 enum { QZK_LS_HDR = 0, QZK_LS_SYM, QZK_LS_RAW, QZK_LS_DONE };
 #ifndef QZK_LIT_RUN
@@ -533,7 +539,7 @@ QZ_DEV void qzk_lane_header(qzk_lane_st *S, qzk_inf_tab *T, uint16_t *lroot, uin
  * odd count in q0.  qzk_tok_drain() stores what is complete; qzk_tok_finish() what is left. */
 typedef uint32_t qzk_u32x4 __attribute__((vector_size(16)));
 typedef struct {
-    uint8_t *lp; qzk_seq *sq;
+    uint8_t *lp; qzk_seq *sq;           /* the region's first byte; its END: sequence i at sq[-1 - i] */
     uint32_t lrun, nseq;                /* literals since the last sequence, sequences so far */
     uint32_t lw;                        /* literal bytes so far */
     uint32_t l0, l1, l2, l3, l4;        /* the literal piece being filled */
@@ -561,9 +567,9 @@ QZ_DEV void qzk_tok_drain(qzk_tok_out *O)
         O->l0 = O->l4; O->l1 = 0; O->l2 = 0; O->l3 = 0; O->l4 = 0; O->lfull = 0;
     }
     if (O->qfull) {
-        qzk_u32x4 v; v[0] = (uint32_t)O->q0; v[1] = (uint32_t)(O->q0 >> 32); v[2] = (uint32_t)O->q1; v[3] = (uint32_t)(O->q1 >> 32);
+        qzk_u32x4 v; v[0] = (uint32_t)O->q1; v[1] = (uint32_t)(O->q1 >> 32); v[2] = (uint32_t)O->q0; v[3] = (uint32_t)(O->q0 >> 32);     /* records nseq - 1, nseq - 2: downward */
 #ifndef QZK_X_NOMEM
-        *(qzk_u32x4 *)((uint64_t *)O->sq + (O->nseq - 2u)) = v;
+        *(qzk_u32x4 *)((uint64_t *)O->sq - O->nseq) = v;
 #endif
         O->qfull = 0;
     }
@@ -617,7 +623,7 @@ QZ_DEV void qzk_tok_flush(qzk_tok_out *O)
     if (O->count_only) return;
     qzk_tok_drain(O);
     if (O->lw & 15u) { qzk_u32x4 v; v[0] = O->l0; v[1] = O->l1; v[2] = O->l2; v[3] = O->l3; *(qzk_u32x4 *)(O->lp + (O->lw & ~15u)) = v; }
-    if (O->nseq & 1u) ((uint64_t *)O->sq)[O->nseq - 1u] = O->q0;
+    if (O->nseq & 1u) *((uint64_t *)O->sq - O->nseq) = O->q0;
 }
 
 QZ_DEV void qzk_tok_finish(qzk_tok_out *O)
@@ -1049,11 +1055,11 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8
         }
         const qzk_tokseg tk = ts[(uint64_t)sidx * ts_stride + ce.sub];
         const uint8_t *lp = lits + tk.lit_off + ce.lit_first;
-        const qzk_seq *sq = seqs + tk.seq_off + ce.seq_first;
+        const qzk_seq *sq = seqs + tk.seq_off - 1 - ce.seq_first;       /* the piece's first record; the next ones BELOW it */
         const uint32_t ns = ce.seq_count;
         uint32_t lbase = 0;                             /* literal bytes of this piece consumed by earlier batches */
         uint32_t b0 = 0;
-        uint64_t cur = (uint32_t)lane < ns ? qzk_rb_ld64((const uint8_t *)(sq + lane)) : 0;
+        uint64_t cur = (uint32_t)lane < ns ? qzk_rb_ld64((const uint8_t *)(sq - lane)) : 0;
         while (b0 < ns) {
             /* a record: {u32 literal run, u16 match length, u16 distance - 1} */
             uint32_t litrun = (uint32_t)cur, mlen = (uint32_t)(cur >> 32) & 0xffffu, dist = (uint32_t)(cur >> 48) + 1;
@@ -1072,11 +1078,11 @@ QZ_KERNEL_OCC(64 * QZK_RES_WAVES, QZK_RES_OCC) qzk_lz_resolve_kernel(const uint8
                 qzk_rb_skip(&S, L);
                 if (M) { qzk_rb_direct_match(&S, D, M, lane); QZK_RSYNC(); qzk_rb_skip(&S, M); }
                 lbase += L; b0 += 1;
-                cur = b0 + (uint32_t)lane < ns ? qzk_rb_ld64((const uint8_t *)(sq + b0 + lane)) : 0;
+                cur = b0 + (uint32_t)lane < ns ? qzk_rb_ld64((const uint8_t *)(sq - b0 - lane)) : 0;
                 continue;
             }
             /* the records of the batch after this one: asked for now, used when this batch is out */
-            const uint64_t nxt = b0 + n + (uint32_t)lane < ns ? qzk_rb_ld64((const uint8_t *)(sq + b0 + n + lane)) : 0;
+            const uint64_t nxt = b0 + n + (uint32_t)lane < ns ? qzk_rb_ld64((const uint8_t *)(sq - b0 - n - lane)) : 0;
             if ((uint32_t)lane >= n) { s_tot -= litrun + mlen; s_lit -= litrun; litrun = 0; mlen = 0; }    /* (sums of idle lanes: never read) */
             const uint32_t Tb = qz_readlane(s_tot, (int)n - 1), Lb = qz_readlane(s_lit, (int)n - 1);
             err = qzk_rb_batch(&S, lp + lbase, Lb, s_lit - litrun, litrun, mlen, dist, s_tot, Tb, lane);

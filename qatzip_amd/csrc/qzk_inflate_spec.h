@@ -49,17 +49,33 @@
 #define QZK_SPEC_REACH(K) ((K) >= 16 ? 6u : 4u)    /* shares a lane decodes from its start before it gives the rest back */
 #endif
 #define QZK_SPEC_MINBITS 512u      /* a block is split only when every lane gets at least this much of it */
-/* scratch of the sub-streams: lane 0 may have to decode the whole segment alone (nobody falls into step with a flat
- * code); the last lane decodes to the end of the block however much longer than guessed that is (a share and all that
- * follows it: K - 1 shares cover it whenever the block is not longer than the segment's input); the lanes between stop at
- * twice a fair share - past that the segment goes back to the serial kernel */
-#ifdef QZK_SPEC_TINY        /* emulator stress builds: sub-streams that overflow at once, so that the continuation rounds are exercised */
-#define QZK_SPEC_SLACK(K, j) 1ull / 3
-#else
-#define QZK_SPEC_SLACK(K, j) ((j) == (K) - 1 ? (uint64_t)((K) > 2 ? (K) - 1 : 2) : 2ull)
+/* scratch of the sub-streams, sized by NEED (round 6; rounds 4-5 sized every one for its worst case - lane 0 for a whole
+ * segment, the others for two or K - 1 shares of "a match every three bytes", literals and sequences apart: 673 KB per
+ * 64 KB segment at K = 4, 44 GB for a 4 GiB call).  A lane's sub-stream is one region (qzk_inflate_lane.h: literals up,
+ * sequences down) of QZK_SPEC_SLACK8 eighths of a share (a lane decodes past its own share until it falls into step, the
+ * last one to the block's end) at QZK_SPEC_DENS8 eighths of a byte of scratch per byte of output - zlib's level-1 parse of
+ * the bench's text segments needs 1.4 (a fifth of the bytes literals, a match every 6.7), its random segments 1.0.  What
+ * outgrows that is not lost: a lane out of scratch stops, is on nobody's chain, and the block goes on in a round of its
+ * own; a segment whose lane 0 runs out is handed back (QZK_INF_ESPEC) and the serial kernel decodes it into a HAND-BACK
+ * area of whole-segment regions the host keeps for one segment in thirty-two (more than that: the call takes the one-lane
+ * path, whose single region per segment holds any segment and is 3.7 times the output). */
+#ifndef QZK_SPEC_DENS8
+#define QZK_SPEC_DENS8 15
 #endif
-#define QZK_SPEC_LITCAP(out_cap, K, j) ((j) == 0 ? QZK_TOK_LITCAP(out_cap) + 64 + 512 : (((uint64_t)(out_cap) * QZK_SPEC_SLACK(K, j) / (K) + 255) & ~(uint64_t)63) + 64 + 512)
-#define QZK_SPEC_SEQCAP(out_cap, K, j) ((j) == 0 ? (QZK_TOK_SEQCAP(out_cap) + 13 + 64) & ~(uint64_t)1 : (((uint64_t)(out_cap) / 3) * QZK_SPEC_SLACK(K, j) / (K) + 24 + 64) & ~(uint64_t)1)
+#ifdef QZK_SPEC_TINY        /* emulator stress builds: sub-streams that overflow at once, so that the continuation rounds are exercised */
+#define QZK_SPEC_SLACK8(K, j) (8ull / 3)
+#else
+/* eighths of a share: 1.25 shares, the last lane 1.75; lane 0 two and a half and never less than half of the segment - it is the lane
+ * that is right by construction and decodes on through the share of a neighbour that met a false END_BLOCK after one trip.  Sixteen
+ * lanes (segments of 16 - 128 KB in launches that do not fill the chip) get one and a half, thirty-two (256 / 512 KB segments: a score
+ * of blocks each, lanes that go up to six small shares before they fall into step) two: 1 GiB of 128 KB segments 11.5 -> 10.7 ms of
+ * phase A, of 512 KB 55 -> 18.  All lanes together: 1.66 - 1.92 segments' worth up to K = 16, 2.5 at K = 32 */
+#define QZK_SPEC_SLACK8(K, j) ((j) == 0 ? ((K) > 5 ? 4ull * (K) : 20ull) : (K) >= 32 ? ((j) == (K) - 1 ? 20ull : 16ull) : (j) == (K) - 1 ? 14ull : (K) >= 16 ? 12ull : 10ull)
+#endif
+/* a sub-stream's region in bytes (a multiple of 64): the margins are what QZK_SPEC_EVERY unchecked trips can add, both ways */
+#define QZK_SPEC_MARGIN (96 + 512 + 8 * (10 + 64))
+#define QZK_SPEC_REGION(out_cap, K, j) ((((uint64_t)(out_cap) * QZK_SPEC_DENS8 / 8 * QZK_SPEC_SLACK8(K, j) / 8 / (K) + 63) & ~(uint64_t)63) + ((QZK_SPEC_MARGIN + 63) & ~63))
+#define QZK_SPEC_HANDBACK(nsegs) ((nsegs) / 32u > 64u ? (nsegs) / 32u : 64u)      /* whole-segment regions kept for the segments handed back */
 
 typedef struct __attribute__((aligned(32))) { uint32_t pos, nlit, nseq, lrun, olen, tag, pad0, pad1; } qzk_rec;     /* a mark: trip start (bit offset) and the token counters there */
 enum { QZK_ST_RUN = 0, QZK_ST_SYNC, QZK_ST_EOB, QZK_ST_REDO };
@@ -96,7 +112,7 @@ __device__ unsigned long long qzk_stamp[8];     /* wall-clock (100 MHz) first en
 template <int K>
 QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                   qzk_inf_tab *tabs, const qzk_tokseg *ts /* [nsegs * K] */, uint8_t *lits, qzk_seq *seqs,
-                                  qzk_chain *chains, qzk_rec *recs /* [nsegs * K * QZK_SPEC_NREC] */, uint32_t epoch,
+                                  qzk_chain *chains, qzk_rec *recs /* [nsegs * K * QZK_SPEC_NREC] */, uint64_t epoch /* of the launch, process-wide, never reused */,
                                   uint32_t over_shares /* shares beyond its own the last lane of a block may decode before the rest is shared out again */)
 {
     constexpr int SPW = 64 / K;                                     /* segments per wave */
@@ -137,7 +153,9 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
     qzk_tok_out O;
     qzk_tok_init(&O, lits + ts[slot].lit_off, seqs + ts[slot].seq_off, false);
     /* checked on the trips that leave a mark: the margin is what QZK_SPEC_EVERY trips can add */
-    const uint32_t lit_cap = (uint32_t)QZK_SPEC_LITCAP(sg.out_cap, K, j) - 96 - QZK_SPEC_EVERY * 8, seq_cap = (uint32_t)QZK_SPEC_SEQCAP(sg.out_cap, K, j) - 10 - QZK_SPEC_EVERY;
+    /* literal bytes + 8 x sequences my region holds, less what the unchecked trips between two marks can add */
+    const uint32_t tok_cap = (uint32_t)QZK_SPEC_REGION(sg.out_cap, K, j) - QZK_SPEC_MARGIN;
+#define QZK_TOK_FULL(O_) (QZK_NLIT(O_) + 8u * (O_).nseq > tok_cap)
     /* where the segment's input is taken to end: the host's hint (the next candidate's start), moved on by lane 0 when the
      * decode gets there and the segment goes on - 00 00 FF FF inside a segment's own data cuts its hint short, and a lane 0
      * left to decode the rest alone was a whole serial chain at the end of the launch (profiles/r4_phaseA_timeline.txt) */
@@ -233,7 +251,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
         const uint32_t my_at = h_end + (uint32_t)j * h_span;       /* where my share of this round begins */
         if (active && (j > 0 || h_mode == 2)) {                     /* my guessed start (lane 0 stands behind the header, or goes to where the chain broke) */
             const uint32_t at = h_end + (uint32_t)j * h_span;
-            if (j > 0 && (at + 64 >= limit_bits || (at >> 3) + 64 > S.b.end || QZK_NLIT(O) > lit_cap || O.nseq > seq_cap)) active = false;
+            if (j > 0 && (at + 64 >= limit_bits || (at >> 3) + 64 > S.b.end || QZK_TOK_FULL(O))) active = false;
             else {
                 qzk_lseek(&S.b, at >> 3);
                 qzk_lrefill(&S.b);
@@ -246,7 +264,10 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
         S.state = QZK_LS_SYM;
         QZK_SPROF(1);                                               /* [1] starts and tables */
         static_assert(QZK_CHAIN_MAXEL < 1024, "a round's tag has ten bits");
-        const uint32_t tag = (epoch << 10) | (round & 1023u);    /* a segment takes at most QZK_CHAIN_MAXEL rounds (each adds a piece): no two of a launch share a tag */
+        /* a segment takes at most QZK_CHAIN_MAXEL rounds (each adds a piece): no two of a launch share a tag; the launch's
+         * number is 54 bits wide across tag and pad0 - the 22 bits the tag alone has room for come round again after 4.2 million launches
+         * (every lone 64 KB call is one), and a record left by the launch 2^22 before this one must not pass for a mark of this one */
+        const uint32_t tag = ((uint32_t)epoch << 10) | (round & 1023u), tag_hi = (uint32_t)(epoch >> 22);
         /* a lane that started beyond the end of the block (the block was shorter than guessed) or that never falls into
          * step decodes garbage: the end of the segment's input stops it; lane 0 is always right */
         const uint32_t give_up = j == 0 ? 0xffffffffu : limit_bits + 64;
@@ -290,10 +311,10 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
         ntrip++; \
         if (due_) { \
             if (ridx + 1 < QZK_SPEC_NREC) { \
-                qzk_rec r_; r_.pos = at_; r_.nlit = QZK_NLIT(O); r_.nseq = O.nseq; r_.lrun = O.lrun; r_.olen = S.op; r_.tag = tag; r_.pad0 = r_.pad1 = 0; \
+                qzk_rec r_; r_.pos = at_; r_.nlit = QZK_NLIT(O); r_.nseq = O.nseq; r_.lrun = O.lrun; r_.olen = S.op; r_.tag = tag; r_.pad0 = tag_hi; r_.pad1 = 0; \
                 myrec[ridx++] = r_; \
             } \
-            if (st.kind == QZK_ST_RUN && (QZK_NLIT(O) > lit_cap || O.nseq > seq_cap || at_ >= give_up || at_ >= over)) { \
+            if (st.kind == QZK_ST_RUN && (QZK_TOK_FULL(O) || at_ >= give_up || at_ >= over)) { \
                 st.kind = QZK_ST_REDO; st.cidx = at_ >= give_up ? 1u : at_ >= over ? 4u : 2u; st.at = at_; } \
             if (st.kind == QZK_ST_RUN && j != 0 && my_at >= *(volatile uint32_t *)&gend[g]) {      /* my share lies behind the block's end: I am decoding garbage */ \
                 st.kind = QZK_ST_REDO; st.cidx = 5u; st.at = at_; } \
@@ -310,7 +331,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                 for (int tries_ = 0; tries_ < 4; tries_++) { \
                     const qzk_rec *q_ = recs + ((uint64_t)(sidx * K + target) * QZK_SPEC_NREC + cursor); \
                     const uint32_t qp_ = qzk_ld32_l2(&q_->pos), qt_ = qzk_ld32_l2(&q_->tag); \
-                    if (qt_ != tag) { again_ = false; break; }     /* not written (yet): the neighbour has not got there, or has stopped */ \
+                    if (qt_ != tag || qzk_ld32_l2(&q_->pad0) != tag_hi) { again_ = false; break; }     /* not written (yet): the neighbour has not got there, or has stopped */ \
                     if (qp_ >= at_) { rp = qp_; again_ = false; break; } \
                     if (cursor + 2 >= QZK_SPEC_NREC) { again_ = false; break; }    /* the trail ends here */ \
                     cursor++; \
@@ -398,7 +419,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
 #if defined(QZ_SIM) && defined(QZK_SPEC_STATS)
         if (getenv("QZDBG_SPEC") && live && sidx == (uint32_t)atoi(getenv("QZDBG_SPEC")))
             fprintf(stderr, "round %u lane %2d: start %8u span %6u stop kind %u cidx %u at %8u trips %5u  target %u cursor %u rp %u wake %u limit %u nlit %u/%u nseq %u/%u ridx %u\n", round, j, my_at, h_span, st.kind, st.cidx,
-                    st.kind == QZK_ST_RUN ? 0u : st.at, ntrip, target, cursor, rp, wake, limit_bits, QZK_NLIT(O), lit_cap, O.nseq, seq_cap, ridx);
+                    st.kind == QZK_ST_RUN ? 0u : st.at, ntrip, target, cursor, rp, wake, limit_bits, QZK_NLIT(O), tok_cap, O.nseq, tok_cap / 8, ridx);
 #endif
 #ifdef QZK_SPEC_STATS          /* emulator builds only (tools/spec_stats.py): trips of every lane and round */
         if (live && round < 8) qzk_spec_stats[(sidx * K + (uint32_t)j) * 8 + round] = (ntrip & 0xffffffu) | (st.kind == QZK_ST_REDO ? (st.cidx & 15u) << 24 : 0u) | st.kind << 28;
@@ -469,7 +490,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                     O.l2 = w > 2 ? v[2] : w == 2 ? v[2] & m : 0u;
                     O.l3 = w == 3 ? v[3] & m : 0u;
                 }
-                if (O.nseq & 1u) O.q0 = ((const uint64_t *)O.sq)[O.nseq - 1u];
+                if (O.nseq & 1u) O.q0 = *((const uint64_t *)O.sq - O.nseq);
             }
             QZK_SPROF(3);
             if (j == 0 && h_mode != 0) {

@@ -1061,6 +1061,12 @@ QZ_KERNEL_OCC(64, 6) qzk_lz4d_kernel(const uint8_t *comp, uint8_t *out, const qz
         uint32_t flg = p[4];
         if ((flg >> 6) != 1 || (flg & 2)) break;
         const bool bcheck = (flg >> 4) & 1, csize = (flg >> 3) & 1, ccheck = (flg >> 2) & 1, dict = flg & 1;
+        /* BD: the frame's largest block (64 KB << 2 (id - 4), id 4..7: 4 MiB at most).  liblz4 refuses a block above it
+         * (LZ4F_decompress: maxBlockSizeInvalid / "block size > maxBlockSize"), and so must this decoder: the walk below adds
+         * sequence lengths in 32 bits, and only a block of 16 MiB and more could make such a sum wrap */
+        const uint32_t bd = p[5], bid = (bd >> 4) & 7;
+        if ((bd & 0x8f) || bid < 4) break;
+        const uint32_t bmax = 65536u << (2 * (bid - 4));
         pos = 6 + (csize ? 8 : 0) + (dict ? 4 : 0);
         if (pos + 1 > n) { status = QZK_LZ4_EIN; break; }
         if (p[pos] != ((qzk_wave_xxh32(p + 4, pos - 4, lane) >> 8) & 0xff)) break;
@@ -1071,6 +1077,7 @@ QZ_KERNEL_OCC(64, 6) qzk_lz4d_kernel(const uint8_t *comp, uint8_t *out, const qz
             uint32_t bh = qz_ld32(p + pos); pos += 4;
             if (bh == 0) break;
             uint32_t bsz = bh & 0x7fffffffu;
+            if (bsz > bmax) { ok = false; break; }
             if (bsz > n - pos) { status = QZK_LZ4_EIN; ok = false; break; }
             if (bh & 0x80000000u) {
                 if (bsz > sg.out_cap - S.obase) { status = QZK_LZ4_EOUT; ok = false; break; }

@@ -315,16 +315,18 @@ static void two_phase_serial(const uint8_t *comp, uint8_t *out, const qzk_infseg
     std::vector<qzk_inf_tab> tabs(nsegs);
     std::vector<qzk_tokseg> ts(nsegs);
     std::vector<qzk_chain> chains(nsegs);
-    uint64_t lt = 0, sqt = 0;
+    /* one arena, a region per segment: literals up from its first byte, sequences down from its end (qzk_inflate_lane.h) */
+    uint64_t lt = 0;
     for (uint32_t i = 0; i < nsegs; i++) {
-        ts[i].lit_off = lt; ts[i].seq_off = sqt;
-        if (!(segs[i].flags & QZK_INF_COUNT_ONLY)) { lt += QZK_TOK_LITCAP(segs[i].out_cap); sqt += QZK_TOK_SEQCAP(segs[i].out_cap); }
+        const uint64_t rg = segs[i].flags & QZK_INF_COUNT_ONLY ? 0 : QZK_TOK_REGION(segs[i].out_cap);
+        ts[i].lit_off = lt; ts[i].seq_off = (lt + rg) / 8;
+        lt += rg;
     }
-    std::vector<uint8_t> lits(lt + 1088, 0xee);          /* phase B reads whole 16-byte rows (qzk_lz_batch.h) */
-    std::vector<qzk_seq> seqs(sqt + 8);
+    std::vector<uint64_t> arena((lt + 1088) / 8 + 1, 0xeeeeeeeeeeeeeeeeull);          /* phase B reads whole 16-byte rows (qzk_lz_batch.h) */
+    uint8_t *const lits_p = (uint8_t *)arena.data(); qzk_seq *const seqs_p = (qzk_seq *)arena.data();
     /* 16 segments per workgroup; the emulator wants whole waves, the kernel bounds-checks */
     sim::launch((nsegs + 15) / 16, 64, 0, [&] {
-        if (threadIdx.x < 16) qzk_inflate_tok_kernel<16>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data(), nullptr, 0u, 1u);
+        if (threadIdx.x < 16) qzk_inflate_tok_kernel<16>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits_p, seqs_p, chains.data(), nullptr, 0u, 1u);
     });
     /* phase B the way the host streams output: launches over index lists (here: the segments in reverse, two parts) */
     std::vector<uint32_t> ord(nsegs);
@@ -334,7 +336,7 @@ static void two_phase_serial(const uint8_t *comp, uint8_t *out, const qzk_infseg
         const uint32_t first = part ? half : 0, cnt = part ? nsegs - half : half;
         if (!cnt) continue;
         sim::launch((cnt + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
-            qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), 1u, lits.data(), seqs.data(), chains.data(),
+            qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), 1u, lits_p, seqs_p, chains.data(),
                                   ord.data() + first, cnt);
         });
     }
@@ -357,22 +359,23 @@ static int two_phase_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *s
     std::vector<qzk_tokseg> ts((size_t)nsegs * K);
     std::vector<qzk_chain> chains(nsegs);
     std::vector<qzk_rec> recs((size_t)nsegs * K * QZK_SPEC_NREC);
-    uint64_t lt = 0, sqt = 0;
+    uint64_t lt = 0;
     for (uint32_t i = 0; i < nsegs; i++)
         for (int j = 0; j < K; j++) {
-            ts[(size_t)i * K + j].lit_off = lt; ts[(size_t)i * K + j].seq_off = sqt;
-            lt += QZK_SPEC_LITCAP(segs[i].out_cap, K, j); sqt += QZK_SPEC_SEQCAP(segs[i].out_cap, K, j);
+            const uint64_t rg = QZK_SPEC_REGION(segs[i].out_cap, K, j);
+            ts[(size_t)i * K + j].lit_off = lt; ts[(size_t)i * K + j].seq_off = (lt + rg) / 8;
+            lt += rg;
         }
-    std::vector<uint8_t> lits(lt + 1088, 0xee);          /* phase B reads whole 16-byte rows (qzk_lz_batch.h) */
-    std::vector<qzk_seq> seqs(sqt + 8);
+    std::vector<uint64_t> arena((lt + 1088) / 8 + 1, 0xeeeeeeeeeeeeeeeeull);          /* phase B reads whole 16-byte rows (qzk_lz_batch.h) */
+    uint8_t *const lits_p = (uint8_t *)arena.data(); qzk_seq *const seqs_p = (qzk_seq *)arena.data();
     const uint32_t spw = 64 / K;
     sim::launch((nsegs + spw - 1) / spw, 64, 0, [&] {
-        static uint32_t epoch = 0;
+        static uint64_t epoch = (5ull << 22) - 40;               /* launch numbers that cross the tag's own 22 bits: the high part lives in the record's second word */
         if (threadIdx.x == 0 && blockIdx.x == 0) epoch++;
-        qzk_inflate_spec_kernel<K>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits.data(), seqs.data(), chains.data(), recs.data(), epoch + 1, (uint32_t)(getenv("QZSIM_OVER") ? atoi(getenv("QZSIM_OVER")) : 1));
+        qzk_inflate_spec_kernel<K>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits_p, seqs_p, chains.data(), recs.data(), epoch + 1, (uint32_t)(getenv("QZSIM_OVER") ? atoi(getenv("QZSIM_OVER")) : 1));
     });
     sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
-        qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), (uint32_t)K, lits.data(), seqs.data(), chains.data(), nullptr, 0);
+        qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), (uint32_t)K, lits_p, seqs_p, chains.data(), nullptr, 0);
     });
     if (getenv("QZSIM_TRACE"))
         for (uint32_t i = 0; i < nsegs; i++) {

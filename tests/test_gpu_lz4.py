@@ -58,6 +58,25 @@ def test_decode_rejects_corruption(ctx):
         d_c.free(); d_o.free()
 
 
+def test_decode_refuses_a_block_above_the_frames_maximum(ctx):
+    """LZ4F_decompress refuses a block larger than the BD byte's maximum block size; the decoder's 32-bit length sums
+    rely on the same bound.  A frame that declares 64 KB blocks and carries one stored block of 70000 bytes
+    is well-formed in every other respect (header checksum, end mark, content checksum)."""
+    import struct
+    import xxhash
+    body = datagen.gen_bytes("text", 70000, 3)
+    for bd, want_ok in ((0x40, False), (0x50, True)):            # 64 KB declared: refused; 256 KB declared: the same bytes decode
+        hdr = bytes([0x60 | 0x04, bd])                           # version 1, independent blocks, content checksum
+        frame = struct.pack("<I", 0x184D2204) + hdr + bytes([(xxhash.xxh32(hdr).intdigest() >> 8) & 0xff])
+        frame += struct.pack("<I", 0x80000000 | len(body)) + body + struct.pack("<I", 0) + struct.pack("<I", xxhash.xxh32(body).intdigest())
+        d_c = ctx.alloc(len(frame)); d_c.upload(frame); d_o = ctx.alloc(len(body))
+        res = ctx.lz4_decompress_frames(d_c, d_o, [(0, 0, len(frame), len(body))])
+        assert (res[0]["status"] == 0) == want_ok, (hex(bd), res[0])
+        if want_ok:
+            assert d_o.download(len(body)).tobytes() == body
+        d_c.free(); d_o.free()
+
+
 def test_api_lz4_session_roundtrip_and_parity():
     s = A.Session(lz4=True)
     assert s.rc_setup == A.QZ_OK

@@ -35,5 +35,9 @@ for mb, ck in shapes:
         if dt < best:
             best = dt; bms = ctx.inflate_timing()
     ok = (iu, ol, crc) == (clen, n, want)
-    print("%-14s %5d MiB / %3d KiB chunks: inflate %6.2f GB/s  wall %7.2f ms  kernels %7.2f = A %6.2f + B %6.2f, crc %5.2f ms  %s"
-          % (name, mb, ck, n / best / 1e9, best * 1e3, bms[0], bms[0] - bms[2], bms[2], bms[1], "OK" if ok else "MISMATCH"), flush=True)
+    try:
+        scr = ctx.L.qzd_inflate_scratch_bytes(ctx.h) / n
+    except AttributeError:                                     # a variant library older than the getter
+        scr = float("nan")
+    print("%-14s %5d MiB / %3d KiB chunks: inflate %6.2f GB/s  wall %7.2f ms  kernels %7.2f = A %6.2f + B %6.2f, crc %5.2f ms  scratch %.2f x output  %s"
+          % (name, mb, ck, n / best / 1e9, best * 1e3, bms[0], bms[0] - bms[2], bms[2], bms[1], scr, "OK" if ok else "MISMATCH"), flush=True)
