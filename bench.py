@@ -388,7 +388,7 @@ def src_sha256():
     return h.hexdigest()
 
 
-def pmc_traffic(fname, command_has, kernels):
+def pmc_traffic(fname, command_has, kernels, key="hbm_bytes_fetch_x2"):
     """HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction) of the kernels whose names start
     with one of `kernels`, summed, from the committed rocprofv3 --pmc summary profiles/<fname> (tools/pmc_summary.py) - or
     None when the file is missing, was taken from other sources than the ones that are running (src_sha256) or from another
@@ -403,7 +403,7 @@ def pmc_traffic(fname, command_has, kernels):
             ks = [k for k in pj["kernels"] if k.startswith(pre)]
             if not ks:
                 return None
-            tot += pj["kernels"][max(ks, key=lambda k: pj["kernels"][k]["hbm_bytes_fetch_x2"])]["hbm_bytes_fetch_x2"]   # the whole-call launch
+            tot += pj["kernels"][max(ks, key=lambda k: pj["kernels"][k]["hbm_bytes_fetch_x2"])][key]   # the whole-call launch
         return tot
     except (OSError, KeyError, ValueError):
         return None
@@ -443,8 +443,8 @@ def raw_sweep(ctx, qz, d_src, mb, sizes=(16384, 65536, 131072)):
                     "ratio": round(cl / n, 4), "lz77_ms_first_batch": round(k1[0], 2),
                     "deflate_kernel_ms": round(kc, 2), "deflate_frac": round(alg / (kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kc > 0 else None,
                     "inflate_kernel_ms": round(kd, 2), "inflate_frac": round(alg / (kd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kd > 0 else None,
-                    "deflate_traffic": pmc_traffic("r5_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),), ("qzk_lz77_pull_kernel",)),
-                    "inflate_traffic": pmc_traffic("r5_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),),
+                    "deflate_traffic": pmc_traffic("r6_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),), ("qzk_lz77_pull_kernel",)),
+                    "inflate_traffic": pmc_traffic("r6_raw%d_pmc.json" % (hw >> 10), ("legs_run.py raw%d %d" % (hw >> 10, mb),),
                                                    ("qzk_inflate_spec_kernel", "qzk_lz_resolve_kernel"))}
     assert ctx.crc32(d_b, n) == ctx.crc32(view(qz, d_src, 0, n), n)
     d_c.free(); d_b.free()
@@ -481,8 +481,8 @@ def lz4_leg(ctx, qz, d_src, mb):
             "ratio": round(cl / n, 4),
             "compress_kernel_ms": round(kc, 2), "compress_frac": round(alg / (kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kc > 0 else None,
             "decompress_kernel_ms": round(kd, 2), "decompress_frac": round(alg / (kd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kd > 0 else None,
-            "compress_traffic": pmc_traffic("r5_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4c_pull_kernel",)),
-            "decompress_traffic": pmc_traffic("r5_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4d_kernel",)),
+            "compress_traffic": pmc_traffic("r6_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4c_pull_kernel",)),
+            "decompress_traffic": pmc_traffic("r6_lz4_pmc.json", ("legs_run.py lz4 %d" % mb,), ("qzk_lz4d_kernel",)),
             "note": "64 KB frames, XXH32 content checksum made and verified in-kernel; call rates host call to host return, "
                     "kernel_ms / frac = (U + C) over the kernels' HIP-event time over the HBM peak"}
 
@@ -788,6 +788,8 @@ def main():
     k_ms = ctx.timing()                      # the probe: one launch of three rounds over the resident waves
     comp_total = allreduce(pg, float(sum(comp_len)), "SUM")
     raw_total = float(total) * world
+    from qatzip_amd import shard as _shard
+    per_rank = _shard.allgather_floats(pg, [tc, td])                 # every rank's own compress / decompress pass (seconds)
     tc = allreduce(pg, tc, "MAX"); td = allreduce(pg, td, "MAX")
 
     extra = {}
@@ -849,8 +851,9 @@ def main():
         # FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH x2 per the gfx950 note) and are quoted
         # only when that file was taken from the sources that are running now (SHA-256 over qatzip_amd/csrc) with this
         # command's --mb - null otherwise, never stale.
-        traffic = pmc_traffic("r5_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_lz77_pull_kernel",))
-        traffic_dec = pmc_traffic("r5_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_inflate_spec_kernel", "qzk_lz_resolve_kernel"))
+        traffic = pmc_traffic("r6_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_lz77_pull_kernel",))
+        traffic_dec = pmc_traffic("r6_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_inflate_spec_kernel", "qzk_lz_resolve_kernel"))
+        traffic_raw = pmc_traffic("r6_pmc.json", ("bench.py --mb %d " % args.mb,), ("qzk_lz77_pull_kernel",), key="hbm_bytes_raw")
         value = 2.0 * raw_total * args.steps / dt / 1e9
         ratio = comp_total / raw_total
         # algorithmic bytes of the K1 launches of the timed region: every input byte read once, every compressed byte
@@ -874,6 +877,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "qzk_lz77_pull_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
+                         # both readings of the counters: `traffic` = FETCH_SIZE x 2 + WRITE_SIZE (the guide's gfx950 correction, calibrated on
+                         # wide streaming reads), `traffic_raw` = FETCH_SIZE + WRITE_SIZE as counted.  For this kernel's scattered 16-byte
+                         # requests x 2 over-corrects (at the launch's duration it would be more than the copy rate measured on the box);
+                         # the truth lies between.  Of the fetched bytes the table gathers are ~24 B per input byte, the far candidates'
+                         # sixteen bytes ~37 (profiles/r6_k1_experiments.txt item 2)
+                         "traffic_raw": traffic_raw,
                          "peak_measured_copy": copy_peak,
                          "frac_of_measured_copy": round(achieved / copy_peak, 6) if copy_peak else None,
                          "launch_ms": round(launch_ms, 3), "launches": int(k1_launches),
@@ -884,8 +893,10 @@ def main():
                          # compiled out - the parse and the CRC alone, measured once on an MI355X, not by this run
                          "design_ceiling_GBps": {"value": 58.5, "compress_input_GBps": 42.2, "launch_ms_4GiB": 101.8,
                                                  "what": "qzk_lz77_pull_kernel with K2 compiled out (-DQZK_K1_NOK2), 4 GiB, (U + C) / launch; K2 in "
-                                                         "the wave costs 12.6 of 114.5 ms, the parse is bound by its table requests: parked",
-                                                 "source": "profiles/r5_k1_without_k2.txt"},
+                                                         "the wave costs 12.6 of 114.5 ms.  Round 6: the parse is NOT bound by its table requests - 44 % of "
+                                                         "them removed (an LDS cache of entries) and their wait hidden (entries asked a window ahead) left the "
+                                                         "launch no faster; a window is a chain of ~100 dependent LDS / cross-lane / scalar steps",
+                                                 "source": "profiles/r5_k1_without_k2.txt, profiles/r6_k1_experiments.txt"},
                          "other_kernels_ms": {"separate K2 / CRC launches": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
                                               "inflate kernels (last call)": round(inf_ms[0], 3),
                                               "of which qzk_lz_resolve_kernel": round(inf_ms[2], 3),
@@ -913,6 +924,17 @@ def main():
             res["config"]["ranks_share_devices"] = "%d ranks on %d device(s)" % (world, ndev)
         if one is not None:
             res["config"]["one_stream"] = one
+        if world > 1:
+            # what a SCALE record is read for, at the top level: every rank's own rates (its 4 GiB per direction) and what
+            # the multi-GPU member costs (the gathers' share of a pass that no deflate ran beside)
+            res["per_rank"] = {"compress_GBps": [round(total / r[0] / 1e9, 2) for r in per_rank],
+                               "decompress_GBps": [round(total / r[1] / 1e9, 2) for r in per_rank]}
+            if isinstance(one, dict):
+                for tr in ("ipc", "rccl"):
+                    leg = one.get(tr) if isinstance(one.get(tr), dict) else None
+                    if leg and "gather_share" in leg:
+                        res.setdefault("one_stream_gather_share", {})[tr] = leg["gather_share"]
+                        res.setdefault("one_stream_GBps", {})[tr] = leg.get("GBps", leg.get("value"))
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_mb, args.base_mb, args.cpu_threads)
         print(json.dumps(res), flush=True)

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <atomic>
 
 #include "qzd_internal.h"
 #include "qzk_deflate_huff.h"
@@ -161,15 +162,23 @@ extern "C" int qzd_device_count(void)
  * 14 ms of the copy in, or behind its sibling's phase A (profiles/r5_api_decompress_pieces.txt).  A stream created with a
  * CU mask is never pooled; the mask here names every CU.  (Such a stream is a blocking one: this library puts nothing on
  * the null stream while the streams made here are busy.)  Falls back to a stream of the highest priority, then to an
- * ordinary one. */
-static hipError_t stream_own_queue(hipStream_t *st, int device)
+ * ordinary one.  Hardware queues are few: a process holds at most QZD_OWN_QUEUES of these per device across all its
+ * sessions (QATZIP_AMD_OWN_QUEUES=<n>; sixty-four sessions with two each ran the small-call sweep at a fifth of its rate) -
+ * the sessions that come later get pooled streams and a slower piece-wise decode, not a slower everything. */
+#define QZD_OWN_QUEUES 20
+static std::atomic<int> g_own_queues[QZD_MAX_DEVICES];
+static hipError_t stream_own_queue(hipStream_t *st, int device, qzd_ctx *owner)
 {
     hipDeviceProp_t prop;
-    if (!getenv("QATZIP_AMD_POOLED_STREAMS") && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+    int cap = QZD_OWN_QUEUES;
+    const char *ce = getenv("QATZIP_AMD_OWN_QUEUES");
+    if (ce) cap = atoi(ce);
+    std::atomic<int> &held = g_own_queues[device % QZD_MAX_DEVICES];
+    if (!getenv("QATZIP_AMD_POOLED_STREAMS") && held.load() < cap && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         uint32_t mask[32];
         const uint32_t cus = (uint32_t)std::min(prop.multiProcessorCount, 1024), words = (cus + 31) / 32;
         for (uint32_t w = 0; w < words; w++) mask[w] = w + 1 < words || (cus & 31u) == 0 ? 0xffffffffu : (1u << (cus & 31u)) - 1u;
-        if (hipExtStreamCreateWithCUMask(st, words, mask) == hipSuccess) return hipSuccess;
+        if (hipExtStreamCreateWithCUMask(st, words, mask) == hipSuccess) { held++; owner->own_queues++; return hipSuccess; }
         (void)hipGetLastError();
     }
     int least = 0, greatest = 0;
@@ -184,8 +193,8 @@ static hipError_t stream_own_queue(hipStream_t *st, int device)
 int qzd_pipe_streams(qzd_ctx *c)
 {
     if (c->pq_copy && c->pq_out) return QZD_OK;
-    if (!c->pq_copy && stream_own_queue(&c->pq_copy, c->device) != hipSuccess) { c->pq_copy = NULL; return QZD_ERR_HIP; }
-    if (!c->pq_out && stream_own_queue(&c->pq_out, c->device) != hipSuccess) { c->pq_out = NULL; return QZD_ERR_HIP; }
+    if (!c->pq_copy && stream_own_queue(&c->pq_copy, c->device, c) != hipSuccess) { c->pq_copy = NULL; return QZD_ERR_HIP; }
+    if (!c->pq_out && stream_own_queue(&c->pq_out, c->device, c) != hipSuccess) { c->pq_out = NULL; return QZD_ERR_HIP; }
     return QZD_OK;
 }
 static int ctx_create(int device, qzd_ctx **out, bool helper);
@@ -212,7 +221,7 @@ static int ctx_create(int device, qzd_ctx **out, bool helper)
 #define QZD_CREATE_FAIL do { qzd_destroy(c); return QZD_ERR_HIP; } while (0)   /* no half-built context leaks */
     for (int i = 0; i < QZD_NBUF; i++) {
         if (helper && i > 0) c->st[i] = c->st[0];
-        else if ((helper ? stream_own_queue(&c->st[i], device) : hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking)) != hipSuccess) QZD_CREATE_FAIL;
+        else if ((helper ? stream_own_queue(&c->st[i], device, c) : hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking)) != hipSuccess) QZD_CREATE_FAIL;
         hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->k1done[i], hipEventDisableTiming);
         for (int k = 0; k < 4; k++) hipEventCreate(&c->ev[i][k]);
@@ -285,6 +294,7 @@ extern "C" void qzd_destroy(qzd_ctx *c)
     if (c->d_lane) hipFree(c->d_lane);
     if (c->d_cdesc) hipFree(c->d_cdesc);
     for (int i = 0; i < 8; i++) { if (c->pipe_ctx[i]) qzd_destroy(c->pipe_ctx[i]); if (c->pipe_ev[i]) hipEventDestroy(c->pipe_ev[i]); }
+    g_own_queues[c->device % QZD_MAX_DEVICES] -= (int)c->own_queues;
     delete c;
 }
 
@@ -603,7 +613,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         /* level 1: one chunk per wave (K1, window speculation over the four-newest table); levels 2-9: zlib's own loop
          * and tables, one chunk per LANE (K1b).  QATZIP_AMD_DEFLATE=lane takes level 1 through K1b as well. */
         const char *force = getenv("QATZIP_AMD_DEFLATE");
-        if ((level != 1 || (force && force[0] == 'l')) && h_src && n) HIPCHK(c, hipMemcpy((void *)d_src, h_src, n, hipMemcpyHostToDevice));
+        if ((level != 1 || (force && force[0] == 'l')) && h_src && n) { HIPCHK(c, hipMemcpyAsync((void *)d_src, h_src, n, hipMemcpyHostToDevice, c->st[0])); HIPCHK(c, hipStreamSynchronize(c->st[0])); }    /* (not the null stream: it would wait for every blocking stream of the process) */
         /* the lazy levels have their own, parallel, path; QATZIP_AMD_LAZY=0 sends them through K1b instead */
         const char *lz = getenv("QATZIP_AMD_LAZY");
         if (level >= 4 && !(lz && lz[0] == '0')) return deflate_lazy_path(c, d_src, n, chunk_sz, level, last, d_dst, dst_cap, nchunks, cdesc);
@@ -616,7 +626,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         const char *k1 = getenv("QATZIP_AMD_K1");
         const bool force_wide = k1 && k1[0] == 'w', force_pull = k1 && k1[0] == 'p';
         if (chunk_sz <= 65536 && (force_wide || (!force_pull && nchunks <= c->cus + c->cus / 2))) {      /* measured crossover: profiles/r4_k1_crossover.txt */
-            if (h_src && n) HIPCHK(c, hipMemcpy((void *)d_src, h_src, n, hipMemcpyHostToDevice));
+            if (h_src && n) { HIPCHK(c, hipMemcpyAsync((void *)d_src, h_src, n, hipMemcpyHostToDevice, c->st[0])); HIPCHK(c, hipStreamSynchronize(c->st[0])); }
             return deflate_wide_path(c, d_src, n, chunk_sz, last, d_dst, dst_cap, nchunks, cdesc);
         }
     }

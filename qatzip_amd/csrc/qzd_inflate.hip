@@ -1076,7 +1076,7 @@ extern "C" int qzd_inflate_stream_from_host(qzd_ctx *c, const uint8_t *h_src, ui
     }
     if (P >= 2) cut[P] = n;                                         /* (fewer helpers than planned: the last one takes the rest) */
     if (P < 2) {
-        HIPCHK(c, hipMemcpy(d_src, h_src, n, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpyAsync(d_src, h_src, n, hipMemcpyHostToDevice, c->st[0])); HIPCHK(c, hipStreamSynchronize(c->st[0]));      /* (not the null stream) */
         return inflate_stream(c, d_src, n, d_dst, dst_cap, seg_hint, h_in_used, h_out_len, h_crc, h_dst, h_sent);
     }
     c->inf_ms[0] = c->inf_ms[1] = c->inf_ms[2] = c->inf_ms[3] = 0;

@@ -64,6 +64,7 @@ struct qzd_ctx {
     /* helpers of a piece-wise host-to-host decode (qzd_inflate_stream_from_host): contexts of their own - streams, scratch,
      * pinned staging - so that the pieces' phases run side by side; made at the first such call, freed with this context */
     struct qzd_ctx *pipe_ctx[8]; hipEvent_t pipe_ev[8];
+    uint32_t own_queues;                            /* streams of this context that hold a hardware queue of their own (counted per device) */
     char err[256];
 };
 

@@ -440,3 +440,15 @@ def allreduce(pg, v: float, op: str) -> float:
     t = torch.tensor([v], dtype=torch.float64)
     pg.all_reduce(t, op=getattr(pg.ReduceOp, op))
     return float(t[0])
+
+
+def allgather_floats(pg, vals):
+    """every rank's list of floats, rank by rank (a world of one: its own)"""
+    if pg is None:
+        return [list(vals)]
+    import torch
+    world = pg.get_world_size()
+    mine = torch.tensor(list(vals), dtype=torch.float64)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    pg.all_gather(out, mine)
+    return [[float(x) for x in t] for t in out]

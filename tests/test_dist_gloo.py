@@ -46,6 +46,8 @@ def _worker(rank, world, port, q):
     recs = S.all_gather_records(dist, S.pack_record(len(mine), len(comp), zlib.crc32(mine)), world)
     offs, raw, total, crc = S.fold_records(recs)
     t = S.allreduce(dist, float(rank + 1), "MAX")
+    # what bench.py's top level reports for N > 1: every rank's own pass times, rank by rank
+    assert S.allgather_floats(dist, [rank + 0.5, 10.0 * rank]) == [[r + 0.5, 10.0 * r] for r in range(world)]
     q.put((rank, offs[rank], comp, raw, total, crc, t))
     dist.barrier()
     dist.destroy_process_group()
