@@ -246,7 +246,7 @@ static int ctx_create(int device, qzd_ctx **out, bool helper)
         unsigned a = 0;
         if (e && sscanf(e, "%u", &a) == 1 && a > 0 && a <= 65536) c->k1_wgs = a;
         c->batch_chunks = QZD_BATCH_ROUNDS * c->k1_wgs;
-        /* the tables (16 MiB per workgroup, 4 GiB for a full device) belong to the device (g_k1pool): allocated by the
+        /* the tables (4 MiB per workgroup, 5 GiB for a full device) belong to the device (g_k1pool): allocated by the
          * first call that needs them and only as many as its chunks can occupy, shared by every context on the GPU */
         if (hipMalloc(&c->k1_counter, QZD_NBUF * 4) != hipSuccess) QZD_CREATE_FAIL;
     }
@@ -630,7 +630,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
             return deflate_wide_path(c, d_src, n, chunk_sz, last, d_dst, dst_cap, nchunks, cdesc);
         }
     }
-    const uint32_t max_wgs = (c->k1_wgs + QZK_K1_WAVES - 1) / QZK_K1_WAVES;      /* workgroups of a full launch (one per CU) */
+    const uint32_t max_wgs = (c->k1_wgs + QZK_K1_WAVES - 1) / QZK_K1_WAVES;      /* workgroups of a full launch (QZK_K1_OCC per CU) */
     qzd_k1pool *const pool = &g_k1pool[c->device % QZD_MAX_DEVICES];
     pthread_once(&g_k1pool_once, k1pool_init);
     /* The device's tables and batch scratch are used by one call at a time - on the GPU: this call's streams wait for the

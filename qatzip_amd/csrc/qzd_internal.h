@@ -28,12 +28,12 @@ struct qzd_ctx {
     uint32_t cus;                                   /* compute units of the device */
     /* output slots of the LZ4 frame kernel (the deflate pipeline's scratch lives in the device's pool, qzd_k1pool) */
     uint8_t *slots[QZD_NBUF];
-    /* K1 (persistent pull kernel): one candidate table (65536 x QZK_K1_WAVES entries of 16 bytes = 16 MiB) per resident
+    /* K1 (persistent pull kernel): one candidate table (65536 x QZK_K1_WAVES entries of 16 bytes = 4 MiB) per resident
      * workgroup, one chunk counter per buffer set */
     /* The tables belong to the DEVICE, not to the context (qzd_k1pool): every session of a process on one GPU parses
-     * with the same 4 GiB - a context borrows them from its first K1 launch of a call until qzd_sync(). */
+     * with the same 5 GiB - a context borrows them from its first K1 launch of a call until qzd_sync(). */
     uint32_t *k1_counter;
-    uint32_t k1_wgs;                                /* resident pulling WAVES (QZK_K1_WAVES per workgroup, one workgroup per CU) */
+    uint32_t k1_wgs;                                /* resident pulling WAVES (QZK_K1_WAVES per workgroup, QZK_K1_OCC workgroups per CU) */
     uint32_t batch_chunks;
     /* K1 launch durations (HIP events around every K1 launch, harvested at qzd_sync): bench.py's roofline input */
     hipEvent_t k1ev[QZD_K1EV][2]; uint32_t k1ev_chunks[QZD_K1EV]; uint32_t k1ev_n;

@@ -626,7 +626,7 @@ QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t
 }
 
 /* ------------------------------------------------------------------ K1 (+ K2) launch shape
- * Persistent workgroups of QZK_K1_WAVES waves, one per CU; every WAVE pulls chunk numbers from a counter (uneven chunks
+ * Persistent workgroups of QZK_K1_WAVES waves, QZK_K1_OCC per CU; every WAVE pulls chunk numbers from a counter (uneven chunks
  * balance themselves) and owns one column of its workgroup's table: entry h of wave w at
  * tables[(blockIdx.x * 65536 + h) * QZK_K1_WAVES + w].  The waves never talk to each other - what they share is cache
  * lines.  epoch_base + chunk number = the chunk's epoch (host: unique per chunk across launches, never 0).

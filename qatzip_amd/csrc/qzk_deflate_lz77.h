@@ -1,6 +1,6 @@
 /*
  * qzk_deflate_lz77.h — K1: zlib-exact greedy LZ77 parse ("deflate_fast", level 1) of one hw_buff_sz chunk per WAVE
- * (qzk_lz77_chunk), gfx950.  The kernel that runs it - persistent sixteen-wave workgroups whose waves pull chunks, parse
+ * (qzk_lz77_chunk), gfx950.  The kernel that runs it - persistent four-wave workgroups, five to a CU, whose waves pull chunks, parse
  * them, code them (K2) and fold their CRC-32 - is qzk_lz77_pull_kernel in qzk_deflate_huff.h.
  *
  * What it replaces: the deflate() hot loop the reference's software path spends
@@ -20,11 +20,11 @@
  *     newest inserted positions (level 1 never follows more than four links) - one
  *     16-byte gather and one scatter per window, no dependent chain reads.  An entry is
  *     4 x 24-bit chunk offsets + a 32-bit epoch (the chunk's number): a new chunk needs
- *     no clear and zlib's window slide no pass over the table.  The sixteen waves of a
+ *     no clear and zlib's window slide no pass over the table.  The four waves of a
  *     workgroup (one chunk each) share table LINES - bucket h of wave w sits next to
  *     bucket h of wave w+1 - so the buckets every chunk of a corpus keeps hitting (its
  *     common trigrams) are a few thousand fully used lines that stay in L2, instead of
- *     sixteen times as many lines with one live entry each.
+ *     four times as many lines with one live entry each.
  *   - LDS (8 KiB per wave) holds a 4 KiB ring of the input - the last ~3.7 KiB and 328 bytes ahead of the window -
  *     from which the lanes' own bytes, three quarters of the candidates and the extension of long matches are
  *     compared, and the per-window slot tables; far candidates are gathered from HBM/L2.  The chunk's CRC-32 is
@@ -70,17 +70,13 @@
 #define QZK_PF_MINL 30             /* ... and a window whose first lane without an entry comes earlier than this asks the table itself */
 #endif
 #ifndef QZK_NSLOT
-#if QZK_CNB
-#define QZK_NSLOT 256              /* the cache takes half of what the slot tables had: sixteen waves per CU still fit (and cost 3 %) */
-#else
-#define QZK_NSLOT 512
-#endif
+#define QZK_NSLOT 256              /* (512 / 256 were round 5's: 3 % fewer lanes on the exact path, and LDS for sixteen waves a CU only) */
 #endif
 #ifndef QZK_RING
 #define QZK_RING 4096              /* bytes of recent input kept in LDS */
 #endif
 #ifndef QZK_K1_OCC
-#define QZK_K1_OCC 1               /* workgroups per CU the register budget is cut for */
+#define QZK_K1_OCC 5               /* workgroups per CU the register budget is cut for: 5 x 4 waves = five waves a SIMD (96 VGPRs) */
 #endif
 #define QZK_RINGW (QZK_RING / 4)
 #ifndef QZK_NSLOT2                  /* second slot table, keyed by the hash's high bits */
@@ -92,7 +88,12 @@
 #endif
 #define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW + 4 + QZK_NSLOT2 + 3 * QZK_CNB)   /* words of LDS one wave's parse needs */
 #ifndef QZK_K1_WAVES
-#define QZK_K1_WAVES 16            /* waves per K1 workgroup, one chunk each; they share the lines of the candidate table */
+#define QZK_K1_WAVES 4             /* waves per K1 workgroup, one chunk each, one per SIMD; their entries of a bucket are one 64-byte line
+                                    * of the candidate table.  Round 6 (profiles/r6_k1_occupancy.txt): the window is a chain of dependent
+                                    * steps, so waves per SIMD are what the rate follows - 4 x 5 workgroups (twenty waves a CU, slot tables
+                                    * 256 / 256 to fit the LDS) 105 ms per 4 GiB against 113 for 16 x 1; a workgroup's waves go to the SIMDs
+                                    * in turn from SIMD 0, so 10 x 2 leaves a CU with ONE workgroup (3 + 3 waves on a SIMD > 5): 153 ms;
+                                    * 4 x 6 (80 VGPRs, 20 spilled) 119 ms */
 #endif
 
 /* one bucket of the candidate table: the four newest inserted positions with this hash, newest first, as 24-bit chunk
@@ -102,7 +103,7 @@ typedef struct __attribute__((aligned(16))) { uint32_t w0, w1, w2, ep; } qzk_bkt
  * round trips to HBM) */
 typedef uint32_t qzk_u32x4 __attribute__((vector_size(16)));
 
-/* The gather of a table entry is served by the L2 (agent-scope `sc1` load), never by this CU's vector L1: the sixteen
+/* The gather of a table entry is served by the L2 (agent-scope `sc1` load), never by this CU's vector L1: the
  * waves of a workgroup keep their entries of one bucket in one cache line, and the L1 (write-through, no write-allocate,
  * not coherent) may be filled with a copy of that line that is already missing a neighbour wave's latest store - which
  * that wave would then read back as its own entry (seen on gfx950 as soon as two waves shared lines).  The L2 is the

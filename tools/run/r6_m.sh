@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export PYTHONPATH=$GRAFT_REPO_ROOT
+: > gpurun_out/r6m_k1.log
+for v in default w4o5a w4o5b w4o4 default w4o5a w4o5b; do
+  if [ $v = default ]; then unset QATZIP_AMD_SO; else export QATZIP_AMD_SO=$GRAFT_REPO_ROOT/build/var/lib_$v.so; fi
+  timeout 300 python tools/k1_var_run.py 4096 >> gpurun_out/r6m_k1.log 2>&1
+done
+cat gpurun_out/r6m_k1.log
