@@ -52,10 +52,14 @@
  *       ask the segment's sorted list in memory".  On mixed data (text next to bytes of every value) a block has ~220
  *       such symbols carrying up to a fifth of its symbols (tools/inflate_longcodes.py), and fetching each of them
  *       from memory stood on every lane's critical path.
- * While a dynamic block's header is read, the side region holds the code-length code's root (2^7 x u16). */
+ * While a dynamic block's header is read, the side region holds the code-length code's root (2^7 x u16).
+ * The side region's last QZK_SIDE_SPARE bytes belong to the kernel (round 6): phase A with four lanes a segment keeps its
+ * group's END_BLOCK bookkeeping there between two headers - its sixteen rows of root tables are 20 480 bytes, an eighth of a
+ * CU's LDS, and 448 bytes of arrays of its own on top were the eighth wave of every CU (profiles/r6_phaseA_order.txt). */
 #define QZK_CLROOT 7
 #define QZK_SIDE_BYTES 256
-#define QZK_LPOOL_N (QZK_SIDE_BYTES - (1 << QZK_LDROOT))
+#define QZK_SIDE_SPARE 28
+#define QZK_LPOOL_N (QZK_SIDE_BYTES - (1 << QZK_LDROOT) - QZK_SIDE_SPARE)
 #define QZK_LANE_ROOTSZ ((1 << QZK_LLROOT) + QZK_SIDE_BYTES / 2)
 #define QZK_DROOT8(droot) ((uint8_t *)(droot))
 #define QZK_LPOOL(droot) ((uint8_t *)(droot) + (1 << QZK_LDROOT))

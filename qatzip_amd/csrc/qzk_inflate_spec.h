@@ -89,6 +89,28 @@ QZ_DEV uint32_t qzk_ld32_l2(const uint32_t *p) { return *p; }
 QZ_DEV uint32_t qzk_ld32_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
+/* host side: which wave's segments every workgroup of the launch takes.  A wave keeps its spw consecutive segments (their
+ * input, their scratch and their output lie side by side: waves of sixteen segments from sixteen ends of a 4 GiB call, sorted
+ * one by one, took half as long again - profiles/r6_phaseA_order.txt); the WAVES are started longest first, a wave's length
+ * being that of its longest segment's input (a counting sort over 1024 classes of length: 4096 waves in microseconds; waves
+ * of one class keep their order).  worder: (nsegs + spw - 1) / spw entries. */
+static inline void qzk_spec_order_host(const qzk_infseg *hs, uint32_t nsegs, uint32_t spw, uint32_t *worder)
+{
+    const uint32_t nw = (nsegs + spw - 1) / spw;
+    uint32_t maxlen = 1, cnt[1025];
+    for (uint32_t i = 0; i < nsegs; i++) if (hs[i].in_len > maxlen) maxlen = hs[i].in_len;
+    for (uint32_t k = 0; k <= 1024; k++) cnt[k] = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (uint32_t w = 0; w < nw; w++) {
+            uint32_t m = 0;
+            for (uint32_t i = w * spw; i < nsegs && i < (w + 1) * spw; i++) if (hs[i].in_len > m) m = hs[i].in_len;
+            const uint32_t cls = 1023u - (uint32_t)((uint64_t)m * 1023u / maxlen);       /* 0 = the longest */
+            if (pass == 0) cnt[cls + 1]++; else worder[cnt[cls]++] = w;
+        }
+        if (pass == 0) for (uint32_t k = 0; k < 1024; k++) cnt[k + 1] += cnt[k];
+    }
+}
+
 #ifdef QZK_SPEC_STATS
 static uint32_t qzk_spec_stats[1 << 20];
 #endif
@@ -113,7 +135,8 @@ template <int K>
 QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                   qzk_inf_tab *tabs, const qzk_tokseg *ts /* [nsegs * K] */, uint8_t *lits, qzk_seq *seqs,
                                   qzk_chain *chains, qzk_rec *recs /* [nsegs * K * QZK_SPEC_NREC] */, uint64_t epoch /* of the launch, process-wide, never reused */,
-                                  uint32_t over_shares /* shares beyond its own the last lane of a block may decode before the rest is shared out again */)
+                                  uint32_t over_shares /* shares beyond its own the last lane of a block may decode before the rest is shared out again */,
+                                  const uint32_t *worder /* NULL, or the wave whose segments every workgroup takes: the host's longest-first list */)
 {
     constexpr int SPW = 64 / K;                                     /* segments per wave */
     QZ_LDS uint16_t roots[SPW][QZK_LANE_ROOTSZ];
@@ -123,23 +146,34 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
      * puts it in step, it ran to the end of the segment's input - 1400 to 5800 trips where its group-mates made 270 (the
      * emulator's trip counts over the bench data, profiles/r5_phaseA_tail.txt), the whole wave waiting, and the junk tokens
      * filled its scratch, so that it sat out the segment's later blocks.  Now such a lane leaves at its next marked trip. */
-    QZ_LDS uint32_t gend[SPW];
+    /* (K = 4: these live in the spare bytes behind each segment's root tables, qzk_inflate_lane.h - they are written after a round's
+     * headers and dead before the next ones, when the code-length root takes the whole side region) */
+    constexpr bool OVL = 8 + 5 * K <= QZK_SIDE_SPARE;
+    QZ_LDS uint32_t gend_s[OVL ? 1 : SPW];
     /* Only a lane that decodes the TRUE stream may say where the block ends (a lane not yet in step meets a false END_BLOCK
      * once in ~30 000 symbols: some forty times per 64 MiB).  Who is on the true stream is known link by link: lane 0 is; a lane
      * that fell into step with lane t's trail vouches for t from there on, if it is vouched for itself.  Every lane leaves its
      * link (gnext) and its END_BLOCK (geob) when it stops; whoever is confirmed walks the links in front of it. */
-    QZ_LDS uint32_t gconf[SPW], geob[64];
-    QZ_LDS uint8_t gnext[64];
+    QZ_LDS uint32_t gconf_s[OVL ? 1 : SPW], geob_s[OVL ? 1 : 64];
+    QZ_LDS uint8_t gnext_s[OVL ? 4 : 64];
 #ifdef QZK_SPEC_PROF
     QZK_STAMP_IN(1);
 #endif
 
     const int lane = (int)threadIdx.x, g = lane / K, j = lane % K, gbase = lane - j;
-    const uint32_t sidx = blockIdx.x * SPW + (uint32_t)g;
+    /* Which segments: the waves of a launch are started in the order of their numbers and a wave lasts as long as its longest
+     * segment, so the host lists the waves longest (compressed) first - the launch no longer ends with a wave of long
+     * segments that happened to come last (round 6: profiles/r6_phaseA_order.txt) */
+    const uint32_t sidx = (worder ? worder[blockIdx.x] : blockIdx.x) * SPW + (uint32_t)g;
     const bool live = sidx < nsegs;
     const qzk_infseg sg = segs[live ? sidx : 0];
     qzk_inf_tab *T = tabs + (live ? sidx : 0);
     uint16_t *const lroot = roots[g], *const droot = lroot + (1 << QZK_LLROOT);
+    /* my group's: where the block ends, who is confirmed, the lanes' END_BLOCKs [K] and links [K] */
+    uint8_t *const spare = (uint8_t *)droot + QZK_SIDE_BYTES - QZK_SIDE_SPARE;
+    uint32_t *const gend = OVL ? (uint32_t *)spare : &gend_s[OVL ? 0 : g], *const gconf = OVL ? (uint32_t *)(spare + 4) : &gconf_s[OVL ? 0 : g];
+    uint32_t *const geob = OVL ? (uint32_t *)(spare + 8) : &geob_s[OVL ? 0 : gbase];
+    uint8_t *const gnext = OVL ? spare + 8 + 4 * K : &gnext_s[OVL ? 0 : gbase];
     const uint32_t slot = (live ? sidx : 0) * K + (uint32_t)j;     /* my sub-stream */
     qzk_rec *const myrec = recs + (uint64_t)slot * QZK_SPEC_NREC;
     qzk_chain *C = chains + (live ? sidx : 0);
@@ -238,8 +272,8 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
         if (j == 0 && live && seg_done && !p_segdone) p_segdone = QZK_PCLK() - p_start;
 #endif
         if (j == 0 && h_span != 0) prev_span = h_span;
-        if (j == 0) { gend[g] = 0xffffffffu; gconf[g] = 1u; }
-        gnext[lane] = 0xff; geob[lane] = 0xffffffffu;
+        if (j == 0) { *gend = 0xffffffffu; *gconf = 1u; }
+        gnext[j] = 0xff; geob[j] = 0xffffffffu;
         qz_wave_sync();                                             /* the tables (LDS) and their ranges (the segment's record) are the group's now */
         h_mode = qz_shfl(h_mode, gbase); h_end = qz_shfl(h_end, gbase); h_span = qz_shfl(h_span, gbase); h_last = qz_shfl(h_last, gbase);
         h_lmax = qz_shfl(h_lmax, gbase); h_dmax = qz_shfl(h_dmax, gbase); h_lbase = qz_shfl(h_lbase, gbase);
@@ -316,7 +350,7 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
             } \
             if (st.kind == QZK_ST_RUN && (QZK_TOK_FULL(O) || at_ >= give_up || at_ >= over)) { \
                 st.kind = QZK_ST_REDO; st.cidx = at_ >= give_up ? 1u : at_ >= over ? 4u : 2u; st.at = at_; } \
-            if (st.kind == QZK_ST_RUN && j != 0 && my_at >= *(volatile uint32_t *)&gend[g]) {      /* my share lies behind the block's end: I am decoding garbage */ \
+            if (st.kind == QZK_ST_RUN && j != 0 && my_at >= *(volatile uint32_t *)gend) {      /* my share lies behind the block's end: I am decoding garbage */ \
                 st.kind = QZK_ST_REDO; st.cidx = 5u; st.at = at_; } \
             if (rp == 0xffffffffu && target != (uint32_t)j) wake = 0;           /* the neighbour may have written since */ \
         } \
@@ -398,16 +432,16 @@ QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infs
                     /* my link and my END_BLOCK for whoever confirms me; if I am confirmed already, I confirm what lies in front
                      * of me (the lanes of a wave run in lockstep and this block has no wave-wide operation in it: nobody else's
                      * bookkeeping interleaves with mine) */
-                    if (st.kind == QZK_ST_SYNC) gnext[lane] = (uint8_t)st.target;
-                    if (st.kind == QZK_ST_EOB) geob[lane] = st.at;
-                    if ((*(volatile uint32_t *)&gconf[g] >> j) & 1u) {
+                    if (st.kind == QZK_ST_SYNC) gnext[j] = (uint8_t)st.target;
+                    if (st.kind == QZK_ST_EOB) geob[j] = st.at;
+                    if ((*(volatile uint32_t *)gconf >> j) & 1u) {
                         uint32_t t = (uint32_t)j;
                         for (int hop = 0; hop < K; hop++) {
-                            const uint32_t e = *(volatile uint32_t *)&geob[gbase + (int)t];
-                            if (e != 0xffffffffu) atomicMin(&gend[g], e);       /* the block's end, from a lane that is right */
-                            const uint32_t nx = *(volatile uint8_t *)&gnext[gbase + (int)t];
+                            const uint32_t e = *(volatile uint32_t *)&geob[t];
+                            if (e != 0xffffffffu) atomicMin(gend, e);           /* the block's end, from a lane that is right */
+                            const uint32_t nx = *(volatile uint8_t *)&gnext[t];
                             if (nx >= (uint32_t)K || nx == t) break;
-                            atomicOr(&gconf[g], 1u << nx);
+                            atomicOr(gconf, 1u << nx);
                             t = nx;
                         }
                     }
