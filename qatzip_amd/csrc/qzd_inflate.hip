@@ -55,26 +55,33 @@
 #define QZD_LANE_MIN(seg_bytes) ((seg_bytes) <= 65536u + 64u ? QZD_LANE_MIN_SEGS : QZD_LANE_MIN_SEGS_BIG)
 #define QZD_LANE_SEGS_PER_WAVE 16u
 /* lanes per segment of phase A (QATZIP_AMD_INFLATE_K = 1, 4, 8, 16, 32 overrides; 1 = the serial phase A).  The lanes
- * of a segment share its tables in LDS, start at evenly spaced bits and fall into step with each other.  How many: the chip
- * seats 2048 waves of this kernel, and a launch that does not fill it ends with its longest lane - so up to 8192 segments
- * sixteen lanes each (1 GiB of 128 KB segments: 17.1 -> 14.6 ms; 256 MiB of 64 KB: 11.2 -> 8.6; 16 MiB: 5.7 -> 4.1), eight up
- * to 16384, four beyond (a full chip is better served by fewer lanes falling into step).  Exception, measured: segments of
- * 16 KB and less give sixteen lanes under a hundred bytes each.  (Round 4 also kept sixteen lanes from segments above 256 KB:
- * twenty blocks of sixteen pieces outgrew a piece list of 160 and came back through the serial kernel - 1 GiB of 512 KB: 89 ms
- * with eight lanes, 221 with sixteen; the list holds 640 now.) */
+ * of a segment share its tables in LDS, start at evenly spaced bits and fall into step with each other: more lanes, shorter
+ * chains and more waves, but more bits decoded twice.  Round 6 measured the table again with three waves a SIMD to choose from
+ * (profiles/r6_phaseA_order.txt, phase A in ms at 2 / 3 waves a SIMD):
+ *     segments of 64 KB      four lanes     eight          sixteen        thirty-two
+ *      1024 ( 64 MiB)         8.9            5.7            3.8 / 3.7      - / 3.4
+ *      8192 (512 MiB)        12.2            7.8            6.0 / 5.8      - / 6.5
+ *     16384 (  1 GiB)        12.0            8.0            6.2 / 6.4      - / 8.9
+ *     32768 (  2 GiB)        13.0           10.3 / 10.3    10.0 / 8.7      - / 12.8
+ *     65536 (  4 GiB)        17.6           18.7 / 15.6    21.1 / 17.3     - / 22.3
+ *   1 GiB of 128 KB: sixteen 10.5; of 512 KB: thirty-two 18.9 (sixteen 35); of 16 KB (65536 segments): four 5.8, eight 7.4.
+ * So: segments above 16 KB take sixteen lanes up to 32768 of them (thirty-two when they are above 128 KB and few) and eight
+ * beyond; segments of 16 KB and less - sixteen lanes would get under a hundred bytes each - eight up to 16384, four beyond.
+ * (Round 4 kept sixteen lanes from segments above 256 KB: twenty blocks of sixteen pieces outgrew a piece list of 160 and came
+ * back through the serial kernel; the list holds 640 now.) */
 #define QZD_SPEC_LANES 4u
 #define QZD_SPEC_LANES_FEW 8u
 #define QZD_SPEC_FEW_SEGS 16384u
-#define QZD_SPEC_FEW_SEGS_BIG 32768u    /* segments above 16 KB (round 5, 2 GiB of 64 KB: 12.5 ms with four lanes, 11.0 with eight; 65536 segments: the same either way) */
+#define QZD_SPEC_FEW_SEGS_BIG 32768u
 #define QZD_SPEC_LANES_FEWER 16u
 #define QZD_SPEC_FEWER_SEGS 8192u
 static uint32_t spec_lanes(const qzk_infseg *hs, uint32_t nsegs)
 {
-    /* segments above 128 KB hold many blocks one behind the other: thirty-two lanes (round 5, 1 GiB of 512 KB segments:
-     * phase A 35.2 -> 18.4 ms, of 256 KB: 21.3 -> 13.9; at 64 KB sixteen lanes do better, 3.8 against 4.3 ms for 64 MiB) */
-    uint32_t K = nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 131072u + 64u && hs[0].out_cap <= 524288u + 64u ? 32u
-               : nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 16384u + 64u && hs[0].out_cap <= 524288u + 64u ? QZD_SPEC_LANES_FEWER
-               : nsegs <= (hs[0].out_cap > 16384u + 64u ? QZD_SPEC_FEW_SEGS_BIG : QZD_SPEC_FEW_SEGS) ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
+    const bool big = hs[0].out_cap > 16384u + 64u, upto512 = hs[0].out_cap <= 524288u + 64u;
+    uint32_t K = nsegs <= QZD_SPEC_FEWER_SEGS && hs[0].out_cap > 131072u + 64u && upto512 ? 32u
+               : big && upto512 && nsegs <= QZD_SPEC_FEW_SEGS_BIG ? QZD_SPEC_LANES_FEWER
+               : big ? QZD_SPEC_LANES_FEW
+               : nsegs <= QZD_SPEC_FEW_SEGS ? QZD_SPEC_LANES_FEW : QZD_SPEC_LANES;
     const char *ke = getenv("QATZIP_AMD_INFLATE_K");
     if (ke) { int v = atoi(ke); if (v == 1 || v == 4 || v == 8 || v == 16 || v == 32) K = (uint32_t)v; }
     /* it needs a compressed-length hint (qzk_infseg.pad) and segments that write output and begin with no history */
@@ -305,9 +312,16 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
             HIPCHK(c, ctl_copy(ord2_d, st_ord2, (size_t)grid.x * 4, st));
             order = ord2_d;
         }
-#define QZD_SPEC_LAUNCH(N) hipLaunchKernelGGL(qzk_inflate_spec_kernel<N>, grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
+        /* waves per SIMD (qzk_inflate_spec.h): three - with a third of the registers spilled - pay from the third round of
+         * resident waves on (QATZIP_AMD_INFLATE_OCC=2 / 3 overrides) */
+        int socc = grid.x > 16u * c->cus && K != 4 ? 3 : 2;
+        if (occ == 2 || (occ == 3 && K != 4)) socc = occ;
+#define QZD_SPEC_LAUNCH(N, W) hipLaunchKernelGGL((qzk_inflate_spec_kernel<N, W>), grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
                                              ts_d, lit_d, seq_d, ch_d, rec_d, epoch, over, order)
-        if (K == 4) QZD_SPEC_LAUNCH(4); else if (K == 16) QZD_SPEC_LAUNCH(16); else if (K == 32) QZD_SPEC_LAUNCH(32); else QZD_SPEC_LAUNCH(8);
+        if (K == 4) QZD_SPEC_LAUNCH(4, 2);
+        else if (K == 16) { if (socc == 3) QZD_SPEC_LAUNCH(16, 3); else QZD_SPEC_LAUNCH(16, 2); }
+        else if (K == 32) { if (socc == 3) QZD_SPEC_LAUNCH(32, 3); else QZD_SPEC_LAUNCH(32, 2); }
+        else { if (socc == 3) QZD_SPEC_LAUNCH(8, 3); else QZD_SPEC_LAUNCH(8, 2); }
 #undef QZD_SPEC_LAUNCH
         /* what that kernel hands back (QZK_INF_ESPEC: a sub-stream outgrew its scratch, too many pieces) goes through the
          * serial phase A, into the segment's first sub-stream - which is sized for a whole segment */
@@ -1181,8 +1195,8 @@ extern "C" int qzd_inflate_occupancy(int out[4])
 {
     int a = -1, b = -1, c4 = -1, d = -1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, qzk_inflate_tok_kernel<16, QZD_TOK_OCC>, 16, 0);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, qzk_inflate_spec_kernel<4>, 64, 0);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&c4, qzk_inflate_spec_kernel<8>, 64, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, qzk_inflate_spec_kernel<4, 2>, 64, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&c4, qzk_inflate_spec_kernel<8, 3>, 64, 0);
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, qzk_lz_resolve_kernel, 64 * QZK_RES_WAVES, 0);
     out[0] = a; out[1] = b; out[2] = c4; out[3] = d;
     return 0;

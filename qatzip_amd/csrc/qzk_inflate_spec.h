@@ -131,8 +131,13 @@ __device__ unsigned long long qzk_stamp[8];     /* wall-clock (100 MHz) first en
 #define QZK_LOOK_IN() ((void)0)
 #define QZK_LOOK_OUT() ((void)0)
 #endif
-template <int K>
-QZ_KERNEL_OCC(64, 2) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
+/* OCC = waves per SIMD the register budget is cut for.  Two: ~237 VGPRs, nothing spilled - what the kernel wants.  Three: 168
+ * VGPRs, ~95 spilled (230 bytes of scratch a lane) - and still the better deal for a launch of more than two rounds of waves,
+ * because the trip is a dependent chain and a third wave fills what two leave idle (round 6, profiles/r6_phaseA_order.txt:
+ * 4 GiB of 64 KB segments, eight lanes each, 18.7 -> 15.6 ms; four waves a SIMD spill 290 and lose).  K = 4 cannot: its
+ * sixteen rows of root tables are an eighth of the CU's LDS. */
+template <int K, int OCC>
+QZ_KERNEL_OCC(64, OCC) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                   qzk_inf_tab *tabs, const qzk_tokseg *ts /* [nsegs * K] */, uint8_t *lits, qzk_seq *seqs,
                                   qzk_chain *chains, qzk_rec *recs /* [nsegs * K * QZK_SPEC_NREC] */, uint64_t epoch /* of the launch, process-wide, never reused */,
                                   uint32_t over_shares /* shares beyond its own the last lane of a block may decode before the rest is shared out again */,

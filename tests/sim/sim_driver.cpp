@@ -375,7 +375,7 @@ static int two_phase_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *s
     sim::launch((nsegs + spw - 1) / spw, 64, 0, [&] {
         static uint64_t epoch = (5ull << 22) - 40;               /* launch numbers that cross the tag's own 22 bits: the high part lives in the record's second word */
         if (threadIdx.x == 0 && blockIdx.x == 0) epoch++;
-        qzk_inflate_spec_kernel<K>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits_p, seqs_p, chains.data(), recs.data(), epoch + 1, (uint32_t)(getenv("QZSIM_OVER") ? atoi(getenv("QZSIM_OVER")) : 1), order_p);
+        qzk_inflate_spec_kernel<K, 2>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits_p, seqs_p, chains.data(), recs.data(), epoch + 1, (uint32_t)(getenv("QZSIM_OVER") ? atoi(getenv("QZSIM_OVER")) : 1), order_p);
     });
     sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
         qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), (uint32_t)K, lits_p, seqs_p, chains.data(), nullptr, 0);
