@@ -891,12 +891,12 @@ def main():
                          "fused": "K2 (Huffman coding) and the chunk CRC-32 run inside this kernel's waves",
                          # where this design stops (profiles/r5_k1_without_k2.txt): the same launch with K2
                          # compiled out - the parse and the CRC alone, measured once on an MI355X, not by this run
-                         "design_ceiling_GBps": {"value": 58.5, "compress_input_GBps": 42.2, "launch_ms_4GiB": 101.8,
-                                                 "what": "qzk_lz77_pull_kernel with K2 compiled out (-DQZK_K1_NOK2), 4 GiB, (U + C) / launch; K2 in "
-                                                         "the wave costs 12.6 of 114.5 ms.  Round 6: the parse is NOT bound by its table requests - 44 % of "
-                                                         "them removed (an LDS cache of entries) and their wait hidden (entries asked a window ahead) left the "
-                                                         "launch no faster; a window is a chain of ~100 dependent LDS / cross-lane / scalar steps",
-                                                 "source": "profiles/r5_k1_without_k2.txt, profiles/r6_k1_experiments.txt"},
+                         "design_ceiling_GBps": {"value": 57.8, "compress_input_GBps": 41.7, "launch_ms_4GiB": 103.0,
+                                                 "what": "qzk_lz77_pull_kernel with K2 compiled out (-DQZK_K1_NOK2), 4 GiB, (U + C) / launch, on the round's launch shape "
+                                                         "(4 waves x 5 workgroups a CU): K2 in the wave costs 3.2 of 106.2 ms (12.6 of 114.5 at round 5's sixteen waves); the parse "
+                                                         "alone is no faster with twenty waves than with sixteen - it moves 3.5 TB/s of random 64-byte requests (table gathers "
+                                                         "and stores, far candidates; a streaming copy reaches 4.6 on the box)",
+                                                 "source": "profiles/r6_k1_occupancy.txt, profiles/r5_k1_without_k2.txt, profiles/r6_k1_experiments.txt"},
                          "other_kernels_ms": {"separate K2 / CRC launches": round(k_ms[1], 3), "scan+gather": round(k_ms[2], 3),
                                               "inflate kernels (last call)": round(inf_ms[0], 3),
                                               "of which qzk_lz_resolve_kernel": round(inf_ms[2], 3),
