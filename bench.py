@@ -19,15 +19,15 @@ N ranks when no launcher set WORLD_SIZE.
 Beside the headline the line carries (rank 0, N = 1 only, all outside the timed region):
   config.api_*          the same work through qatzip.h itself: ONE qzCompress / qzDecompress call of --api-mb (2047) MiB on
                         qzMalloc(PINNED_MEM) buffers, PCIe both ways included, and its ratio to min(link, kernel rate)
-                        (the decode takes the member in two pieces while it arrives: profiles/r4_api_decompress.txt)
+                        (the decode takes the member in growing pieces while it arrives: profiles/r5_api_decompress_pieces.txt)
   config.pcie_*         plain pinned hipMemcpyAsync, 1 GiB each way, on this box
   config.concurrent_sessions   the buffer as 2 GiB calls of two sessions started together (the harness' -t)
   config.raw_sweep      BASELINE config 3: QZ_DEFLATE_RAW, hw_buff_sz 16 / 64 / 128 KB - call rates, the kernels' own
                         milliseconds (HIP events inside the library), their fraction of the HBM peak and their measured HBM
-                        traffic per launch (profiles/r4_raw<K>_pmc.json)
-  config.lz4            BASELINE config 4: LZ4 frames of 64 KB with XXH32, the same way (profiles/r4_lz4_pmc.json)
+                        traffic per launch (profiles/r6_raw<K>_pmc.json)
+  config.lz4            BASELINE config 4: LZ4 frames of 64 KB with XXH32, the same way (profiles/r6_lz4_pmc.json)
   roofline              the dominant kernel (K1, qzk_lz77_pull_kernel) against the HBM peak (datasheet) and the copy rate
-                        measured on this box; traffic = HBM bytes per launch from profiles/r4_pmc.json
+                        measured on this box; traffic = HBM bytes per launch from profiles/r6_pmc.json
   roofline_decode       the two inflate kernels of a call (phase A + phase B), the same way
   cpu_baseline          the software path's port on every physical core of this host, and this host's own libz
 `traffic` fields are read from the committed rocprofv3 --pmc summaries and only when those were taken from THESE sources
@@ -880,8 +880,8 @@ def main():
                          # both readings of the counters: `traffic` = FETCH_SIZE x 2 + WRITE_SIZE (the guide's gfx950 correction, calibrated on
                          # wide streaming reads), `traffic_raw` = FETCH_SIZE + WRITE_SIZE as counted.  For this kernel's scattered 16-byte
                          # requests x 2 over-corrects (at the launch's duration it would be more than the copy rate measured on the box);
-                         # the truth lies between.  Of the fetched bytes the table gathers are ~24 B per input byte, the far candidates'
-                         # sixteen bytes ~37 (profiles/r6_k1_experiments.txt item 2)
+                         # the truth lies between.  What the bytes are: table gathers (a 16-byte entry per 64-byte line, L2 hit rate
+                         # 19 %), table stores, the far candidates' sixteen bytes and the input (profiles/r6_k1_occupancy.txt)
                          "traffic_raw": traffic_raw,
                          "peak_measured_copy": copy_peak,
                          "frac_of_measured_copy": round(achieved / copy_peak, 6) if copy_peak else None,
