@@ -669,7 +669,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
             if (pool->tables) hipFree(pool->tables);
             pool->tables = NULL; pool->tab_wgs = 0;
             const uint32_t get = want > max_wgs / 4 ? max_wgs : want;     /* a big call: take the whole set at once */
-            const size_t tb = (size_t)get * QZK_HSIZE * QZK_K1_WAVES * sizeof(qzk_bkt);
+            const size_t tb = (size_t)QZK_K1_TABROWS(get) * QZK_HSIZE * QZK_K1_TABW * sizeof(qzk_bkt);
             if (hipMalloc(&pool->tables, tb) != hipSuccess || hipMemset(pool->tables, 0, tb) != hipSuccess ||   /* epoch 0 = never valid */
                 hipDeviceSynchronize() != hipSuccess) {                   /* hipMemset of device memory returns early, and the
                                                                            * (non-blocking) work streams do not wait for it */
@@ -682,7 +682,7 @@ static int deflate_enqueue_impl(qzd_ctx *c, const uint8_t *d_src, uint64_t n, ui
         }
         if ((uint64_t)pool->epoch + nchunks + 1 >= 0xffffffffull) {        /* epochs wrapped: forget everything once */
             hipDeviceSynchronize();
-            hipMemset(pool->tables, 0, (size_t)pool->tab_wgs * QZK_HSIZE * QZK_K1_WAVES * sizeof(qzk_bkt));
+            hipMemset(pool->tables, 0, (size_t)QZK_K1_TABROWS(pool->tab_wgs) * QZK_HSIZE * QZK_K1_TABW * sizeof(qzk_bkt));
             hipDeviceSynchronize();
             pool->epoch = 1;
         }

@@ -628,7 +628,7 @@ QZ_KERNEL_MAX(64) qzk_huff_kernel(const uint8_t *src, uint64_t src_len, uint32_t
 /* ------------------------------------------------------------------ K1 (+ K2) launch shape
  * Persistent workgroups of QZK_K1_WAVES waves, QZK_K1_OCC per CU; every WAVE pulls chunk numbers from a counter (uneven chunks
  * balance themselves) and owns one column of its workgroup's table: entry h of wave w at
- * tables[(blockIdx.x * 65536 + h) * QZK_K1_WAVES + w].  The waves never talk to each other - what they share is cache
+ * tables[(row group * 65536 + h) * QZK_K1_TABW + place * QZK_K1_WAVES + w] (qzk_deflate_lz77.h).  The waves never talk to each other - what they share is cache
  * lines.  epoch_base + chunk number = the chunk's epoch (host: unique per chunk across launches, never 0).
  *
  * With `slots` the wave that parsed a chunk also codes it (K2, qzk_huff_chunk) before it pulls the next one, in the LDS
@@ -775,7 +775,8 @@ QZ_DEV void qzk_lz77_pull_body(const uint8_t *src, uint64_t src_len, uint32_t ch
     if (crc_out) qzk_k1crc_init(&crcT);             /* kernel argument: the whole workgroup takes the same way */
     const int wv = (int)(threadIdx.x >> 6);
     uint32_t *const lds = lds_all[wv];
-    qzk_bkt *tab = tables + (size_t)blockIdx.x * QZK_HSIZE * QZK_K1_WAVES + wv;
+    qzk_bkt *tab = tables + ((size_t)((blockIdx.x / (8u * QZK_K1_TABGRP)) * 8u + (blockIdx.x & 7u)) * QZK_HSIZE) * QZK_K1_TABW
+                          + ((blockIdx.x >> 3) % QZK_K1_TABGRP) * QZK_K1_WAVES + wv;
     uint32_t *const pend = lds + QZK_K1_LDSW;       /* chunks coded by this wave whose bytes have not left their slots yet */
     uint32_t ph = 0, pt = 0;
     for (;;) {

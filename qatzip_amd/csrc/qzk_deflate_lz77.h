@@ -96,6 +96,18 @@
                                     * 4 x 6 (80 VGPRs, 20 spilled) 119 ms */
 #endif
 
+/* Where a workgroup's entries lie in the candidate table.  A bucket's four entries of a four-wave workgroup are one 64-byte
+ * line (a line another workgroup's waves never read).  The lines of QZK_K1_TABGRP workgroups that run on ONE XCD (workgroups are
+ * handed to the eight XCDs in turn, so b, b + 8, b + 16, ... share an L2) lie side by side in a bucket's row: the chunks of a corpus
+ * keep hitting the same buckets (its common trigrams), and neighbouring lines share the L2's 128-byte lines and the DRAM's
+ * pages.  Measured, one 4 GiB launch (profiles/r6_k1_occupancy.txt): G = 1 (a workgroup's table on its own) 105.2 - 105.8 ms, 2 103.9 - 104.1,
+ * 4 104.6, 5 103.6.  Workgroup b: row group (b / (8 G)) * 8 + b % 8, place (b / 8) % G in the row. */
+#ifndef QZK_K1_TABGRP
+#define QZK_K1_TABGRP 5
+#endif
+#define QZK_K1_TABW (QZK_K1_WAVES * QZK_K1_TABGRP)
+#define QZK_K1_TABROWS(wgs) ((((wgs) + 8u * QZK_K1_TABGRP - 1) / (8u * QZK_K1_TABGRP)) * 8u)      /* row groups (of 65536 rows of QZK_K1_TABW entries) a launch of wgs workgroups needs */
+
 /* one bucket of the candidate table: the four newest inserted positions with this hash, newest first, as 24-bit chunk
  * offsets (0 = none: offset 0 is zlib's NIL), valid only while ep equals the epoch of the chunk being parsed */
 typedef struct __attribute__((aligned(16))) { uint32_t w0, w1, w2, ep; } qzk_bkt;
@@ -225,7 +237,7 @@ QZ_DEV int qzk_wave_matchlen(const uint8_t *src, uint64_t src_len, uint64_t a, u
  * table: bkt[hash] = the four most recent inserted positions with that 16-bit hash, newest first - exactly the
  * candidates longest_match() would visit, in its order.  A lookup is a single 16-byte gather instead of a gather plus up
  * to three dependent ones; an insert shifts the entry.  tab points at this wave's column of its workgroup's table (entry
- * h at tab[h * QZK_K1_WAVES]); LDS holds, per wave, a ring of the most recent input and the per-window slot tables. */
+ * h at tab[h * QZK_K1_TABW]); LDS holds, per wave, a ring of the most recent input and the per-window slot tables. */
 QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_sz, uint32_t chunk,
                            uint8_t *sym_lc, uint16_t *sym_dist, qzk_lzmeta *meta, qzk_bkt *tab, uint32_t epoch,
                            const uint32_t *cdesc, uint32_t *lds, const qzk_k1crc_lds *crcT, uint32_t *crc_slot)
@@ -318,7 +330,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 #define QZK_DEFERRED_STORES() do { \
         if ((dPm >> lane) & 1) { const uint32_t i_ = dnsym + (uint32_t)qz_popc64(dPm & qz_below(lane)); \
                                  olc[i_] = (uint8_t)dv_sym; odist[i_] = (uint16_t)(dv_sym >> 8); } \
-        if ((dSTm >> lane) & 1) { const qzk_u32x4 e_ = {dv_e0, dv_e1, dv_e2, epoch}; *(qzk_u32x4 *)&tab[(size_t)dv_h * QZK_K1_WAVES] = e_; } \
+        if ((dSTm >> lane) & 1) { const qzk_u32x4 e_ = {dv_e0, dv_e1, dv_e2, epoch}; *(qzk_u32x4 *)&tab[(size_t)dv_h * QZK_K1_TABW] = e_; } \
         dPm = 0; dSTm = 0; } while (0)
     bool pf_live = false;
 #endif
@@ -447,13 +459,13 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             const uint64_t LACK = qz_ballot(lack);
             if (LACK) {
                 const int fl = qz_ctz64(LACK);
-                if (fl < QZK_PF_MINL + 3) { if (lack) { ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_WAVES]); evhave = true; } QZK_C(15, 1ull << 32); QZK_SIMC(0); }
+                if (fl < QZK_PF_MINL + 3) { if (lack) { ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_TABW]); evhave = true; } QZK_C(15, 1ull << 32); QZK_SIMC(0); }
                 else limdata = fl - 3;
             }
         }
 #else
         const bool evhave = canh && !chit;
-        if (canh && !chit) ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_WAVES]);
+        if (canh && !chit) ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_TABW]);
 #endif
 #if QZK_PF
         if (lim > limdata) lim = limdata;
@@ -468,7 +480,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             q2 = (cp1 & 0xffffu) ? base + (cp1 & 0xffffu) : 0; q3 = (cp1 >> 16) ? base + (cp1 >> 16) : 0;
         }
 #else
-        if (canh) ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_WAVES]);
+        if (canh) ev = qzk_ld_bkt(&tab[(size_t)bucket * QZK_K1_TABW]);
         const bool ev_ok = ev[3] == epoch;                /* another chunk's entry: as good as empty */
         const uint32_t q0 = ev_ok ? ev[0] & 0xffffffu : 0, q1 = ev_ok ? (ev[0] >> 24) | ((ev[1] & 0xffffu) << 8) : 0,
                        q2 = ev_ok ? (ev[1] >> 16) | ((ev[2] & 0xffu) << 16) : 0, q3 = ev_ok ? ev[2] >> 8 : 0;   /* chunk offsets, 0 = none */
@@ -566,7 +578,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
             const uint32_t g0 = (pc0 & 0xffffu) ? base + (pc0 & 0xffffu) : 0, g1 = (pc0 >> 16) ? base + (pc0 >> 16) : 0,
                            g2 = (pc1 & 0xffffu) ? base + (pc1 & 0xffffu) : 0, g3 = (pc1 >> 16) ? base + (pc1 >> 16) : 0;
             pf[0] = g0 | (g1 << 24); pf[1] = (g1 >> 8) | (g2 << 16); pf[2] = (g2 >> 16) | (g3 << 8); pf[3] = epoch;
-            if (pcanh && pct != (ph | 0x10000u)) qzk_ld_bkt_ahead(&pf, &tab[(size_t)ph * QZK_K1_WAVES]);
+            if (pcanh && pct != (ph | 0x10000u)) qzk_ld_bkt_ahead(&pf, &tab[(size_t)ph * QZK_K1_TABW]);
             pf_okm = qz_ballot(pcanh);
         }
 #endif
@@ -743,7 +755,7 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
 #else
         if (store) {
             const qzk_u32x4 e = {n0 | (n1 << 24), (n1 >> 8) | (n2 << 16), (n2 >> 16) | (n3 << 8), epoch};
-            *(qzk_u32x4 *)&tab[(size_t)bucket * QZK_K1_WAVES] = e;
+            *(qzk_u32x4 *)&tab[(size_t)bucket * QZK_K1_TABW] = e;
         }
 #endif
 #if QZK_CNB

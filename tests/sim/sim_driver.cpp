@@ -31,7 +31,7 @@ static void run_k1(uint32_t wgs, const uint8_t *src, uint64_t n, uint32_t chunk_
                    uint32_t *ocrc = nullptr)
 {
     static std::vector<qzk_bkt> tables;
-    const size_t need = (size_t)wgs * QZK_HSIZE * QZK_K1_WAVES;
+    const size_t need = (size_t)QZK_K1_TABROWS(wgs) * QZK_HSIZE * QZK_K1_TABW;
     if (tables.size() < need) {
         qzk_bkt junk; junk.w0 = 0xabcdabcdu; junk.w1 = 0x12345678u; junk.w2 = 0x9abcdef0u; junk.ep = 0;
         tables.assign(need, junk);
