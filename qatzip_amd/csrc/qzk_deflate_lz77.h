@@ -80,18 +80,21 @@
 #endif
 #define QZK_RINGW (QZK_RING / 4)
 #ifndef QZK_NSLOT2                  /* second slot table, keyed by the hash's high bits */
+#define QZK_NSLOT2 128              /* (256 without the third table: 1 ms per 4 GiB slower than 128 + 128) */
+#endif
+#ifndef QZK_NSLOT3                  /* third slot table, keyed by a mix of all the hash's bits (0: none) */
 #if QZK_CNB
-#define QZK_NSLOT2 128
+#define QZK_NSLOT3 0
 #else
-#define QZK_NSLOT2 256
+#define QZK_NSLOT3 128
 #endif
 #endif
-#define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW + 4 + QZK_NSLOT2 + 3 * QZK_CNB)   /* words of LDS one wave's parse needs */
+#define QZK_K1_PARSEW (2 * QZK_NSLOT + QZK_RINGW + 4 + QZK_NSLOT2 + QZK_NSLOT3 + 3 * QZK_CNB)   /* words of LDS one wave's parse needs */
 #ifndef QZK_K1_WAVES
 #define QZK_K1_WAVES 4             /* waves per K1 workgroup, one chunk each, one per SIMD; their entries of a bucket are one 64-byte line
                                     * of the candidate table.  Round 6 (profiles/r6_k1_occupancy.txt): the window is a chain of dependent
                                     * steps, so waves per SIMD are what the rate follows - 4 x 5 workgroups (twenty waves a CU, slot tables
-                                    * 256 / 256 to fit the LDS) 105 ms per 4 GiB against 113 for 16 x 1; a workgroup's waves go to the SIMDs
+                                    * 256 / 128 / 128 to fit the LDS: a workgroup may take 31 KB - 32 064 B were four workgroups a CU) 105 ms per 4 GiB against 113 for 16 x 1; a workgroup's waves go to the SIMDs
                                     * in turn from SIMD 0, so 10 x 2 leaves a CU with ONE workgroup (3 + 3 waves on a SIMD > 5): 153 ms;
                                     * 4 x 6 (80 VGPRs, 20 spilled) 119 ms */
 #endif
@@ -247,15 +250,19 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
      *   scnt[QZK_NSLOT]  per-window: number of lanes on the key
      *   slot2[QZK_NSLOT2] per-window: lowest lane on the hash's HIGH bits - a lane that has an earlier lane with its hash
      *     has one on both keys; half of the lanes the first table alone sent to the exact path had none
+     *   slot3[QZK_NSLOT3] the same under a mix of all sixteen bits: with tables of 256 a lane that has NO earlier lane with its hash
+     *     still finds an earlier lane on its low byte AND another on its high byte in 0.9 windows out of ten (round 6) - each an entry
+     *     into the exact path that leaves at its first test
      *   ring[QZK_RINGW + 4]  the last QZK_RING bytes of input (and ~100 ahead of the parse point).  Every candidate compare
      *     drags a 128-byte line through L2 for 16 bytes, three quarters of them less than 4 KiB back; with a dozen
      *     waves per CU K1 is bound by exactly that traffic (profiles/), so those come from here. */
     uint32_t *const slot = lds, *const scnt = lds + QZK_NSLOT, *const ring = lds + 2 * QZK_NSLOT, *const slot2 = ring + QZK_RINGW + 4;
+    uint32_t *const slot3 = slot2 + QZK_NSLOT2; (void)slot3;
 #if QZK_CNB
     /* the cache of table entries: ctag[s] = hash | 1 << 16 of the entry held (anything else: none - the commit's election
      * leaves its marks here), cpos[s], cpos[QZK_CNB + s] = its four positions, newest first, as 16-bit offsets from the
      * window origin `base` (0 = none: zlib's NIL; what has slid out of the window is NIL to every later lookup) */
-    uint32_t *const ctag = slot2 + QZK_NSLOT2, *const cpos = ctag + QZK_CNB;
+    uint32_t *const ctag = slot3 + QZK_NSLOT3, *const cpos = ctag + QZK_CNB;
 #pragma nounroll
     for (uint32_t i = (uint32_t)qz_lane(); i < QZK_CNB; i += 64) ctag[i] = 0;
 #endif
@@ -521,13 +528,23 @@ QZ_DEV void qzk_lz77_chunk(const uint8_t *src, uint64_t src_len, uint32_t chunk_
              * the lowest lane of its key, or when the key holds exactly two lanes and the other one has a different
              * hash; everything else takes the exact path. */
             const uint32_t key2 = (h >> (16 - 8)) & (QZK_NSLOT2 - 1);
+#if QZK_NSLOT3
+            const uint32_t key3 = ((h * 40503u) >> 12) & (QZK_NSLOT3 - 1);
+            if (canh) slot3[key3] = 0xffffffffu;
+#endif
             if (canh) { slot[key] = 0xffffffffu; scnt[key] = 0; slot2[key2] = 0xffffffffu; }
             qz_lds_sync();
             if (canh) { atomicMin(&slot[key], ((uint32_t)lane << 16) | h); atomicAdd(&scnt[key], 1u); atomicMin(&slot2[key2], (uint32_t)lane); }
+#if QZK_NSLOT3
+            if (canh) atomicMin(&slot3[key3], (uint32_t)lane);
+#endif
             qz_lds_sync();
             {
                 const uint32_t sv = canh ? slot[key] : 0, sc = canh ? scnt[key] : 0, s2 = canh ? slot2[key2] : 0;
                 suspect = canh && (sv >> 16) != (uint32_t)lane && !(sc == 2 && (sv & 0xffff) != h) && s2 != (uint32_t)lane;
+#if QZK_NSLOT3
+                if (suspect && slot3[key3] == (uint32_t)lane) suspect = false;
+#endif
             }
             bool done = false;
             for (int k = 0; k < 4; k++) {
