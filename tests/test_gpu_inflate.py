@@ -121,19 +121,24 @@ def test_both_inflate_kernels_agree(ctx, monkeypatch, mode):
     assert out == src
 
 
+@pytest.mark.parametrize("occ", ["2", "3"])
 @pytest.mark.parametrize("k", ["4", "8", "16", "32"])
-def test_speculative_phase_a_is_bit_exact(ctx, monkeypatch, k):
-    # opt-in sub-segment speculation (qzk_inflate_spec.h): K lanes per segment; whatever it cannot take goes through
-    # the serial kernel, so every kind of stream must still come out right
+def test_speculative_phase_a_is_bit_exact(ctx, monkeypatch, k, occ):
+    # sub-segment speculation (qzk_inflate_spec.h): K lanes per segment; whatever it cannot take goes through
+    # the serial kernel, so every kind of stream must still come out right - with the kernel's register budget cut for two
+    # waves a SIMD and for three (a third of the registers spilled; what launches of more than sixteen waves a CU take)
+    if k == "4" and occ == "3":
+        pytest.skip("four lanes a segment: the root tables' LDS allows two waves a SIMD only")
     monkeypatch.setenv("QATZIP_AMD_INFLATE", "lane")
     monkeypatch.setenv("QATZIP_AMD_INFLATE_K", k)
+    monkeypatch.setenv("QATZIP_AMD_INFLATE_OCC", occ)
     for kind, n, chunk in (("silesia", 6 << 20, 65536), ("text", 3 << 20, 65536), ("lzmix", 140000, 65536),
                            ("rand", 300000, 65536), ("runs", 1 << 20, 16384), ("records", 2 << 20, 131072), ("allA", 1 << 20, 65536)):
         src = datagen.gen_bytes(kind, n, 57)
         rc, _, comp, _ = O.sw_compress("RAW", src, chunk, 1, cap=n * 9 // 8 + 65536)
         for hint in (chunk, 0):                              # optimistic pass (hints) and the two-pass chain (exact lengths)
             iu, out, crc = _inflate(ctx, comp, n, hint)
-            assert out == src and iu == len(comp) and crc == (zlib.crc32(src) & 0xffffffff), (k, kind, hint)
+            assert out == src and iu == len(comp) and crc == (zlib.crc32(src) & 0xffffffff), (k, occ, kind, hint)
     src = datagen.gen_bytes("text", 500000, 2)               # a foreign stream: one long member, no markers
     co = zlib.compressobj(9, zlib.DEFLATED, -15)
     comp = co.compress(src) + co.flush()
