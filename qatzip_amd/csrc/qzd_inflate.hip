@@ -197,8 +197,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
      * times per call, between two kernels) */
     const size_t o_res = (sb + 15) & ~(size_t)15, o_ts = o_res + ((rb + 15) & ~(size_t)15);
     const size_t o_ord = o_ts + (((size_t)nsegs * K * sizeof(qzk_tokseg) + 15) & ~(size_t)15);
-    const size_t o_ord2 = o_ord + (((size_t)nsegs * 4 + 15) & ~(size_t)15);           /* phase A's launch places (K > 1) */
-    int rc = qzd_aux_reserve(c, o_ord2 + (size_t)nsegs * 4 + 64);
+    int rc = qzd_aux_reserve(c, o_ord + (size_t)nsegs * 4 + 64);
     if (rc) return rc;
     qzk_infseg *d_segs = (qzk_infseg *)c->d_aux;
     qzk_infres *d_res = (qzk_infres *)(c->d_aux + o_res);
@@ -231,7 +230,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     /* output streaming: only the plain decode of a whole member (every segment writes, known output offsets) */
     const bool stream_out = run_b && c->so_host && c->so_nat && nsegs >= QZD_LANE_MIN_SEGS;
     const size_t ordb = ((size_t)nsegs * 4 + 255) & ~(size_t)255;
-    const size_t need = tabb + tsb + chb + rcb + litb + seqb + 2 * ordb + 256;
+    const size_t need = tabb + tsb + chb + rcb + litb + seqb + ordb + 256;
     /* the scratch grows with the largest call and shrinks again when EIGHT calls in a row have needed less than a quarter of it
      * (a 4 GiB decode leaves gigabytes behind; a session of small calls gives them back, one that alternates large and small
      * ones keeps them - every change is a free and an allocation).  What runs on the scratch runs on this context's
@@ -263,8 +262,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     qzk_rec *rec_d = (qzk_rec *)pb; pb += rcb;
     uint8_t *lit_d = pb; pb += litb;
     qzk_seq *seq_d = (qzk_seq *)lit_d;                  /* the same arena: a region's sequences count down from its end */
-    uint32_t *ord_d = (uint32_t *)pb; pb += ordb;
-    uint32_t *ord2_d = (uint32_t *)pb;
+    uint32_t *ord_d = (uint32_t *)pb;
     HIPCHK(c, ctl_copy(d_segs, st_segs, sb, st));
     HIPCHK(c, ctl_copy(ts_d, tsv, (size_t)nsegs * K * sizeof(qzk_tokseg), st));
     HIPCHK(c, hipEventRecord(c->ev[1][1], st));
@@ -301,23 +299,12 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         uint32_t over = hs[0].out_cap > 65536u + 64u ? 2u : nsegs <= 4096u ? 1u : 1000u;
         const char *ov = getenv("QATZIP_AMD_INFLATE_OVER");
         if (ov && atoi(ov) > 0) over = (uint32_t)atoi(ov);
-        /* QATZIP_AMD_INFLATE_ORDER=1: the waves started by compressed length, longest first (qzk_inflate_spec.h).  An experiment
-         * that stays switched off: a wave's duration does not follow its segments' compressed length at all (correlation 0.00 over
-         * the bench's 4096 waves) and any order but the segments' own costs locality - 18.9 -> 20.2 ms (profiles/r6_phaseA_order.txt) */
-        const uint32_t *order = NULL;
-        const char *oe2 = getenv("QATZIP_AMD_INFLATE_ORDER");
-        if (oe2 && oe2[0] == '1') {
-            uint32_t *st_ord2 = (uint32_t *)(c->h_aux + o_ord2);
-            qzk_spec_order_host(hs, nsegs, spw, st_ord2);
-            HIPCHK(c, ctl_copy(ord2_d, st_ord2, (size_t)grid.x * 4, st));
-            order = ord2_d;
-        }
         /* waves per SIMD (qzk_inflate_spec.h): three - with a third of the registers spilled - pay from the third round of
          * resident waves on (QATZIP_AMD_INFLATE_OCC=2 / 3 overrides) */
         int socc = grid.x > 16u * c->cus && K != 4 ? 3 : 2;
         if (occ == 2 || (occ == 3 && K != 4)) socc = occ;
 #define QZD_SPEC_LAUNCH(N, W) hipLaunchKernelGGL((qzk_inflate_spec_kernel<N, W>), grid, blk, 0, st, d_comp, d_segs, d_res, nsegs, tb_d, \
-                                             ts_d, lit_d, seq_d, ch_d, rec_d, epoch, over, order)
+                                             ts_d, lit_d, seq_d, ch_d, rec_d, epoch, over)
         if (K == 4) QZD_SPEC_LAUNCH(4, 2);
         else if (K == 16) { if (socc == 3) QZD_SPEC_LAUNCH(16, 3); else QZD_SPEC_LAUNCH(16, 2); }
         else if (K == 32) { if (socc == 3) QZD_SPEC_LAUNCH(32, 3); else QZD_SPEC_LAUNCH(32, 2); }
@@ -739,10 +726,14 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
         if (scan_ok && seg_hint && (ns > 1 || (lone_lanes && seg_hint > 16384u)) && lanes) {
             auto clen = [&](uint32_t k) { return (k + 1 < ns ? start[k + 1] : (uint32_t)n) - start[k]; };
             std::vector<uint32_t> order(ns);
-            {   /* largest compressed size first (32-byte classes): lanes of a wave carry similar work, the longest start first */
+            {   /* largest compressed size first (256-byte classes, a class in stream order): the segments of a wave carry similar work
+                 * and the longest start first.  Round 6 measured what it is worth (profiles/r6_phaseA_order.txt; 4 GiB of 64 KB segments):
+                 * stream order 20.7 ms, classes of 4 KB 15.8 - 16.2, 1 KB 15.2 - 15.4, 256 B 14.9 - 15.3, 32 B 15.4; a wave's duration follows
+                 * its longest segment's compressed length with a correlation of 0.54.  QATZIP_AMD_INFLATE_CLS=<log2 of the class> */
                 const uint32_t NB = 8192;
                 std::vector<uint32_t> cnt(NB + 1, 0);
-                auto rcls = [&](uint32_t k) { uint32_t v = clen(k) >> 5; return NB - 1 - (v < NB ? v : NB - 1); };
+                static const uint32_t cls_shift = getenv("QATZIP_AMD_INFLATE_CLS") ? (uint32_t)atoi(getenv("QATZIP_AMD_INFLATE_CLS")) : 8u;
+                auto rcls = [&](uint32_t k) { uint32_t v = clen(k) >> cls_shift; return NB - 1 - (v < NB ? v : NB - 1); };
                 for (uint32_t i = 0; i < ns; i++) cnt[rcls(i) + 1]++;
                 for (uint32_t i = 0; i < NB; i++) cnt[i + 1] += cnt[i];
                 for (uint32_t i = 0; i < ns; i++) order[cnt[rcls(i)]++] = i;

@@ -89,28 +89,6 @@ QZ_DEV uint32_t qzk_ld32_l2(const uint32_t *p) { return *p; }
 QZ_DEV uint32_t qzk_ld32_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
-/* host side: which wave's segments every workgroup of the launch takes.  A wave keeps its spw consecutive segments (their
- * input, their scratch and their output lie side by side: waves of sixteen segments from sixteen ends of a 4 GiB call, sorted
- * one by one, took half as long again - profiles/r6_phaseA_order.txt); the WAVES are started longest first, a wave's length
- * being that of its longest segment's input (a counting sort over 1024 classes of length: 4096 waves in microseconds; waves
- * of one class keep their order).  worder: (nsegs + spw - 1) / spw entries. */
-static inline void qzk_spec_order_host(const qzk_infseg *hs, uint32_t nsegs, uint32_t spw, uint32_t *worder)
-{
-    const uint32_t nw = (nsegs + spw - 1) / spw;
-    uint32_t maxlen = 1, cnt[1025];
-    for (uint32_t i = 0; i < nsegs; i++) if (hs[i].in_len > maxlen) maxlen = hs[i].in_len;
-    for (uint32_t k = 0; k <= 1024; k++) cnt[k] = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        for (uint32_t w = 0; w < nw; w++) {
-            uint32_t m = 0;
-            for (uint32_t i = w * spw; i < nsegs && i < (w + 1) * spw; i++) if (hs[i].in_len > m) m = hs[i].in_len;
-            const uint32_t cls = 1023u - (uint32_t)((uint64_t)m * 1023u / maxlen);       /* 0 = the longest */
-            if (pass == 0) cnt[cls + 1]++; else worder[cnt[cls]++] = w;
-        }
-        if (pass == 0) for (uint32_t k = 0; k < 1024; k++) cnt[k + 1] += cnt[k];
-    }
-}
-
 #ifdef QZK_SPEC_STATS
 static uint32_t qzk_spec_stats[1 << 20];
 #endif
@@ -140,8 +118,7 @@ template <int K, int OCC>
 QZ_KERNEL_OCC(64, OCC) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_infseg *segs, qzk_infres *res, uint32_t nsegs,
                                   qzk_inf_tab *tabs, const qzk_tokseg *ts /* [nsegs * K] */, uint8_t *lits, qzk_seq *seqs,
                                   qzk_chain *chains, qzk_rec *recs /* [nsegs * K * QZK_SPEC_NREC] */, uint64_t epoch /* of the launch, process-wide, never reused */,
-                                  uint32_t over_shares /* shares beyond its own the last lane of a block may decode before the rest is shared out again */,
-                                  const uint32_t *worder /* NULL, or the wave whose segments every workgroup takes: the host's longest-first list */)
+                                  uint32_t over_shares /* shares beyond its own the last lane of a block may decode before the rest is shared out again */)
 {
     constexpr int SPW = 64 / K;                                     /* segments per wave */
     QZ_LDS uint16_t roots[SPW][QZK_LANE_ROOTSZ];
@@ -166,10 +143,9 @@ QZ_KERNEL_OCC(64, OCC) qzk_inflate_spec_kernel(const uint8_t *comp, const qzk_in
 #endif
 
     const int lane = (int)threadIdx.x, g = lane / K, j = lane % K, gbase = lane - j;
-    /* Which segments: the waves of a launch are started in the order of their numbers and a wave lasts as long as its longest
-     * segment, so the host lists the waves longest (compressed) first - the launch no longer ends with a wave of long
-     * segments that happened to come last (round 6: profiles/r6_phaseA_order.txt) */
-    const uint32_t sidx = (worder ? worder[blockIdx.x] : blockIdx.x) * SPW + (uint32_t)g;
+    /* (the host lists the segments longest compressed length first, qzd_inflate.hip inflate_stream: the segments of a wave
+     * are of one size and the launch does not end with the long ones) */
+    const uint32_t sidx = blockIdx.x * SPW + (uint32_t)g;
     const bool live = sidx < nsegs;
     const qzk_infseg sg = segs[live ? sidx : 0];
     qzk_inf_tab *T = tabs + (live ? sidx : 0);

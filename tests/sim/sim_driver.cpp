@@ -369,13 +369,10 @@ static int two_phase_spec(const uint8_t *comp, uint8_t *out, const qzk_infseg *s
     std::vector<uint64_t> arena((lt + 1088) / 8 + 1, 0xeeeeeeeeeeeeeeeeull);          /* phase B reads whole 16-byte rows (qzk_lz_batch.h) */
     uint8_t *const lits_p = (uint8_t *)arena.data(); qzk_seq *const seqs_p = (qzk_seq *)arena.data();
     const uint32_t spw = 64 / K;
-    std::vector<uint32_t> order((nsegs + spw - 1) / spw);
-    qzk_spec_order_host(segs, nsegs, spw, order.data());        /* as the host does: waves by compressed length (QZSIM_NOORDER=1: by number) */
-    const uint32_t *const order_p = getenv("QZSIM_NOORDER") ? nullptr : order.data();
     sim::launch((nsegs + spw - 1) / spw, 64, 0, [&] {
         static uint64_t epoch = (5ull << 22) - 40;               /* launch numbers that cross the tag's own 22 bits: the high part lives in the record's second word */
         if (threadIdx.x == 0 && blockIdx.x == 0) epoch++;
-        qzk_inflate_spec_kernel<K, 2>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits_p, seqs_p, chains.data(), recs.data(), epoch + 1, (uint32_t)(getenv("QZSIM_OVER") ? atoi(getenv("QZSIM_OVER")) : 1), order_p);
+        qzk_inflate_spec_kernel<K, 2>(comp, segs, res, nsegs, tabs.data(), ts.data(), lits_p, seqs_p, chains.data(), recs.data(), epoch + 1, (uint32_t)(getenv("QZSIM_OVER") ? atoi(getenv("QZSIM_OVER")) : 1));
     });
     sim::launch((nsegs + QZK_RES_WAVES - 1) / QZK_RES_WAVES, 64 * QZK_RES_WAVES, 0, [&] {
         qzk_lz_resolve_kernel(comp, out, segs, res, nsegs, ts.data(), (uint32_t)K, lits_p, seqs_p, chains.data(), nullptr, 0);
