@@ -3,12 +3,13 @@
 import collections
 import csv
 import glob
+import os
 import sys
 
 tag = sys.argv[1]
 filt = sys.argv[2:] or ["qzk_"]
 for d in "ABCDE":
-    for f in glob.glob("gpurun_out/%s%s/*/*counter_collection.csv" % (tag, d)):
+    for f in sorted(glob.glob("gpurun_out/%s%s/*/*counter_collection.csv" % (tag, d)), key=os.path.getmtime)[-1:]:     # the newest pass only
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")

@@ -11,8 +11,8 @@ for leg in lz4 raw16 raw64 raw128; do
   python tools/pmc_summary.py gpurun_out/prof_${leg}_fetch gpurun_out/prof_${leg}_write profiles/${T}_${leg}_pmc.json 0 "python tools/legs_run.py $leg 1024" > /dev/null
 done
 python - <<PY
-import collections, csv, glob
-f = max(glob.glob("gpurun_out/prof_tcc/*/*counter_collection.csv"))
+import collections, csv, glob, os
+f = max(glob.glob("gpurun_out/prof_tcc/*/*counter_collection.csv"), key=os.path.getmtime)     # (gpurun merges into a directory that may hold older passes)
 agg = collections.defaultdict(lambda: [0.0, 0.0])
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")
