@@ -176,6 +176,18 @@ __global__ void qzk_ctl_copy_kernel(uint32_t *dst, const uint32_t *src, size_t n
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+/* The sub-stream descriptors of a call whose segments are all of one size (every call of fixed hw_buff_sz chunks): segment i's
+ * lane j has the region [i * seg + pre[j], + len[j]) - written here instead of being built on the host and sent across (sixteen
+ * bytes a lane: 8 MB for the bench's 4 GiB call, a third of a millisecond of PCIe and as much of host loop before phase A). */
+struct qzk_tsfill { uint64_t pre[32], len[32]; uint64_t seg; };
+__global__ void qzk_ts_fill_kernel(qzk_tokseg *ts, uint32_t nsegs, uint32_t K, const qzk_tsfill F)
+{
+    const size_t n = (size_t)nsegs * K;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t i = t / K, j = t % K, a = i * F.seg + F.pre[j];
+        ts[t].lit_off = a; ts[t].seq_off = (a + F.len[j]) / 8;
+    }
+}
 static hipError_t ctl_copy(void *dst, const void *src, size_t bytes, hipStream_t st)
 {
     if (!bytes) return hipSuccess;
@@ -210,6 +222,26 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
      * (qzk_inflate_lane.h).  K == 1: a region that holds any segment; K > 1: regions sized by need (qzk_inflate_spec.h), and
      * behind them R whole-segment regions for the segments that kernel hands back to the serial one */
     uint64_t arena = 0, max_cap = 0;
+    /* one size for all (no count-only segments, K <= 32): the descriptors are written on the device (qzk_ts_fill_kernel), and the host's
+     * copy of them only if a segment is handed back */
+    bool uniform = nsegs > 0 && K <= 32;
+    for (uint32_t i = 0; i < nsegs && uniform; i++) uniform = !(hs[i].flags & QZK_INF_COUNT_ONLY) && hs[i].out_cap == hs[0].out_cap;
+    qzk_tsfill F;
+    auto fill_host = [&]() {                                    /* the same layout in the host's table */
+        for (uint32_t i = 0; i < nsegs; i++)
+            for (uint32_t j = 0; j < K; j++) {
+                const uint64_t a = (uint64_t)i * F.seg + F.pre[j];
+                tsv[(size_t)i * K + j].lit_off = a; tsv[(size_t)i * K + j].seq_off = (a + F.len[j]) / 8;
+            }
+    };
+    if (uniform) {
+        F.seg = 0; max_cap = hs[0].out_cap;
+        for (uint32_t j = 0; j < K; j++) {
+            F.len[j] = K == 1 ? QZK_TOK_REGION(hs[0].out_cap) : QZK_SPEC_REGION(hs[0].out_cap, K, j);
+            F.pre[j] = F.seg; F.seg += F.len[j];
+        }
+        arena = (uint64_t)nsegs * F.seg;
+    } else
     for (uint32_t i = 0; i < nsegs; i++) {
         const bool writes = !(hs[i].flags & QZK_INF_COUNT_ONLY);
         if (writes && hs[i].out_cap > max_cap) max_cap = hs[i].out_cap;
@@ -264,7 +296,10 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     qzk_seq *seq_d = (qzk_seq *)lit_d;                  /* the same arena: a region's sequences count down from its end */
     uint32_t *ord_d = (uint32_t *)pb;
     HIPCHK(c, ctl_copy(d_segs, st_segs, sb, st));
-    HIPCHK(c, ctl_copy(ts_d, tsv, (size_t)nsegs * K * sizeof(qzk_tokseg), st));
+    if (uniform) {
+        hipLaunchKernelGGL(qzk_ts_fill_kernel, dim3((unsigned)std::min<size_t>(((size_t)nsegs * K + 255) / 256, 1024)), dim3(256), 0, st, ts_d, nsegs, K, F);
+        HIPCHK(c, hipGetLastError());
+    } else HIPCHK(c, ctl_copy(ts_d, tsv, (size_t)nsegs * K * sizeof(qzk_tokseg), st));
     HIPCHK(c, hipEventRecord(c->ev[1][1], st));
     /* segments per single-wave workgroup of the serial phase A: each lane keeps 1.25 KiB of root tables in LDS, and partly
      * filled waves give the serial decode loops more waves to hide behind (measured in DESIGN.md K3b) */
@@ -286,6 +321,7 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
         else QZD_TOK_LAUNCH(16, QZD_TOK_OCC);
 #undef QZD_TOK_LAUNCH
     };
+    bool res_fresh = false;                                         /* the host's copy of the results is current (nothing ran since it was taken) */
     if (K == 1) tok_launch(NULL, 0);
     else {
         const uint32_t spw = 64 / K;
@@ -324,7 +360,9 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
             fprintf(stderr, "\n");
         }
         if (nredo > R) return two_phase(c, d_comp, d_out, hs, nsegs, h_res, 1, st, run_b);      /* more than the hand-back area holds: this data is not what K lanes are for */
+        res_fresh = nredo == 0;
         if (nredo) {
+            if (uniform) fill_host();
             for (uint32_t k = 0; k < nredo; k++) {
                 qzk_tokseg &t0 = tsv[(size_t)st_ord[k] * K];
                 t0.lit_off = hb0 + (uint64_t)k * hb_rg; t0.seq_off = (hb0 + (uint64_t)(k + 1) * hb_rg) / 8;
@@ -340,8 +378,10 @@ static int two_phase(qzd_ctx *c, const uint8_t *d_comp, uint8_t *d_out, const qz
     if (!run_b) {
         /* phase A only: its results say which candidates are real segments and where their output belongs;
          * two_phase_resolve() runs phase B once the host has decided */
-        HIPCHK(c, ctl_copy(st_res, d_res, rb, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        if (!res_fresh) {
+            HIPCHK(c, ctl_copy(st_res, d_res, rb, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+        } else HIPCHK(c, hipEventSynchronize(c->ev[1][0]));         /* (the stream stood still when it was recorded) */
         HIPCHK(c, hipGetLastError());
         memcpy(h_res, st_res, rb);
         float ta = 0;
@@ -706,8 +746,8 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
     start.push_back(0);
     if (scan_ok) for (uint32_t p : mk) if (p < n) start.push_back(p);
     const uint32_t ns = (uint32_t)start.size();
-    std::vector<qzk_infseg> segs(ns);
-    std::vector<qzk_infres> res(ns);
+    std::vector<qzk_infseg> segs;           /* (sized where the passes below begin: the K-lane path has lists of its own, and 3 MB of zeros are a tenth of a millisecond) */
+    std::vector<qzk_infres> res;
     uint64_t total_out = 0, total_in = 0;
     bool done = false;
 
@@ -789,6 +829,7 @@ static int inflate_stream(qzd_ctx *c, const uint8_t *d_src, uint64_t n, uint8_t 
     }
 
 after_lanes:
+    if (!done) { segs.resize(ns); res.resize(ns); }
     /* --- 2b. optimistic single pass (fewer candidates: one wave per segment) --- */
     if (!done && scan_ok && seg_hint && ns > 1 && (!lanes || lanes_nomem)) {
         for (uint32_t k = 0; k < ns; k++) {
